@@ -1,0 +1,61 @@
+"""Hot-path parameters: from the reference's (unchanged) state-dict / module tree to kernel operands.
+
+The checkpoint format is untouched: parameters are read by the reference's own
+names — ``mlp_geo.layers1.layers.N.linear.{weight_g,weight_v,bias}``, ``ibr_compress_gfeat.*``,
+``mlp_tex.*`` — optionally behind the Lightning prefix ``model.`` (reference src/model.py:42).
+
+Two products:
+  * ``effective_weights``: weight-norm folded, plain row-major (out,in) fp32 matrices
+    (``w = g * v / ||v||_row``, reference src/utils.py:542-543 via torch.nn.utils.weight_norm dim=0);
+  * ``pack_for_mfma``: the same matrices re-ordered into the A-operand stream of
+    ``v_mfma_f32_32x32x2_f32`` as consumed by csrc/field_kernels.hip.
+"""
+import numpy as np
+import torch
+
+from .synthetic import HOTPATH_LAYERS
+
+
+def _strip_prefix(sd):
+    if any(k.startswith("model.") for k in sd):
+        return {k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}
+    return sd
+
+
+def effective_weights(state_dict):
+    """dict name -> (W (out,in) float32 numpy, b (out,) float32 numpy); plus 'ani_al' -> float."""
+    sd = _strip_prefix(state_dict)
+    out = {}
+    for name, prefix, shape, wn in HOTPATH_LAYERS:
+        if wn and (prefix + ".weight_g") in sd:
+            g = sd[prefix + ".weight_g"].detach().float().cpu()
+            v = sd[prefix + ".weight_v"].detach().float().cpu()
+            w = torch._weight_norm(v, g, 0)
+        elif (prefix + ".parametrizations.weight.original0") in sd:  # new-style weight_norm
+            g = sd[prefix + ".parametrizations.weight.original0"].detach().float().cpu()
+            v = sd[prefix + ".parametrizations.weight.original1"].detach().float().cpu()
+            w = torch._weight_norm(v, g, 0)
+        else:
+            w = sd[prefix + ".weight"].detach().float().cpu()
+        b = sd[prefix + ".bias"].detach().float().cpu()
+        if tuple(w.shape) != tuple(shape) or b.shape[0] != shape[0]:
+            raise ValueError(
+                f"unsupported architecture: {prefix} has shape {tuple(w.shape)}, the HIP path is built "
+                f"for {shape} (configs/zju.json of the reference)")
+        out[name] = (np.ascontiguousarray(w.numpy(), dtype=np.float32),
+                     np.ascontiguousarray(b.numpy(), dtype=np.float32))
+    out["ani_al"] = float(sd["mlp_tex.ani_al"].detach().float().cpu())
+    return out
+
+
+def flatten_plain(eff):
+    """Flat fp32 vector in HOTPATH_LAYERS order: for each layer W row-major then b; then |ani_al|
+    is NOT folded: the raw ani_al is appended last.  This is the layout the C oracle reads
+    (oracle/kpnerf_oracle.c: struct kpo_weights offsets are derived from the same table)."""
+    parts = []
+    for name, _, _, _ in HOTPATH_LAYERS:
+        w, b = eff[name]
+        parts.append(w.reshape(-1))
+        parts.append(b.reshape(-1))
+    parts.append(np.array([eff["ani_al"]], dtype=np.float32))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)

@@ -1,0 +1,611 @@
+/*
+ * kpnerf_oracle.c — CPU restatement of KeypointNeRF's ray-march path (eval mode).
+ *
+ * TEST INFRASTRUCTURE.  This file is the parity ORACLE for the HIP kernels in
+ * keypointnerf_amd/csrc/.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+ * leg may build, load or call it, and only as the checker / the reported CPU baseline — never
+ * as the thing measured or shipped.  The product package (keypointnerf_amd/) does not import it.
+ *
+ * It restates, in plain scalar fp32 C, the reference's PyTorch code (all citations are
+ * file:line under /root/reference):
+ *   src/model.py:690-782   KeypointNeRF.query
+ *   src/model.py:784-843   KeypointNeRF.query_color
+ *   src/model.py:942-1108  KeypointNeRF.batch_render_pifu_nerf (+ eval_func :978-997)
+ *   src/model.py:1110-1148 importance_sample
+ *   src/model.py:1150-1176 rgba2out
+ *   src/model.py:1178-1237 ray_bbox_intersection
+ *   src/model.py:1239-1302 IBRRenderingHead
+ *   src/spatial.py:23-47,63-86,110-118  SpatialEncoder (rel_z_decay)
+ *   src/utils.py:74-95     feat_sample (grid_sample bilinear/border/align_corners), fused_mean_variance
+ *   src/utils.py:476-748   MLPUNetFusion / MLPUNet / PoolModule / pool_ops / MLP / Linear / Softplus(100,20)
+ *
+ * Parity pinning: the reference ships no tests or golden vectors, so this
+ * oracle is pinned against the reference ITSELF: tests/test_oracle_vs_golden.py compares every
+ * function here with outputs of the imported reference on seeded inputs, stored in
+ * tests/golden/ (npz files) by oracle/make_golden.py.
+ *
+ * The only liberty taken: a point whose validity mask is 0 in every view skips the MLPs, because
+ * the reference's result for it is a constant (pooled features are exactly 0, softmax over equal
+ * -1e9 logits is exactly uniform) — see kpo_query().  Everything else follows the reference's
+ * operation order in fp32.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KPO_NKPT 24
+#define KPO_PE_LEVELS 3
+#define KPO_PE_DIM ((1 + 2 * KPO_PE_LEVELS) * KPO_NKPT) /* 168, spatial.py:49-53 */
+#define KPO_MAXV 16
+
+typedef struct {
+    int32_t V, H, W;       /* source views, source image size */
+    int32_t g0h, g0w;      /* feat_geo[0] (V,64,g0h,g0w) */
+    int32_t g1h, g1w;      /* feat_geo[1] (V, 8,g1h,g1w) */
+    int32_t th, tw;        /* feat_tex    (V, 8,th,tw)   */
+    int32_t disable_fg_mask;
+    float znear, zfar;     /* source normalisation constants 2.0 / 5.0 (model.py:43,345) */
+    float nml_scale;       /* 100.0 (model.py:346) */
+    float sigma;           /* 0.1 (configs/zju.json:43) */
+    const float* KRT;      /* V x 4 x 4 */
+    const float* extrin;   /* V x 4 x 4 */
+    const float* kpt3d;    /* 24 x 3 */
+    const float* img;      /* V x 3 x H x W */
+    const float* fgmask;   /* V x H x W, 0/1 as float (model.py:737 samples fg_mask.float()) */
+    const float* geo0;
+    const float* geo1;
+    const float* tex;
+} kpo_scene;
+
+/* ------------------------------------------------------------------------------------------
+ * Weights: flat fp32 vector in the order of keypointnerf_amd/synthetic.py:HOTPATH_LAYERS
+ * (W row-major (out,in), then bias, per layer; raw ani_al last).  Weight-norm is folded on the
+ * Python side with torch._weight_norm, the very op the reference's forward uses. */
+enum { L_G1_0, L_G1_1, L_G1_2, L_G1_3, L_G2_0, L_G2_1, L_G2_2, L_CMP, L_RE_0, L_RE_1, L_BL_0, L_BL_1,
+       L_V1_0, L_V1_1, L_V2_0, L_V2_1, L_O_0, L_O_1, L_O_2, L_COUNT };
+static const int kpo_dims[L_COUNT][2] = { /* (out, in) */
+    {128, 232}, {128, 128}, {120, 136}, {64, 120}, {64, 128}, {64, 64}, {2, 64}, {24, 128},
+    {16, 4}, {35, 16}, {64, 105}, {32, 64}, {32, 32}, {33, 32}, {32, 32}, {1, 32}, {16, 37}, {8, 16}, {1, 8}};
+
+typedef struct { const float* w[L_COUNT]; const float* b[L_COUNT]; float ani_al; } kpo_weights;
+
+int kpo_weight_count(void) {
+    int n = 0;
+    for (int l = 0; l < L_COUNT; ++l) n += kpo_dims[l][0] * kpo_dims[l][1] + kpo_dims[l][0];
+    return n + 1;
+}
+static void kpo_bind_weights(const float* flat, kpo_weights* wt) {
+    const float* p = flat;
+    for (int l = 0; l < L_COUNT; ++l) {
+        wt->w[l] = p; p += kpo_dims[l][0] * kpo_dims[l][1];
+        wt->b[l] = p; p += kpo_dims[l][0];
+    }
+    wt->ani_al = *p;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* activations */
+static inline float softplus100(float x) { /* utils.py:523-524 Softplus(beta=100, threshold=20) */
+    float t = x * 100.0f;
+    return (t > 20.0f) ? x : log1pf(expf(t)) / 100.0f;
+}
+static inline float eluf(float x) { return x > 0.0f ? x : expm1f(x); } /* nn.ELU alpha=1 */
+static inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* y = W x + b, W (out,in) row-major: th.nn.Linear / F.linear */
+static void linear(const float* W, const float* b, int out, int in, const float* x, float* y) {
+    for (int o = 0; o < out; ++o) {
+        const float* w = W + (size_t)o * in;
+        float acc = 0.0f;
+        for (int i = 0; i < in; ++i) acc += w[i] * x[i];
+        y[o] = acc + b[o];
+    }
+}
+
+/* utils.py:74-89 feat_sample == F.grid_sample(bilinear, padding_mode='border', align_corners=True)
+ * for one view's (C,h,w) map at normalised coords (xn,yn); ATen grid_sampler_2d semantics:
+ * unnormalise ((x+1)/2)*(size-1), clip to [0,size-1], 4 taps nw/ne/sw/se, taps outside skipped. */
+static void sample_bilinear(const float* map, int C, int h, int w, float xn, float yn, float* out) {
+    float ix = ((xn + 1.0f) / 2.0f) * (float)(w - 1);
+    float iy = ((yn + 1.0f) / 2.0f) * (float)(h - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(w - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(h - 1));
+    float fx = floorf(ix), fy = floorf(iy);
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+    float wne = (ix - (float)x0) * ((float)y1 - iy);
+    float wsw = ((float)x1 - ix) * (iy - (float)y0);
+    float wse = (ix - (float)x0) * (iy - (float)y0);
+    int x1ok = x1 <= w - 1, y1ok = y1 <= h - 1; /* x0,y0 always inside after the clip */
+    size_t plane = (size_t)h * w;
+    for (int c = 0; c < C; ++c) {
+        const float* m = map + (size_t)c * plane;
+        float acc = m[(size_t)y0 * w + x0] * wnw;
+        if (x1ok) acc += m[(size_t)y0 * w + x1] * wne;
+        if (y1ok) acc += m[(size_t)y1 * w + x0] * wsw;
+        if (x1ok && y1ok) acc += m[(size_t)y1 * w + x1] * wse;
+        out[c] = acc;
+    }
+}
+
+/* 4x4 inverse (torch.inverse, model.py:823) via Gauss-Jordan in double; only column 3 is used */
+static void inverse4(const float* A, double* inv) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = A[i * 4 + j]; a[i][4 + j] = (i == j); }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        if (p != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+        double d = a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r) if (r != c) {
+            double f = a[r][c];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
+}
+static void inverse3(const float* A /*row stride 4*/, double* inv) {
+    double a = A[0], b = A[1], c = A[2], d = A[4], e = A[5], f = A[6], g = A[8], h = A[9], i = A[10];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    inv[0] = (e * i - f * h) / det; inv[1] = (c * h - b * i) / det; inv[2] = (b * f - c * e) / det;
+    inv[3] = (f * g - d * i) / det; inv[4] = (a * i - c * g) / det; inv[5] = (c * d - a * f) / det;
+    inv[6] = (d * h - e * g) / det; inv[7] = (b * g - a * h) / det; inv[8] = (a * e - b * d) / det;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * IBRRenderingHead.forward for ONE (ray, sample): model.py:1267-1302.
+ * rgb_feat (V,35), ray_diff (V,4), mask (V) -> rgb[3] */
+static void ibr_head(const kpo_weights* wt, int V, const float (*rgb_feat)[35], const float (*ray_diff)[4],
+                     const float* mask, float* rgb_out) {
+    float x35[KPO_MAXV][35], weight[KPO_MAXV], e[KPO_MAXV];
+    float h16[16], dirf[35];
+    for (int v = 0; v < V; ++v) {
+        /* ray_encoder :1279 : Linear(4,16) ELU Linear(16,35) ELU */
+        linear(wt->w[L_RE_0], wt->b[L_RE_0], 16, 4, ray_diff[v], h16);
+        for (int i = 0; i < 16; ++i) h16[i] = eluf(h16[i]);
+        linear(wt->w[L_RE_1], wt->b[L_RE_1], 35, 16, h16, dirf);
+        for (int i = 0; i < 35; ++i) x35[v][i] = rgb_feat[v][i] + eluf(dirf[i]); /* :1281-1284 */
+        e[v] = expf(fabsf(wt->ani_al) * (ray_diff[v][3] - 1.0f));                 /* :1287 */
+    }
+    float emin = e[0];
+    for (int v = 1; v < V; ++v) emin = fminf(emin, e[v]);
+    float wsum = 0.0f;
+    for (int v = 0; v < V; ++v) { weight[v] = (e[v] - emin) * mask[v]; wsum += weight[v]; } /* :1288 */
+    for (int v = 0; v < V; ++v) weight[v] = weight[v] / (wsum + 1e-8f);                     /* :1289 */
+    /* fused_mean_variance utils.py:91-95 */
+    float in105[105];
+    for (int i = 0; i < 35; ++i) {
+        float m = 0.0f;
+        for (int v = 0; v < V; ++v) m += x35[v][i] * weight[v];
+        float var = 0.0f;
+        for (int v = 0; v < V; ++v) { float d = x35[v][i] - m; var += weight[v] * (d * d); }
+        in105[i] = m; in105[35 + i] = var;
+    }
+    float logit[KPO_MAXV];
+    for (int v = 0; v < V; ++v) {
+        float h64[64], x[32], t32[32], t33[33], xin[32], o16[16], o8[8], in37[37], s1;
+        memcpy(in105 + 70, x35[v], 35 * sizeof(float));                    /* :1292 cat */
+        linear(wt->w[L_BL_0], wt->b[L_BL_0], 64, 105, in105, h64);
+        for (int i = 0; i < 64; ++i) h64[i] = eluf(h64[i]);
+        linear(wt->w[L_BL_1], wt->b[L_BL_1], 32, 64, h64, x);
+        for (int i = 0; i < 32; ++i) x[i] = eluf(x[i]);
+        for (int i = 0; i < 32; ++i) xin[i] = x[i] * weight[v];            /* :1294 */
+        linear(wt->w[L_V1_0], wt->b[L_V1_0], 32, 32, xin, t32);
+        for (int i = 0; i < 32; ++i) t32[i] = eluf(t32[i]);
+        linear(wt->w[L_V1_1], wt->b[L_V1_1], 33, 32, t32, t33);
+        for (int i = 0; i < 33; ++i) t33[i] = eluf(t33[i]);
+        for (int i = 0; i < 32; ++i) x[i] = x[i] + t33[i];                 /* :1295-1296 */
+        float sv = sigmoidf(t33[32]);
+        for (int i = 0; i < 32; ++i) xin[i] = x[i] * sv * mask[v];         /* :1297 */
+        linear(wt->w[L_V2_0], wt->b[L_V2_0], 32, 32, xin, t32);
+        for (int i = 0; i < 32; ++i) t32[i] = eluf(t32[i]);
+        linear(wt->w[L_V2_1], wt->b[L_V2_1], 1, 32, t32, &s1);
+        float vis = sigmoidf(s1) * mask[v];
+        memcpy(in37, x, 32 * sizeof(float));                               /* :1300 cat[x, vis, ray_diff] */
+        in37[32] = vis;
+        memcpy(in37 + 33, ray_diff[v], 4 * sizeof(float));
+        linear(wt->w[L_O_0], wt->b[L_O_0], 16, 37, in37, o16);
+        for (int i = 0; i < 16; ++i) o16[i] = eluf(o16[i]);
+        linear(wt->w[L_O_1], wt->b[L_O_1], 8, 16, o16, o8);
+        for (int i = 0; i < 8; ++i) o8[i] = eluf(o8[i]);
+        linear(wt->w[L_O_2], wt->b[L_O_2], 1, 8, o8, &logit[v]);
+        if (mask[v] == 0.0f) logit[v] = -1e9f;                             /* masked_fill :1300 */
+    }
+    /* softmax over views + blend of SOURCE colours :1301 (rgb_feats[..., :3] before the dir add) */
+    float lmax = logit[0];
+    for (int v = 1; v < V; ++v) lmax = fmaxf(lmax, logit[v]);
+    float den = 0.0f, p[KPO_MAXV];
+    for (int v = 0; v < V; ++v) { p[v] = expf(logit[v] - lmax); den += p[v]; }
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.0f;
+        for (int v = 0; v < V; ++v) acc += rgb_feat[v][c] * (p[v] / den);
+        rgb_out[c] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * KeypointNeRF.query (model.py:690-782) for N points, eval mode (no view dropout).
+ * pts (N,3), view (N,3) -> out (N,5) = [sdf_raw, rad, r, g, b], valid (N) in {0,1}.
+ * If apply_eval_func != 0 the eval_func closure (model.py:978-997, rand_noise_std = 0) is applied:
+ * out = [mask*relu(rad), mask*sdf_raw + (1-mask)*(0.1/nml_scale), r, g, b]. */
+void kpo_query(const kpo_scene* sc, const float* wflat, int64_t N, const float* pts, const float* view,
+               int apply_eval_func, float* out, uint8_t* valid) {
+    kpo_weights wt;
+    kpo_bind_weights(wflat, &wt);
+    const int V = sc->V;
+    /* per-view constants: keypoints in camera space (spatial.py:85), source camera centres (model.py:823-824) */
+    float kcam[KPO_MAXV][KPO_NKPT][3], cpos[KPO_MAXV][3];
+    for (int v = 0; v < V; ++v) {
+        const float* E = sc->extrin + v * 16;
+        for (int k = 0; k < KPO_NKPT; ++k)
+            for (int i = 0; i < 3; ++i)
+                kcam[v][k][i] = ((sc->kpt3d[k * 3 + 0] * E[i * 4 + 0] + sc->kpt3d[k * 3 + 1] * E[i * 4 + 1]) +
+                                 sc->kpt3d[k * 3 + 2] * E[i * 4 + 2]) + E[i * 4 + 3];
+        double inv[16];
+        inverse4(sc->KRT + v * 16, inv);
+        for (int i = 0; i < 3; ++i) cpos[v][i] = (float)inv[i * 4 + 3];
+    }
+    /* query() result for a point masked in every view: pooled = 0 -> layers2(0) is a constant */
+    float c0[2];
+    {
+        float z128[128] = {0}, a64[64], b64[64];
+        linear(wt.w[L_G2_0], wt.b[L_G2_0], 64, 128, z128, a64);
+        for (int i = 0; i < 64; ++i) a64[i] = softplus100(a64[i]);
+        linear(wt.w[L_G2_1], wt.b[L_G2_1], 64, 64, a64, b64);
+        for (int i = 0; i < 64; ++i) b64[i] = softplus100(b64[i]);
+        linear(wt.w[L_G2_2], wt.b[L_G2_2], 2, 64, b64, c0);
+    }
+    const float pe_vec[KPO_PE_LEVELS] = {(float)(M_PI * 1.0), (float)(M_PI * 2.0), (float)(M_PI * 4.0)}; /* spatial.py:42-47 */
+    const float two_sigma2 = (float)(2.0 * ((double)sc->sigma * (double)sc->sigma));                      /* spatial.py:114 */
+    const size_t HW = (size_t)sc->H * sc->W;
+
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t n = 0; n < N; ++n) {
+        const float* p = pts + n * 3;
+        const float* vd = view + n * 3;
+        float xn[KPO_MAXV], yn[KPO_MAXV], zn[KPO_MAXV], a[KPO_MAXV], pw[KPO_MAXV];
+        int all_in = 1, all_fg = 1, in_v[KPO_MAXV];
+        for (int v = 0; v < V; ++v) {
+            const float* M = sc->KRT + v * 16;
+            float vh[3];
+            for (int i = 0; i < 3; ++i) /* model.py:713 */
+                vh[i] = ((p[0] * M[i * 4 + 0] + p[1] * M[i * 4 + 1]) + p[2] * M[i * 4 + 2]) + M[i * 4 + 3];
+            float z = vh[2];
+            float x = vh[0] / z, y = vh[1] / z;                                   /* :715 */
+            xn[v] = 2.0f * (x / ((float)sc->W - 1.0f)) - 1.0f;                   /* :721 */
+            yn[v] = 2.0f * (y / ((float)sc->H - 1.0f)) - 1.0f;                   /* :722 */
+            zn[v] = 2.0f * (z - sc->znear) / (sc->zfar - sc->znear) - 1.0f;      /* :723 */
+            const float eps = 1e-2f;
+            in_v[v] = (xn[v] >= -1.0f - eps) && (xn[v] <= 1.0f + eps) && (yn[v] >= -1.0f - eps) &&
+                      (yn[v] <= 1.0f + eps) && (zn[v] >= -1.0f);                 /* :725-729 */
+            all_in &= in_v[v];
+            if (!sc->disable_fg_mask) {
+                float m;
+                sample_bilinear(sc->fgmask + (size_t)v * HW, 1, sc->H, sc->W, xn[v], yn[v], &m); /* :737 */
+                all_fg &= (m > 0.1f);                                                           /* :739 */
+            }
+        }
+        float asum = 0.0f, pwsum = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            a[v] = (float)(in_v[v] && all_in && all_fg);                         /* :735 / :739 */
+            asum += a[v];
+            /* boundary-smooth view weight :752-759 */
+            float c3[3] = {0.5f * xn[v] + 0.5f, 0.5f * yn[v] + 0.5f, 0.5f * zn[v] + 0.5f};
+            float w3[3];
+            for (int i = 0; i < 3; ++i) {
+                float d = fminf(c3[i], 1.0f - c3[i]);
+                w3[i] = sigmoidf(5.0f * (d / 0.1f - 1.0f));
+            }
+            pw[v] = (w3[0] * w3[1] * w3[2]) * a[v];
+            pwsum += pw[v];
+        }
+        for (int v = 0; v < V; ++v) pw[v] = pw[v] / (pwsum + 1e-6f);
+        float* o = out + n * 5;
+        const int is_valid = asum > 0.0f;                                        /* utils.py:643-646 */
+        if (valid) valid[n] = (uint8_t)is_valid;
+
+        float rgb_feat[KPO_MAXV][35];
+        for (int v = 0; v < V; ++v)                                              /* model.py:806 */
+            sample_bilinear(sc->img + (size_t)v * 3 * HW, 3, sc->H, sc->W, xn[v], yn[v], rgb_feat[v]);
+
+        float sdf_raw, rad, rgb[3];
+        if (!is_valid) {
+            /* every view masked: pooled == 0, IBR logits all -1e9 -> uniform softmax (see header) */
+            sdf_raw = c0[0]; rad = c0[1];
+            float pu = 1.0f / (float)V; /* exp(0)/sum == 1/V exactly as computed by softmax */
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.0f;
+                for (int v = 0; v < V; ++v) acc += rgb_feat[v][c] * pu;
+                rgb[c] = acc;
+            }
+        } else {
+            float xv[KPO_MAXV][64];
+            for (int v = 0; v < V; ++v) {
+                float in232[232], h0[128], h1[136], h2[120];
+                /* SpatialEncoder rel_z_decay: spatial.py:76,85,110-118 */
+                const float* E = sc->extrin + v * 16;
+                float c[3];
+                for (int i = 0; i < 3; ++i)
+                    c[i] = ((p[0] * E[i * 4 + 0] + p[1] * E[i * 4 + 1]) + p[2] * E[i * 4 + 2]) + E[i * 4 + 3];
+                for (int k = 0; k < KPO_NKPT; ++k) {
+                    float dz = 1.0f * (c[2] - kcam[v][k][2]);
+                    float dx = c[0] - kcam[v][k][0], dy = c[1] - kcam[v][k][1], dzz = c[2] - kcam[v][k][2];
+                    float d2 = (dx * dx + dy * dy) + dzz * dzz;
+                    float w = expf(-d2 / two_sigma2);
+                    in232[k] = dz * w;
+                    for (int l = 0; l < KPO_PE_LEVELS; ++l) { /* layout spatial.py:36-39 */
+                        float y = dz * pe_vec[l];
+                        in232[(1 + 2 * l) * KPO_NKPT + k] = sinf(y) * w;
+                        in232[(2 + 2 * l) * KPO_NKPT + k] = cosf(y) * w;
+                    }
+                }
+                sample_bilinear(sc->geo0 + (size_t)v * 64 * sc->g0h * sc->g0w, 64, sc->g0h, sc->g0w, xn[v], yn[v],
+                                in232 + KPO_PE_DIM);                              /* model.py:763-765 */
+                /* MLPUNet utils.py:691-720 with skip_layers [0,2] */
+                linear(wt.w[L_G1_0], wt.b[L_G1_0], 128, 232, in232, h0);
+                for (int i = 0; i < 128; ++i) h0[i] = softplus100(h0[i]);
+                linear(wt.w[L_G1_1], wt.b[L_G1_1], 128, 128, h0, h1);
+                for (int i = 0; i < 128; ++i) h1[i] = softplus100(h1[i]);
+                sample_bilinear(sc->geo1 + (size_t)v * 8 * sc->g1h * sc->g1w, 8, sc->g1h, sc->g1w, xn[v], yn[v], h1 + 128);
+                linear(wt.w[L_G1_2], wt.b[L_G1_2], 120, 136, h1, h2);
+                for (int i = 0; i < 120; ++i) h2[i] = softplus100(h2[i]);
+                linear(wt.w[L_G1_3], wt.b[L_G1_3], 64, 120, h2, xv[v]);
+            }
+            /* PoolModule / pool_ops utils.py:612-647,722-748: weighted mean & var over views */
+            float pooled[128], a64[64], b64[64], o2[2], lat[24];
+            for (int i = 0; i < 64; ++i) {
+                float m = 0.0f;
+                for (int v = 0; v < V; ++v) m += pw[v] * xv[v][i];
+                float var = 0.0f;
+                for (int v = 0; v < V; ++v) { float d = xv[v][i] - m; var += pw[v] * (d * d); }
+                pooled[i] = m; pooled[64 + i] = var;
+            }
+            linear(wt.w[L_G2_0], wt.b[L_G2_0], 64, 128, pooled, a64);
+            for (int i = 0; i < 64; ++i) a64[i] = softplus100(a64[i]);
+            linear(wt.w[L_G2_1], wt.b[L_G2_1], 64, 64, a64, b64);
+            for (int i = 0; i < 64; ++i) b64[i] = softplus100(b64[i]);
+            linear(wt.w[L_G2_2], wt.b[L_G2_2], 2, 64, b64, o2);
+            sdf_raw = o2[0]; rad = o2[1];
+            /* query_color model.py:784-843 */
+            linear(wt.w[L_CMP], wt.b[L_CMP], 24, 128, pooled, lat);               /* :819 */
+            float ray_diff[KPO_MAXV][4];
+            for (int v = 0; v < V; ++v) {
+                sample_bilinear(sc->tex + (size_t)v * 8 * sc->th * sc->tw, 8, sc->th, sc->tw, xn[v], yn[v], rgb_feat[v] + 3);
+                memcpy(rgb_feat[v] + 11, lat, 24 * sizeof(float));                /* :820 */
+                float cr[3] = {p[0] - cpos[v][0], p[1] - cpos[v][1], p[2] - cpos[v][2]};
+                float nrm = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+                nrm = fmaxf(nrm, 1e-12f);                                         /* thf.normalize eps :825 */
+                for (int i = 0; i < 3; ++i) cr[i] /= nrm;
+                float rd[3] = {vd[0] - cr[0], vd[1] - cr[1], vd[2] - cr[2]};      /* :828 */
+                float rn = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+                float dot = (cr[0] * vd[0] + cr[1] * vd[1]) + cr[2] * vd[2];      /* :830 */
+                float rc = fmaxf(rn, 1e-6f);                                      /* :831 */
+                ray_diff[v][0] = rd[0] / rc; ray_diff[v][1] = rd[1] / rc; ray_diff[v][2] = rd[2] / rc;
+                ray_diff[v][3] = dot;
+            }
+            ibr_head(&wt, V, (const float(*)[35])rgb_feat, (const float(*)[4])ray_diff, a, rgb);
+        }
+        if (apply_eval_func) { /* model.py:981-997 */
+            float mask = (float)is_valid;
+            o[0] = mask * fmaxf(rad, 0.0f);
+            o[1] = mask * sdf_raw + (1.0f - mask) * (0.1f / sc->nml_scale);
+        } else {
+            o[0] = sdf_raw; o[1] = rad;
+        }
+        o[2] = rgb[0]; o[3] = rgb[1]; o[4] = rgb[2];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ray_bbox_intersection model.py:1178-1237.  bounds (2,3), orig (3), dirs (R,3) ->
+ * near (R), far (R), hit (R). */
+void kpo_ray_bbox_intersection(const float* bounds, const float* orig, const float* dirs, int64_t R,
+                               float* near_out, float* far_out, uint8_t* hit) {
+    float bmin[3], bmax[3];
+    for (int i = 0; i < 3; ++i) { bmin[i] = bounds[i] + (-0.01f); bmax[i] = bounds[3 + i] + 0.01f; } /* :1193 */
+    for (int64_t r = 0; r < R; ++r) {
+        float d[3];
+        for (int i = 0; i < 3; ++i) { d[i] = dirs[r * 3 + i]; if (fabsf(d[i]) < 1e-5f) d[i] = 1e-5f; } /* :1198 */
+        int cnt = 0;
+        float pint[2][3];
+        /* plane order of reshape(-1,6): (min x,y,z, max x,y,z) :1199 */
+        for (int s = 0; s < 6; ++s) {
+            int ax = s % 3;
+            float bound = (s < 3) ? bmin[ax] : bmax[ax];
+            float t = (bound - orig[ax]) / d[ax];
+            float pt[3] = {t * d[0] + orig[0], t * d[1] + orig[1], t * d[2] + orig[2]}; /* :1202 */
+            const float eps = 1e-6f;
+            int inside = (pt[0] >= bmin[0] - eps) && (pt[0] <= bmax[0] + eps) && (pt[1] >= bmin[1] - eps) &&
+                         (pt[1] <= bmax[1] + eps) && (pt[2] >= bmin[2] - eps) && (pt[2] <= bmax[2] + eps);
+            if (inside) { if (cnt < 2) memcpy(pint[cnt], pt, sizeof(pt)); ++cnt; }
+        }
+        if (cnt == 2) { /* :1217 exactly two */
+            float nr = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            float dd[2];
+            for (int k = 0; k < 2; ++k) {
+                float e0 = pint[k][0] - orig[0], e1 = pint[k][1] - orig[1], e2 = pint[k][2] - orig[2];
+                dd[k] = sqrtf((e0 * e0 + e1 * e1) + e2 * e2) / nr;                /* :1221-1223 */
+            }
+            near_out[r] = fminf(dd[0], dd[1]); far_out[r] = fmaxf(dd[0], dd[1]); hit[r] = 1;
+        } else { near_out[r] = 1.0f; far_out[r] = 1.0f; hit[r] = 0; }          /* :1229-1230 */
+    }
+}
+
+/* torch.linspace(0,1,steps) in fp32 (ATen: symmetric evaluation from both ends) */
+static float linspace01(int i, int steps) {
+    if (steps == 1) return 0.0f;
+    float step = (1.0f - 0.0f) / (float)(steps - 1);
+    int half = steps / 2;
+    return (i < half) ? (0.0f + step * (float)i) : (1.0f - step * (float)(steps - 1 - i));
+}
+
+/* importance_sample model.py:1110-1148.  contrib (R,D-2), z (R,D-1), optional u (R,n) (NULL = uniform
+ * linspace, :1126) -> samples (R,n). */
+void kpo_importance_sample(const float* contrib, const float* z, const float* u, int64_t R, int Dm2, int n,
+                           float* out) {
+    const int C = Dm2 + 1; /* cdf length == z length */
+#pragma omp parallel for
+    for (int64_t r = 0; r < R; ++r) {
+        float cdf[512], pdf;
+        const float* c = contrib + r * Dm2;
+        const float* zz = z + r * C;
+        float sum = 0.0f;
+        for (int i = 0; i < Dm2; ++i) sum += (c[i] + 1e-5f);                     /* :1120-1121 */
+        cdf[0] = 0.0f;
+        float run = 0.0f;
+        for (int i = 0; i < Dm2; ++i) { pdf = (c[i] + 1e-5f) / sum; run += pdf; cdf[i + 1] = run; } /* :1122-1123 */
+        for (int k = 0; k < n; ++k) {
+            float s = u ? u[r * n + k] : linspace01(k, n);
+            int idx = 0;                                                          /* searchsorted right=True :1131 */
+            while (idx < C && cdf[idx] <= s) ++idx;
+            int ip = idx - 1 < 0 ? 0 : idx - 1;                                   /* :1132 */
+            int in = idx > C - 1 ? C - 1 : idx;                                   /* :1133 */
+            float num = s - cdf[ip], den = cdf[in] - cdf[ip];
+            if (den < 1e-5f) den = 1.0f;                                          /* :1146 */
+            out[r * n + k] = zz[ip] + (num / den) * (zz[in] - zz[ip]);            /* :1147 */
+        }
+    }
+}
+
+/* rgba2out model.py:1150-1176.  rgba (R,S,5) = [alpha(sigma), sdf, r,g,b], z (R,S) ->
+ * color (R,3), depth (R), alpha (R), contrib (R,S), sdf (R) */
+void kpo_rgba2out(const float* rgba, const float* z, int64_t R, int S, float* color, float* depth, float* alpha,
+                  float* contrib, float* sdf) {
+#pragma omp parallel for
+    for (int64_t r = 0; r < R; ++r) {
+        const float* q = rgba + r * S * 5;
+        const float* zz = z + r * S;
+        float T = 1.0f, col[3] = {0, 0, 0}, asum = 0.0f, ssum = 0.0f, dsum = 0.0f;
+        for (int i = 0; i < S; ++i) {
+            float dist = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;               /* :1166 */
+            float c = 1.0f - expf(-q[i * 5 + 0] * dist);                          /* :1167 */
+            float cw = c * T;                                                     /* :1168-1169 exclusive cumprod */
+            T = T * (1.0f - c);
+            if (contrib) contrib[r * S + i] = cw;
+            col[0] += q[i * 5 + 2] * cw; col[1] += q[i * 5 + 3] * cw; col[2] += q[i * 5 + 4] * cw;
+            asum += cw; ssum += q[i * 5 + 1] * cw; dsum += zz[i] * cw;
+        }
+        color[r * 3 + 0] = col[0]; color[r * 3 + 1] = col[1]; color[r * 3 + 2] = col[2];
+        alpha[r] = asum;
+        sdf[r] = ssum / (asum + 1e-8f);                                           /* :1173 */
+        depth[r] = dsum / (asum + 1e-8f);                                         /* :1174 */
+    }
+}
+
+/* Ray set-up of batch_render_pifu_nerf, model.py:1026-1043, for an arbitrary list of integer pixel
+ * positions (px,py) of the target camera.  K,RT are 4x4.  Outputs: dirs (R,3), cam_pos (3),
+ * near (R), far (R) after the AABB clip. */
+void kpo_make_rays(const float* K, const float* RT, float znear, float zfar, const float* bounds, int64_t R,
+                   const int32_t* pix /* (R,2) x,y */, float* dirs, float* cam_pos, float* near_out, float* far_out) {
+    double iKd[9];
+    inverse3(K, iKd);
+    float iK[9];
+    for (int i = 0; i < 9; ++i) iK[i] = (float)iKd[i];
+    /* cam_pos = -t^T R : model.py:1036 */
+    for (int i = 0; i < 3; ++i)
+        cam_pos[i] = -((RT[0 * 4 + 3] * RT[0 * 4 + i] + RT[1 * 4 + 3] * RT[1 * 4 + i]) + RT[2 * 4 + 3] * RT[2 * 4 + i]);
+    float* z1 = (float*)malloc(sizeof(float) * R);
+    float* z2 = (float*)malloc(sizeof(float) * R);
+    uint8_t* hit = (uint8_t*)malloc(R);
+    for (int64_t r = 0; r < R; ++r) {
+        float g[3] = {(float)pix[r * 2 + 0], (float)pix[r * 2 + 1], 1.0f};
+        float c[3], cn[3], cf[3];
+        for (int i = 0; i < 3; ++i) { /* grids_h @ inv_K with inv_K = inverse(K)^T  :1031-1034 */
+            c[i] = (g[0] * iK[i * 3 + 0] + g[1] * iK[i * 3 + 1]) + g[2] * iK[i * 3 + 2];
+            cn[i] = ((znear * g[0]) * iK[i * 3 + 0] + (znear * g[1]) * iK[i * 3 + 1]) + (znear * g[2]) * iK[i * 3 + 2];
+            cf[i] = ((zfar * g[0]) * iK[i * 3 + 0] + (zfar * g[1]) * iK[i * 3 + 1]) + (zfar * g[2]) * iK[i * 3 + 2];
+        }
+        near_out[r] = sqrtf((cn[0] * cn[0] + cn[1] * cn[1]) + cn[2] * cn[2]);
+        far_out[r] = sqrtf((cf[0] * cf[0] + cf[1] * cf[1]) + cf[2] * cf[2]);
+        float w[3];
+        for (int i = 0; i < 3; ++i) /* cam_rays @ RT[:3,:3] :1035 */
+            w[i] = (c[0] * RT[0 * 4 + i] + c[1] * RT[1 * 4 + i]) + c[2] * RT[2 * 4 + i];
+        float nr = fmaxf(sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]), 1e-12f);
+        for (int i = 0; i < 3; ++i) dirs[r * 3 + i] = w[i] / nr;
+    }
+    kpo_ray_bbox_intersection(bounds, cam_pos, dirs, R, z1, z2, hit);             /* :1039 */
+    for (int64_t r = 0; r < R; ++r) {                                             /* :1040-1043 */
+        if (hit[r] && z1[r] > near_out[r]) near_out[r] = z1[r];
+        if (hit[r] && z2[r] < far_out[r]) far_out[r] = z2[r];
+    }
+    free(z1); free(z2); free(hit);
+}
+
+static int cmp_float(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* batch_render_pifu_nerf, eval branch with uniform=True (model.py:1019-1096), for R rays given by
+ * integer target pixels.  Outputs (any may be NULL): tex_fg (R,3), depth, alpha (R); if fine:
+ * tex_fg_fine (R,3), depth_fine, alpha_fine, sdf (R).  Stage dumps: z_c (R,Sc), z_f (R,Sc+Sf),
+ * rgba_c (R,Sc,5), rgba_f (R,Sc+Sf,5). */
+void kpo_render_rays(const kpo_scene* sc, const float* wflat, const float* K, const float* RT, float znear,
+                     float zfar, const float* bounds, int64_t R, const int32_t* pix, int Sc, int Sf, int fine,
+                     float* tex_fg, float* depth, float* alpha, float* tex_fg_fine, float* depth_fine,
+                     float* alpha_fine, float* sdf_out, float* z_c_out, float* z_f_out, float* rgba_c_out,
+                     float* rgba_f_out) {
+    float* dirs = (float*)malloc(sizeof(float) * R * 3);
+    float* nearr = (float*)malloc(sizeof(float) * R);
+    float* farr = (float*)malloc(sizeof(float) * R);
+    float cam_pos[3];
+    kpo_make_rays(K, RT, znear, zfar, bounds, R, pix, dirs, cam_pos, nearr, farr);
+    const int Sfull = Sc + Sf;
+    float* z = (float*)malloc(sizeof(float) * R * Sc);
+    float* pts = (float*)malloc(sizeof(float) * R * Sfull * 3);
+    float* vw = (float*)malloc(sizeof(float) * R * Sfull * 3);
+    float* rgba = (float*)malloc(sizeof(float) * R * Sfull * 5);
+    float* contrib = (float*)malloc(sizeof(float) * R * Sfull);
+    float* sdf_tmp = (float*)malloc(sizeof(float) * R);
+    float* col_tmp = (float*)malloc(sizeof(float) * R * 3);
+    float* dep_tmp = (float*)malloc(sizeof(float) * R);
+    float* alp_tmp = (float*)malloc(sizeof(float) * R);
+    for (int64_t r = 0; r < R; ++r)
+        for (int i = 0; i < Sc; ++i) {
+            float t = linspace01(i, Sc);                                          /* :1045 */
+            float zz = nearr[r] + (farr[r] - nearr[r]) * t;                       /* :1055 */
+            z[r * Sc + i] = zz;
+            for (int k = 0; k < 3; ++k) {
+                pts[(r * Sc + i) * 3 + k] = cam_pos[k] + dirs[r * 3 + k] * zz;    /* :1057 */
+                vw[(r * Sc + i) * 3 + k] = dirs[r * 3 + k];                       /* :1060 */
+            }
+        }
+    kpo_query(sc, wflat, R * Sc, pts, vw, 1, rgba, NULL);                         /* :1062 */
+    kpo_rgba2out(rgba, z, R, Sc, tex_fg ? tex_fg : col_tmp, depth ? depth : dep_tmp, alpha ? alpha : alp_tmp,
+                 contrib, sdf_tmp);                                               /* :1065 */
+    if (z_c_out) memcpy(z_c_out, z, sizeof(float) * R * Sc);
+    if (rgba_c_out) memcpy(rgba_c_out, rgba, sizeof(float) * R * Sc * 5);
+    if (fine) {
+        float* zmid = (float*)malloc(sizeof(float) * R * (Sc - 1));
+        float* cin = (float*)malloc(sizeof(float) * R * (Sc - 2));
+        float* znew = (float*)malloc(sizeof(float) * R * Sf);
+        float* zf = (float*)malloc(sizeof(float) * R * Sfull);
+        for (int64_t r = 0; r < R; ++r) {
+            for (int i = 0; i < Sc - 1; ++i) zmid[r * (Sc - 1) + i] = 0.5f * (z[r * Sc + i + 1] + z[r * Sc + i]); /* :1074 */
+            for (int i = 0; i < Sc - 2; ++i) cin[r * (Sc - 2) + i] = contrib[r * Sc + 1 + i];                    /* :1075 */
+        }
+        kpo_importance_sample(cin, zmid, NULL, R, Sc - 2, Sf, znew);
+        for (int64_t r = 0; r < R; ++r) {                                         /* :1076 sort(cat) */
+            memcpy(zf + r * Sfull, z + r * Sc, sizeof(float) * Sc);
+            memcpy(zf + r * Sfull + Sc, znew + r * Sf, sizeof(float) * Sf);
+            qsort(zf + r * Sfull, Sfull, sizeof(float), cmp_float);
+            for (int i = 0; i < Sfull; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    pts[(r * Sfull + i) * 3 + k] = cam_pos[k] + dirs[r * 3 + k] * zf[r * Sfull + i];            /* :1077 */
+                    vw[(r * Sfull + i) * 3 + k] = dirs[r * 3 + k];
+                }
+        }
+        kpo_query(sc, wflat, R * Sfull, pts, vw, 1, rgba, NULL);                  /* :1082 */
+        kpo_rgba2out(rgba, zf, R, Sfull, tex_fg_fine ? tex_fg_fine : col_tmp, depth_fine ? depth_fine : dep_tmp,
+                     alpha_fine ? alpha_fine : alp_tmp, contrib, sdf_out ? sdf_out : sdf_tmp);                   /* :1085 */
+        if (z_f_out) memcpy(z_f_out, zf, sizeof(float) * R * Sfull);
+        if (rgba_f_out) memcpy(rgba_f_out, rgba, sizeof(float) * R * Sfull * 5);
+        free(zmid); free(cin); free(znew); free(zf);
+    }
+    free(dirs); free(nearr); free(farr); free(z); free(pts); free(vw); free(rgba); free(contrib);
+    free(sdf_tmp); free(col_tmp); free(dep_tmp); free(alp_tmp);
+}

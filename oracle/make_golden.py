@@ -1,0 +1,151 @@
+"""Generate the committed golden vectors in tests/golden/ by running the UNMODIFIED reference
+(imported from /root/reference through oracle/ref_shim.py) on small seeded synthetic scenes.
+
+Run in the build container only:   python -m oracle.make_golden
+TEST INFRASTRUCTURE ONLY.
+
+Each golden file holds: the complete inputs (scene tensors, hot-path state dict, cameras), and the
+reference's outputs — the final out-dict of ``batch_render_pifu_nerf`` (eval, uniform=True) plus
+stage-level captures obtained by wrapping the ``net`` attributes the reference itself looks up
+(``net.query``, ``net.rgba2out``, ``net.importance_sample``, ``net.ray_bbox_intersection``;
+reference src/model.py:979,1039,1065,1075,1085).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from keypointnerf_amd.synthetic import make_scene, perturb_reference_net  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+HOT_PREFIXES = ("mlp_geo.", "mlp_tex.", "ibr_compress_gfeat.")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def scene_to_npz(scene):
+    d = {"img": _np(scene["img"]), "geo0": _np(scene["feat_geo"][0]), "geo1": _np(scene["feat_geo"][1]),
+         "tex": _np(scene["feat_tex"]), "fgmask": _np(scene["src_foreground_mask"]),
+         "KRT": _np(scene["cam"]["KRT"]), "K": _np(scene["cam"]["K"]), "extrin": _np(scene["cam"]["extrin"]),
+         "tar_K": _np(scene["cam_tar"]["K"]), "tar_RT": _np(scene["cam_tar"]["RT"]),
+         "tar_meta": np.array([scene["cam_tar"]["width"], scene["cam_tar"]["height"], scene["cam_tar"]["znear"],
+                               scene["cam_tar"]["zfar"]], np.float64),
+         "src_meta": np.array([scene["cam"]["width"], scene["cam"]["height"], scene["cam"]["znear"],
+                               scene["cam"]["zfar"], scene["cam"]["nml_scale"]], np.float64),
+         "kpt3d": _np(scene["sp_data"]["kpt3d"]), "bounds": _np(scene["bounds"])}
+    return {"scene." + k: v for k, v in d.items()}
+
+
+class Recorder:
+    """Wraps the reference's own attribute seams on ``net`` and records their inputs/outputs."""
+
+    def __init__(self, net):
+        self.net = net
+        self.calls = {"query": [], "rgba2out": [], "importance_sample": [], "ray_bbox_intersection": []}
+        cls = type(net)
+        orig_query = net.query  # bound
+        rgba2out, imp, bbox = cls.rgba2out, cls.importance_sample, cls.ray_bbox_intersection
+
+        def q(pts, cam, *a, **k):
+            out, valid = orig_query(pts, cam, *a, **k)
+            self.calls["query"].append({"pts": _np(pts), "view": _np(k["view"]), "out": _np(out), "valid": _np(valid)})
+            return out, valid
+
+        def r2o(rgba, z):
+            res = rgba2out(rgba, z)
+            self.calls["rgba2out"].append({"rgba": _np(rgba), "z": _np(z), "color": _np(res[0]), "depth": _np(res[1]),
+                                           "alpha": _np(res[2]), "contrib": _np(res[3]), "sdf": _np(res[4])})
+            return res
+
+        def im(contrib, z, n, uniform=False):
+            res = imp(contrib, z, n, uniform=uniform)
+            self.calls["importance_sample"].append({"contrib": _np(contrib), "z": _np(z), "out": _np(res)})
+            return res
+
+        def bb(bounds, orig, direct):
+            res = bbox(bounds, orig, direct)
+            self.calls["ray_bbox_intersection"].append({"bounds": _np(bounds), "orig": _np(orig), "direct": _np(direct),
+                                                        "near": _np(res[0]), "far": _np(res[1]), "hit": _np(res[2])})
+            return res
+
+        net.query, net.rgba2out, net.importance_sample, net.ray_bbox_intersection = q, r2o, im, bb
+
+    def restore(self):
+        for k in ("query", "rgba2out", "importance_sample", "ray_bbox_intersection"):
+            if k in self.net.__dict__:
+                del self.net.__dict__[k]
+
+
+def run_case(net, name, n_views, src_hw, tar_hw, mask, level, stride, Sc, Sf, seed, tar_angle=None):
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=tar_hw, mask=mask, seed=seed, tar_angle=tar_angle)
+    rec = Recorder(net)
+    cfg = dict(fine=True, uniform=True, sample_per_ray_c=Sc, sample_per_ray_f=Sf,
+               src_foreground_mask=scene["src_foreground_mask"], bounds=scene["bounds"])
+    strd = torch.tensor([[float(stride[0]), float(stride[1])]])  # [[j, i]] as reference src/model.py:920
+    with torch.no_grad():
+        out = net.batch_render_pifu_nerf(net, scene["img"], scene["cam"], n_views, scene["cam_tar"], level, strd, None,
+                                         scene["feat_geo"], scene["feat_tex"], dict(scene["sp_data"]), None, **cfg)
+    rec.restore()
+    d = scene_to_npz(scene)
+    d["cfg"] = np.array([n_views, level, stride[0], stride[1], Sc, Sf], np.int64)
+    for k, v in out.items():
+        d["out." + k] = _np(v)
+    for stage, calls in rec.calls.items():
+        for i, c in enumerate(calls):
+            for k, v in c.items():
+                d[f"{stage}.{i}.{k}"] = v
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: rays={out['alpha'].numel()} alpha_fine mean={float(out['alpha_fine'].mean()):.4f} "
+          f"valid_c={rec.calls['query'][0]['valid'].mean():.3f} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+    return scene, out
+
+
+def run_tiled_case(net, name, n_views, src_hw, tar_hw, mask, level, Sc, Sf, seed):
+    """render_pifu_nerf's stride^2 tiles + pixel_shuffle re-assembly (reference src/model.py:897-940),
+    with the image encoders bypassed (feature maps are the synthetic ones)."""
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=tar_hw, mask=mask, seed=seed)
+    net.attach_geo_feat = lambda im, return_val=False: scene["feat_geo"]
+    net.attach_tex_feat = lambda im, return_val=False: scene["feat_tex"]
+    try:
+        with torch.no_grad():
+            out = net.render_pifu_nerf(net, scene["img"], scene["cam"], scene["cam_tar"], level=level,
+                                       sp_data=dict(scene["sp_data"]), fine=True, uniform=True, sample_per_ray_c=Sc,
+                                       sample_per_ray_f=Sf, src_foreground_mask=scene["src_foreground_mask"],
+                                       bounds=scene["bounds"])
+    finally:
+        del net.__dict__["attach_geo_feat"], net.__dict__["attach_tex_feat"]
+    d = scene_to_npz(scene)
+    d["cfg"] = np.array([n_views, level, 0, 0, Sc, Sf], np.int64)
+    for k, v in out.items():
+        d["out." + k] = _np(v)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: frame {tuple(out['tex_fg_fine'].shape)} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    net = ref_shim.build_reference_net(seed=0)
+    perturb_reference_net(net, seed=7)
+    sd = {k: _np(v) for k, v in net.state_dict().items() if k.startswith(HOT_PREFIXES)}
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"), **sd)
+    print("weights:", sum(v.size for v in sd.values()), "floats")
+    # A: shipped view count, ellipsoid mask, level 1 (every pixel of a 32x32 target)
+    run_case(net, "case_a_v3_ellipsoid", 3, (64, 64), (32, 32), "ellipsoid", 1, (0, 0), 16, 16, seed=1)
+    # B: V=4, dense mask, non-square source and target, level 2 tile with offset (j=1,i=0), Sc != Sf (the reference needs (Sc+Sf) % Sf == 0, src/model.py:808,835)
+    run_case(net, "case_b_v4_dense_tile", 4, (48, 80), (32, 48), "dense", 2, (1, 0), 24, 12, seed=2)
+    # C: a target camera far off the ring so that many rays miss the AABB / leave the source frusta
+    run_case(net, "case_c_v3_offaxis", 3, (64, 64), (24, 24), "dense", 1, (0, 0), 8, 8, seed=3, tar_angle=95.0)
+    # D: full-frame assembly through the reference tile loop + pixel_shuffle
+    run_tiled_case(net, "case_d_v3_tiled_frame", 3, (64, 64), (16, 16), "ellipsoid", 3, 8, 8, seed=4)
+
+
+if __name__ == "__main__":
+    main()

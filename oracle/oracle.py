@@ -1,0 +1,165 @@
+"""ctypes front-end of the C oracle (oracle/kpnerf_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+Takes the same scene dict that keypointnerf_amd.synthetic.make_scene() returns (CPU tensors) and
+the reference-named state dict, and returns numpy arrays.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libkpnerf_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "kpnerf_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _SO
+
+
+class _Scene(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("V", "H", "W", "g0h", "g0w", "g1h", "g1w", "th", "tw", "disable_fg_mask")] + \
+               [(n, ctypes.c_float) for n in ("znear", "zfar", "nml_scale", "sigma")] + \
+               [(n, ctypes.c_void_p) for n in
+                ("KRT", "extrin", "kpt3d", "img", "fgmask", "geo0", "geo1", "tex")]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        try:
+            build()
+            _lib = ctypes.CDLL(_SO)
+        except OSError:
+            build(force=True)
+            _lib = ctypes.CDLL(_SO)
+        _lib.kpo_weight_count.restype = ctypes.c_int
+    return _lib
+
+
+def _f32(t):
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().float().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleScene:
+    """Keeps the numpy buffers alive behind a kpo_scene struct."""
+
+    def __init__(self, scene, disable_fg_mask=False, sigma=0.1):
+        cam = scene["cam"]
+        self.bufs = dict(
+            KRT=_f32(cam["KRT"]), extrin=_f32(scene["sp_data"]["extrin"]),
+            kpt3d=_f32(scene["sp_data"]["kpt3d"]).reshape(-1, 3), img=_f32(scene["img"]),
+            fgmask=_f32(scene["src_foreground_mask"].float()).reshape(-1, *scene["img"].shape[-2:]),
+            geo0=_f32(scene["feat_geo"][0]), geo1=_f32(scene["feat_geo"][1]), tex=_f32(scene["feat_tex"]))
+        V, _, H, W = self.bufs["img"].shape
+        assert self.bufs["kpt3d"].shape == (24, 3)
+        s = _Scene()
+        s.V, s.H, s.W = V, H, W
+        s.g0h, s.g0w = self.bufs["geo0"].shape[-2:]
+        s.g1h, s.g1w = self.bufs["geo1"].shape[-2:]
+        s.th, s.tw = self.bufs["tex"].shape[-2:]
+        s.disable_fg_mask = int(disable_fg_mask)
+        s.znear, s.zfar, s.nml_scale, s.sigma = float(cam["znear"]), float(cam["zfar"]), float(cam["nml_scale"]), sigma
+        for k, a in self.bufs.items():
+            setattr(s, k, a.ctypes.data)
+        self.struct = s
+        self.V = V
+
+
+def flat_weights(state_dict):
+    from keypointnerf_amd.weights import effective_weights, flatten_plain
+    w = flatten_plain(effective_weights(state_dict))
+    assert w.size == lib().kpo_weight_count(), (w.size, lib().kpo_weight_count())
+    return w
+
+
+def query(oscene, wflat, pts, view, apply_eval_func=False):
+    pts, view = _f32(pts).reshape(-1, 3), _f32(view).reshape(-1, 3)
+    N = pts.shape[0]
+    out = np.empty((N, 5), np.float32)
+    valid = np.empty((N,), np.uint8)
+    lib().kpo_query(ctypes.byref(oscene.struct), _ptr(wflat), ctypes.c_int64(N), _ptr(pts), _ptr(view),
+                    ctypes.c_int(int(apply_eval_func)), _ptr(out), _ptr(valid))
+    return out, valid.astype(bool)
+
+
+def ray_bbox_intersection(bounds, orig, dirs):
+    bounds, orig, dirs = _f32(bounds).reshape(2, 3), _f32(orig).reshape(3), _f32(dirs).reshape(-1, 3)
+    R = dirs.shape[0]
+    near, far, hit = np.empty(R, np.float32), np.empty(R, np.float32), np.empty(R, np.uint8)
+    lib().kpo_ray_bbox_intersection(_ptr(bounds), _ptr(orig), _ptr(dirs), ctypes.c_int64(R), _ptr(near), _ptr(far), _ptr(hit))
+    return near, far, hit.astype(bool)
+
+
+def importance_sample(contrib, z, n, u=None):
+    contrib, z = _f32(contrib), _f32(z)
+    R, Dm2 = contrib.reshape(-1, contrib.shape[-1]).shape
+    assert z.shape[-1] == Dm2 + 1
+    out = np.empty((R, n), np.float32)
+    uu = _f32(u).reshape(R, n) if u is not None else None
+    lib().kpo_importance_sample(_ptr(contrib), _ptr(z), _ptr(uu) if uu is not None else None, ctypes.c_int64(R),
+                                ctypes.c_int(Dm2), ctypes.c_int(n), _ptr(out))
+    return out
+
+
+def rgba2out(rgba, z):
+    rgba, z = _f32(rgba), _f32(z)
+    S = z.shape[-1]
+    R = z.size // S
+    color, depth, alpha = np.empty((R, 3), np.float32), np.empty(R, np.float32), np.empty(R, np.float32)
+    contrib, sdf = np.empty((R, S), np.float32), np.empty(R, np.float32)
+    lib().kpo_rgba2out(_ptr(rgba), _ptr(z), ctypes.c_int64(R), ctypes.c_int(S), _ptr(color), _ptr(depth), _ptr(alpha),
+                       _ptr(contrib), _ptr(sdf))
+    return color, depth, alpha, contrib, sdf
+
+
+def make_rays(cam_tar, bounds, pix):
+    K, RT = _f32(cam_tar["K"]).reshape(4, 4), _f32(cam_tar["RT"]).reshape(4, 4)
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    dirs, cam_pos = np.empty((R, 3), np.float32), np.empty(3, np.float32)
+    near, far = np.empty(R, np.float32), np.empty(R, np.float32)
+    b = _f32(bounds).reshape(2, 3)
+    lib().kpo_make_rays(_ptr(K), _ptr(RT), ctypes.c_float(cam_tar["znear"]), ctypes.c_float(cam_tar["zfar"]), _ptr(b),
+                        ctypes.c_int64(R), _ptr(pix), _ptr(dirs), _ptr(cam_pos), _ptr(near), _ptr(far))
+    return dirs, cam_pos, near, far
+
+
+def render_rays(oscene, wflat, cam_tar, bounds, pix, Sc=64, Sf=64, fine=True, stages=False):
+    """eval-mode batch_render_pifu_nerf (uniform=True) for integer target pixels pix (R,2)=(x,y)."""
+    K, RT = _f32(cam_tar["K"]).reshape(4, 4), _f32(cam_tar["RT"]).reshape(4, 4)
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    b = _f32(bounds).reshape(2, 3)
+    o = {"tex_fg": np.empty((R, 3), np.float32), "depth": np.empty(R, np.float32), "alpha": np.empty(R, np.float32)}
+    if fine:
+        o.update({"tex_fg_fine": np.empty((R, 3), np.float32), "depth_fine": np.empty(R, np.float32),
+                  "alpha_fine": np.empty(R, np.float32), "sdf": np.empty(R, np.float32)})
+    st = {}
+    if stages:
+        st["z_c"] = np.empty((R, Sc), np.float32)
+        st["rgba_c"] = np.empty((R, Sc, 5), np.float32)
+        if fine:
+            st["z_f"] = np.empty((R, Sc + Sf), np.float32)
+            st["rgba_f"] = np.empty((R, Sc + Sf, 5), np.float32)
+    g = lambda d, k: _ptr(d[k]) if k in d else None
+    lib().kpo_render_rays(ctypes.byref(oscene.struct), _ptr(wflat), _ptr(K), _ptr(RT), ctypes.c_float(cam_tar["znear"]),
+                          ctypes.c_float(cam_tar["zfar"]), _ptr(b), ctypes.c_int64(R), _ptr(pix), ctypes.c_int(Sc),
+                          ctypes.c_int(Sf), ctypes.c_int(int(fine)), g(o, "tex_fg"), g(o, "depth"), g(o, "alpha"),
+                          g(o, "tex_fg_fine"), g(o, "depth_fine"), g(o, "alpha_fine"), g(o, "sdf"), g(st, "z_c"),
+                          g(st, "z_f"), g(st, "rgba_c"), g(st, "rgba_f"))
+    o.update(st)
+    return o

@@ -1,0 +1,44 @@
+"""Load the committed golden vectors (tests/golden/*.npz, made by oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["case_a_v3_ellipsoid", "case_b_v4_dense_tile", "case_c_v3_offaxis"]
+TILED_CASE = "case_d_v3_tiled_frame"
+
+
+def load_weights():
+    z = np.load(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    t = lambda k: torch.from_numpy(g["scene." + k])
+    sm, tm = g["scene.src_meta"], g["scene.tar_meta"]
+    scene = {
+        "img": t("img"), "feat_geo": [t("geo0"), t("geo1")], "feat_tex": t("tex"),
+        "src_foreground_mask": t("fgmask"),
+        "cam": {"KRT": t("KRT"), "K": t("K"), "extrin": t("extrin"), "Rt": t("extrin")[:, :3, :4].contiguous(),
+                "width": int(sm[0]), "height": int(sm[1]), "znear": float(sm[2]), "zfar": float(sm[3]),
+                "nml_scale": float(sm[4])},
+        "cam_tar": {"K": t("tar_K"), "RT": t("tar_RT"), "KRT": torch.bmm(t("tar_K"), t("tar_RT")), "width": int(tm[0]),
+                    "height": int(tm[1]), "znear": float(tm[2]), "zfar": float(tm[3]), "nml_scale": float(sm[4])},
+        "sp_data": {"kpt3d": t("kpt3d"), "extrin": t("extrin")}, "bounds": t("bounds"), "n_views": int(g["cfg"][0]),
+    }
+    cfg = dict(zip(["n_views", "level", "stride_j", "stride_i", "Sc", "Sf"], [int(x) for x in g["cfg"]]))
+    return scene, cfg, g
+
+
+def pixel_list(cfg, cam_tar):
+    """Integer target pixels (x,y) of one batch_render_pifu_nerf call, eval branch
+    (reference src/model.py:1019-1022): grid step 2^(level-1), offset (j,i), row-major over (y,x)."""
+    step = 2 ** (cfg["level"] - 1)
+    ys = np.arange(0, cam_tar["height"], step)
+    xs = np.arange(0, cam_tar["width"], step)
+    yy, xx = np.meshgrid(ys, xs, indexing="ij")
+    pix = np.stack([xx.reshape(-1) + cfg["stride_j"], yy.reshape(-1) + cfg["stride_i"]], -1).astype(np.int32)
+    return pix, (len(ys), len(xs))
