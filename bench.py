@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py — rays/s of the ray-march path on MI355X (contract: see the task statement / DESIGN.md §6).
+
+A "step" is one pass of the hot path over one batch of synthetic input = ONE full novel-view frame of
+BASELINE.json configs[1]: 512x512 target, 3 source views (512x512), 64 coarse + 64 fine samples per
+ray (192 field evaluations per ray), synthetic seeded scene + random-init hot-path weights.  Inside a
+step: scene preparation (NCHW -> channels-last), ray set-up, coarse field pass, compositing, importance
+resampling, fine field pass, compositing, planar image write.  Inputs are resident in HBM before the
+timed region.  With --gpus N every rank renders its own target camera per step (frames of a render job
+shard over ranks, weak scaling) and the finished RGB images are all-gathered over RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel k_geo_rows (fp32
+MFMA bound; duration measured live with HIP events on the launch stream, see kpn_profile_*), and
+"cpu_baseline": the CPU oracle ("port") timed on this host's cores on a bounded sample of the same
+workload (one reference tile = 4096 strided rays of the same frame).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--views", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=64, help="coarse = fine samples per ray")
+    ap.add_argument("--mask", default="ellipsoid", choices=["ellipsoid", "dense"])
+    ap.add_argument("--chunk-rays", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=int, default=4096)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, scene_cpu, sd):
+    """Oracle (C restatement, OpenMP) on one reference tile: stride res/64 sub-lattice of the frame."""
+    import numpy as np
+    from oracle import oracle
+    step = max(1, args.res // 64)
+    n = int(round(args.cpu_sample_rays ** 0.5))
+    ys, xs = np.meshgrid(np.arange(n) * step, np.arange(n) * step, indexing="ij")
+    pix = np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.int32)
+    osc = oracle.OracleScene(scene_cpu)
+    wflat = oracle.flat_weights(sd)
+    oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix[:64], args.samples, args.samples)  # warm
+    t0 = time.perf_counter()
+    oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples)
+    dt = time.perf_counter() - t0
+    return {"value": pix.shape[0] / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{pix.shape[0]} rays (one {n}x{n} strided tile, step {step}) of the same frame, "
+                      f"{args.samples}+{args.samples} samples, {dt:.1f} s, OpenMP over points"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from keypointnerf_amd import lib as kl
+    from keypointnerf_amd import ops
+    from keypointnerf_amd.parallel import orbit_target_camera
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
+
+    L = kl.get_library()
+    sd = random_hotpath_state_dict(seed=3)
+    res = args.res
+    scene_cpu = make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), mask=args.mask, seed=1)
+    scene = to_device(scene_cpu, dev)
+    w = ops.PackedWeights(sd, device=dev)
+    ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
+                           scene["src_foreground_mask"])
+    plan = ops.RenderPlan(ps, (0, 0, 1, res, res), args.samples, args.samples, fine=True, chunk_rays=args.chunk_rays)
+    gather_buf = torch.empty(world, 3, res, res, device=dev) if world > 1 else None
+
+    def step(i):
+        # frame i of the job: rank r renders target camera (i*world + r) of the orbit
+        cam_tar = orbit_target_camera(scene["cam_tar"], i * world + rank) if world > 1 else scene["cam_tar"]
+        L.check(L.kpn_scene_prepare(ctypes.byref(ps.desc), ctypes.c_void_p(ps.ws.data_ptr()),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        out = ops.render_rays(ps, w, cam_tar, scene["bounds"], plan=plan)
+        if world > 1:
+            dist.all_gather_into_tensor(gather_buf, out["tex_fg_fine"][0])
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    L.check(L.kpn_profile_enable(1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.kpn_profile_collect(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows)))
+    L.check(L.kpn_profile_enable(0))
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    rays_per_step = res * res
+    value = world * rays_per_step * args.steps / dt
+    if rank == 0:
+        flops_row = L.kpn_flops_per_row()
+        achieved = (rows.value * flops_row) / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        alpha_mean = float(out["alpha_fine"].mean())
+        line = {
+            "metric": "rendered rays/sec (64 coarse + 64 fine samples/ray = 192 field evaluations/ray)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {res}x{res} novel view, {args.views} source views {res}x{res}, "
+                                   f"{args.samples} coarse + {args.samples} fine samples/ray, {args.mask} fg mask, "
+                                   f"seeded synthetic scene, random-init hot-path weights",
+                       "rays_per_step": rays_per_step, "field_evals_per_ray": 3 * args.samples,
+                       "sampled_points_per_sec": value * 3 * args.samples,
+                       "valid_rows_per_step": rows.value / max(1, args.steps),
+                       "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},
+            "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
+                         "algorithmic_flop_per_row": flops_row,
+                         "kernel_time_share": (ms.value * 1e-3) / dt},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, scene_cpu, sd)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

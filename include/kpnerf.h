@@ -1,0 +1,163 @@
+/*
+ * kpnerf.h — C ABI of libkpnerf_hip.so, the MI355X (gfx950) ray-march library behind
+ * KeypointNeRF's render path.
+ *
+ * The reference (facebookresearch/KeypointNeRF, pure Python) has no FFI/plugin interface; the seam
+ * for this path is attribute lookup on its `net` object.  Each entry point below
+ * replaces one of those Python callables and cites it (file:line under the reference repo).
+ * The binding a maintainer would add on the reference side is a ctypes stub — see INTEGRATION.md
+ * and keypointnerf_amd/lib.py, which is exactly that stub.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory unless its name ends in `_host`;
+ *   - all arithmetic is fp32 (the reference sets torch default dtype float32, train.py:16);
+ *     index/compaction lists are int32; masks are uint8 (0/1);
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it, never synchronise,
+ *     never allocate;
+ *   - inputs are never written; outputs and `workspace` are caller-allocated;
+ *   - every function returns 0 on success, a negative KPN_E* code otherwise; kpn_last_error()
+ *     gives the message (thread-local).  Nothing returns NaN silently for valid inputs.
+ */
+#ifndef KPNERF_H
+#define KPNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPN_ABI_VERSION 1
+#define KPN_N_KPT 24      /* configs/zju.json:44 sp_args.n_kpt */
+#define KPN_MAX_VIEWS 16
+
+enum { KPN_OK = 0, KPN_EINVAL = -1, KPN_ELAUNCH = -2, KPN_EWORKSPACE = -3 };
+
+int kpn_abi_version(void);
+const char* kpn_last_error(void);
+/* 1 if the library was built for the device (gfx950), 0 for the host SIMT emulator build (tests only) */
+int kpn_is_device_build(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Parameters.  `plain_host`: the weight-norm-folded hot-path parameters as one flat fp32 vector in
+ * the order of keypointnerf_amd/synthetic.py:HOTPATH_LAYERS (W row-major (out,in) then bias per
+ * layer, raw ani_al last) — i.e. the reference modules mlp_geo (src/utils.py:476-517),
+ * ibr_compress_gfeat (src/model.py:577-580) and mlp_tex (src/model.py:1239-1258).
+ * kpn_pack_weights re-orders them into the MFMA A-operand streams the kernels read. */
+size_t kpn_plain_weight_floats(void);
+size_t kpn_packed_weight_floats(void);
+int kpn_pack_weights(const float* plain_host, float* packed_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene = what KeypointNeRF.query() receives besides the points: source cameras, keypoints, source
+ * images, fg masks and the encoder feature maps in NCHW, as the reference hands them over
+ * (src/model.py:690-701, 336-355, 653-680). */
+typedef struct kpn_scene_desc {
+    int32_t n_views;                 /* V  (<= KPN_MAX_VIEWS) */
+    int32_t src_h, src_w;            /* source image size H, W (cam["height"], cam["width"]) */
+    int32_t geo0_h, geo0_w;          /* feat_geo[0]: (V,64,geo0_h,geo0_w) */
+    int32_t geo1_h, geo1_w;          /* feat_geo[1]: (V, 8,geo1_h,geo1_w) */
+    int32_t tex_h, tex_w;            /* feat_tex   : (V, 8,tex_h,tex_w)   */
+    int32_t disable_fg_mask;         /* KeypointNeRF.disable_fg_mask, src/model.py:566,734 */
+    float znear, zfar;               /* cam["znear"], cam["zfar"] (2.0/5.0, src/model.py:43,345) */
+    float nml_scale;                 /* cam["nml_scale"] (100.0) */
+    float sigma;                     /* sp_args.sigma (0.1) */
+    const float* KRT;                /* (V,4,4) */
+    const float* extrin;             /* (V,4,4) */
+    const float* kpt3d;              /* (24,3) */
+    const float* img;                /* (V,3,H,W) */
+    const uint8_t* fg_mask;          /* (V,H,W) bool bytes; ignored if disable_fg_mask */
+    const float* geo0;
+    const float* geo1;
+    const float* tex;
+} kpn_scene_desc;
+
+/* bytes of device workspace that kpn_scene_prepare fills (channels-last maps + per-view tables) */
+size_t kpn_scene_workspace_bytes(const kpn_scene_desc* desc);
+/* Builds the kernel-side scene: NCHW -> channels-last (one 256-B line per 64-channel tap), RGB+mask
+ * interleaved, keypoints moved to every camera frame (src/spatial.py:85), source camera centres
+ * (inverse(KRT)[:3,3], src/model.py:823-824). */
+int kpn_scene_prepare(const kpn_scene_desc* desc, void* scene_ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage ops = the reference's per-stage callables. */
+
+/* KeypointNeRF.ray_bbox_intersection, src/model.py:1178-1237.
+ * bounds (2,3), orig (3), direct (R,3) -> near (R), far (R), hit (R). */
+int kpn_ray_bbox_intersection(const float* bounds, const float* orig, const float* direct, int64_t n_rays,
+                              float* near_out, float* far_out, uint8_t* hit_out, void* stream);
+
+/* Ray set-up of batch_render_pifu_nerf, src/model.py:1019-1043, for the pixel grid
+ * px = x0 + ix*step, py = y0 + iy*step (ix<nx, iy<ny; ray index = iy*nx + ix; eval branch :1019-1022
+ * has step = 2^(level-1), (x0,y0) = stride offset (j,i)).  K,RT: target camera (4,4).
+ * -> dirs (R,3), cam_pos (3), near (R), far (R) after the AABB clip. */
+int kpn_make_rays(const float* K, const float* RT, float znear, float zfar, const float* bounds, int32_t x0,
+                  int32_t y0, int32_t step, int32_t nx, int32_t ny, float* dirs, float* cam_pos, float* near_out,
+                  float* far_out, void* stream);
+
+/* KeypointNeRF.importance_sample, src/model.py:1110-1148.  contrib (R,D-2), z (R,D-1),
+ * u (R,n) or NULL (uniform=True -> linspace(0,1,n)) -> samples (R,n). */
+int kpn_importance_sample(const float* contrib, const float* z, const float* u, int64_t n_rays, int32_t d_minus_2,
+                          int32_t n_samples, float* samples_out, void* stream);
+
+/* KeypointNeRF.rgba2out, src/model.py:1150-1176.  rgba (R,S,5) [sigma,sdf,r,g,b], z (R,S) ->
+ * color (R,3), depth (R), alpha (R), contrib (R,S) (may be NULL), sdf (R). */
+int kpn_rgba2out(const float* rgba, const float* z, int64_t n_rays, int32_t n_samples, float* color, float* depth,
+                 float* alpha, float* contrib, float* sdf, void* stream);
+
+/* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
+ * pts (N,3), view (N,3) -> out (N,5), valid (N).
+ * mode 0: out = [sdf_raw, rad, r,g,b] exactly as query() returns;
+ * mode 1: out = eval_func(query()) = [mask*relu(rad), mask*sdf+(1-mask)*0.1/nml_scale, r,g,b]
+ *         (src/model.py:978-997, rand_noise_std = 0).
+ * workspace: kpn_query_workspace_bytes(N, V) bytes. */
+size_t kpn_query_workspace_bytes(int64_t n_points, int32_t n_views);
+int kpn_query(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights, int64_t n_points,
+              const float* pts, const float* view, int32_t mode, float* out, uint8_t* valid, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole path: KeypointNeRF.batch_render_pifu_nerf, eval branch (src/model.py:942-1108), and — with
+ * step=1 over the full image — render_pifu_nerf's tile loop + pixel_shuffle (src/model.py:897-940),
+ * which visits exactly the same rays.  Outputs are planar like the reference's out dict (B=1):
+ * tex_fg (3,ny,nx), depth (ny,nx), alpha (ny,nx), and if fine: tex_fg_fine, depth_fine, alpha_fine,
+ * sdf.  Any output pointer may be NULL. */
+typedef struct kpn_render_args {
+    const float* K;          /* cam_tar["K"]  (4,4) */
+    const float* RT;         /* cam_tar["RT"] (4,4) */
+    const float* bounds;     /* (2,3) */
+    float znear, zfar;       /* cam_tar znear/zfar */
+    int32_t x0, y0, step, nx, ny;
+    int32_t n_coarse, n_fine;   /* sample_per_ray_c / _f */
+    int32_t fine;               /* dr_kwargs.fine */
+    int32_t chunk_rays;         /* rays per internal pass (0 = default) */
+    float* tex_fg; float* depth; float* alpha;
+    float* tex_fg_fine; float* depth_fine; float* alpha_fine; float* sdf;
+} kpn_render_args;
+
+size_t kpn_render_workspace_bytes(const kpn_scene_desc* desc, const kpn_render_args* args);
+int kpn_render_rays(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
+                    const kpn_render_args* args, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py).  When enabled, every launch of the dominant kernel (k_geo_rows) is
+ * bracketed by HIP events recorded on the caller's stream and the number of (point,view) rows it
+ * processed is copied back asynchronously.  kpn_profile_collect synchronises the recorded events
+ * and returns the totals since kpn_profile_enable(1).  Diagnostic only; off by default. */
+int kpn_profile_enable(int32_t on);
+int kpn_profile_collect(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host);
+
+/* FLOP / byte model of one field evaluation, for roofline reporting */
+double kpn_flops_per_point(int32_t n_views);
+/* algorithmic FLOPs of one k_geo_rows row = 2 * 70,080 MACs (MLPUNet layers1) */
+double kpn_flops_per_row(void);
+
+/* Device self-test of the MFMA operand/result lane maps the kernels assume (asymmetric operands).
+ * Returns 0 if D == A*B for v_mfma_f32_32x32x2_f32 in the assumed layout. */
+int kpn_selftest_mfma(float* scratch_256k, void* stream, float* max_err_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPNERF_H */

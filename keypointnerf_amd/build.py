@@ -1,0 +1,37 @@
+"""Builds keypointnerf_amd/_lib/libkpnerf_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m keypointnerf_amd.build [--force]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_lib", "libkpnerf_hip.so")
+SOURCES = ["kpn_api.hip", "ray_kernels.hip", "field_kernels.hip", "kpn_device.h", "kpn_common.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "kpnerf.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "kpn_api.hip"), "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

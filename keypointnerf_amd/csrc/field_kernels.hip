@@ -1,0 +1,462 @@
+// field_kernels.hip — the field evaluation KeypointNeRF.query (reference src/model.py:690-843,
+// 1239-1302; src/spatial.py:63-118; src/utils.py:476-748) as three gfx950 kernels:
+//
+//   k_mask_compact : per point — project into the V source views, validity + fg mask (AND over
+//                    views, model.py:725-739), write the constant result of masked points and append
+//                    valid points to a compact list (wave-aggregated atomic).
+//   k_geo_rows     : [dominant, MFMA-bound] per (valid point, view) "row" — bilinear gather of the
+//                    64+8 geometry channels, keypoint-relative encoding (168), MLPUNet layers1
+//                    232->128->128->(+8)120->64 on v_mfma_f32_32x32x2_f32; writes the 64-vector.
+//   k_fuse_color   : per valid point — view-weighted mean/var pooling, layers2 128->64->64->2,
+//                    ibr_compress 128->24, IBR head over the V views, softmax blend of source colours.
+//
+// Work unit: a wavefront owns a tile of 32 valid points (the N dimension of the 32x32x2 MFMA); lane
+// l = (p = l&31, h = l>>5) holds half of point p's features.  Activations never leave registers
+// between layers (kpn_common.h).  Weights stream from the packed buffer (L2-resident, 0.4 MB).
+#include "kpn_device.h"
+
+struct kpn_points {
+    // explicit points (kpn_query): pts/view (N,3); or ray-marched (kpn_render_rays): cam_pos(3),
+    // dirs (R,3), z (R,S): point n = ray n/S at depth z[n], view = dirs[n/S]  (model.py:1057-1061)
+    const float* pts;
+    const float* view;
+    const float* cam_pos;
+    const float* dirs;
+    const float* z;
+    int S;
+};
+__device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, float (&P)[3], float (&D)[3]) {
+    if (ps.pts) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { P[k] = ps.pts[n * 3 + k]; D[k] = ps.view[n * 3 + k]; }
+    } else {
+        const int64_t r = n / ps.S;
+        const float zz = ps.z[n];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            D[k] = ps.dirs[r * 3 + k];
+            P[k] = KADD(ps.cam_pos[k], KMUL(D[k], zz));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_points ps, int64_t N, int mode,
+                                                      const float* __restrict__ wscalars, float* __restrict__ out,
+                                                      uint8_t* __restrict__ valid, int* __restrict__ list,
+                                                      int* __restrict__ count) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int is_valid = 0;
+    if (n < N) {
+        float P[3], D[3];
+        kpn_get_point(ps, n, P, D);
+        int all_in = 1, all_fg = 1;
+        float acc[3] = {0.f, 0.f, 0.f};
+        const float pu = 1.0f / (float)sc.V;
+        const size_t HW = (size_t)sc.H * sc.W;
+        for (int v = 0; v < sc.V; ++v) {
+            const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+            const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+            all_in &= q.in;
+            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+            const float4 s = kpn_tap4(sc.rgbm + (size_t)v * HW * 4, 4, 0, tp);
+            if (!sc.disable_fg_mask) all_fg &= (s.w > 0.1f);  // model.py:737-739
+            acc[0] = KADD(acc[0], KMUL(s.x, pu)); acc[1] = KADD(acc[1], KMUL(s.y, pu)); acc[2] = KADD(acc[2], KMUL(s.z, pu));
+        }
+        is_valid = all_in && all_fg;
+        if (valid) valid[n] = (uint8_t)is_valid;
+        if (!is_valid) {
+            // every view masked: pooled features are exactly 0 and the IBR softmax is uniform, so the
+            // reference's result is a constant + the plain average of the sampled source colours
+            float* o = out + n * 5;
+            if (mode == 1) { o[0] = 0.0f; o[1] = 0.1f / sc.nml_scale; }  // eval_func, model.py:981-996
+            else { o[0] = wscalars[1]; o[1] = wscalars[2]; }
+            o[2] = acc[0]; o[3] = acc[1]; o[4] = acc[2];
+        }
+    }
+    const unsigned long long m = __ballot(is_valid);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (is_valid) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row kernel.  x scratch layout: [(tile*V + v)*8 + q4][lane] float4, q4 = 4 consecutive registers of
+// the lane's 32-register result (block b = q4/4, regs 4*(q4%4)..+3) — lane-contiguous 1-KB stores.
+__global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                     const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                     float* __restrict__ xscr) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int count = *count_ptr;
+    const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
+    const int nwork = ntiles * sc.V;
+    const float pe_pi = 3.14159274101257324f;  // float32(pi), spatial.py:42-47
+
+    for (int wi = wave; wi < nwork; wi += nwaves) {
+        const int t = wi / sc.V, v = wi - t * sc.V;
+        int ci = t * KPN_TILE + p;
+        if (ci >= count) ci = count - 1;  // pad lanes recompute the last point; their result is never read
+        const int64_t n = list[ci];
+        float P[3], D[3];
+        kpn_get_point(ps, n, P, D);
+        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+        const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+
+        // ---- layers1.0 : [168 keypoint encoding | 64 geometry channels] -> 128, softplus ----
+        float act[68];
+        {
+            const float* E = tb + KPN_TBL_EXT;  // camera-space position, spatial.py:76
+            const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
+            const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
+            const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
+            const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
+            kpn_f32x16 acc[4];
+            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_0A), h, acc);
+            // group j = keypoint j + 12h: 7 encoding values (spatial.py:110-118), produced while the
+            // previous keypoint's 28 MFMAs issue
+            kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
+                constexpr int j = decltype(gi)::value;
+                const float dx = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
+                const float d2 = KADD(KADD(KMUL(dx, dx), KMUL(dy, dy)), KMUL(dz, dz));
+                const float w = expf(-d2 / sc.two_sigma2);
+                float s1, c1;
+                sincosf(KMUL(dz, pe_pi), &s1, &c1);
+                // sin/cos(2y), sin/cos(4y): the reference's arguments are exactly 2y and 4y
+                // (float32(2*pi) == 2*float32(pi)), so the double-angle identities apply to them
+                const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
+                const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
+                x[0] = dz * w;
+                x[1] = s1 * w; x[2] = c1 * w;
+                x[3] = s2 * w; x[4] = c2 * w;
+                x[5] = s4 * w; x[6] = c4 * w;
+            }, acc);
+            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);  // model.py:763-765
+            const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
+            kpn_mfma_layer<32, 4, 4>(wp + kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp);
+                x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
+            }, acc);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[16 * b + r] = kpn_softplus100(acc[b][r]);
+        }
+        // ---- layers1.1 : 128 -> 128, softplus ----
+        {
+            kpn_f32x16 acc[4];
+            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_1), h, acc);
+            kpn_mfma_layer_regs<64, 4>(wp + kpn_seg_woff(SEG_G1_1), lane, act, acc);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[16 * b + r] = kpn_softplus100(acc[b][r]);
+        }
+        // ---- layers1.2 : [128 | 8 hd channels] -> 120, softplus (skip connection, utils.py:706-713) ----
+        {
+            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
+            const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
+            act[64] = f.x; act[65] = f.y; act[66] = f.z; act[67] = f.w;
+            kpn_f32x16 acc[4];
+            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_2), h, acc);
+            kpn_mfma_layer_regs<68, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, act, acc);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[16 * b + r] = kpn_softplus100(acc[b][r]);
+        }
+        // ---- layers1.3 : 120 -> 64, linear ----
+        {
+            kpn_f32x16 acc[2];
+            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G1_3), h, acc);
+            kpn_mfma_layer_regs<64, 2>(wp + kpn_seg_woff(SEG_G1_3), lane, act, acc);
+            float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * 8) * 64 + lane;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    dst[(b * 4 + qd) * 64] =
+                        make_float4(acc[b][4 * qd + 0], acc[b][4 * qd + 1], acc[b][4 * qd + 2], acc[b][4 * qd + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-view inputs of the IBR head for this lane's point (query_color, model.py:806-832)
+struct kpn_ibr_view {
+    float xb0[16];  // x' rows rowmap(r,h): x' = [lat24 | rgb3 | tex8] + ray_encoder(ray_diff)   (block 0)
+    float xb1[3];   // x' rows 32..34 (h == 0 lanes only)
+    float rd[4];    // ray_diff = [direction(3), dot]
+    float rgb[3];   // sampled source colour
+};
+
+__device__ __forceinline__ void kpn_ibr_view_inputs(const kpn_scene_dev& sc, const float* __restrict__ wp, int v,
+                                                    int lane, int h, const float (&P)[3], const float (&D)[3],
+                                                    const float (&lat0)[16], kpn_ibr_view& o) {
+    const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+    const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+    const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+    const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
+    o.rgb[0] = c.x; o.rgb[1] = c.y; o.rgb[2] = c.z;
+    const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+    const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+    const float4 t0 = kpn_tap4(tx, 8, 0, tt), t1 = kpn_tap4(tx, 8, 4, tt);       // model.py:818
+    // ray-direction difference, model.py:823-832
+    const float* cp = tb + KPN_TBL_CPOS;
+    float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+    cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+    const float r0 = KSUB(D[0], cr[0]), r1 = KSUB(D[1], cr[1]), r2 = KSUB(D[2], cr[2]);
+    const float rn = sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2));
+    const float rc = fmaxf(rn, 1e-6f);
+    o.rd[0] = r0 / rc; o.rd[1] = r1 / rc; o.rd[2] = r2 / rc;
+    o.rd[3] = kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]);
+    // ray_encoder: Linear(4,16) ELU Linear(16,35) ELU  (model.py:1246,1279)
+    const float in4[4] = {h ? o.rd[1] : o.rd[0], h ? o.rd[3] : o.rd[2], 0.0f, 0.0f};
+    kpn_f32x16 a1[1];
+    kpn_load_bias<1>(wp + kpn_seg_boff(SEG_RE_0), h, a1);
+    kpn_mfma_layer_regs<4, 1>(wp + kpn_seg_woff(SEG_RE_0), lane, in4, a1);
+    float in8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) in8[r] = kpn_elu(a1[0][r]);
+    kpn_f32x16 a2[2];
+    kpn_load_bias<2>(wp + kpn_seg_boff(SEG_RE_1), h, a2);
+    kpn_mfma_layer_regs<8, 2>(wp + kpn_seg_woff(SEG_RE_1), lane, in8, a2);
+    // x' = rgb_feat' + dir'  (model.py:1281-1284) in the permuted order [lat24 | rgb3 | tex8]:
+    // rows 24..27 live in regs 12..15 of the h=0 lanes, rows 28..31 in regs 12..15 of h=1, rows 32..34
+    // in block 1 regs 0..2 of h=0
+    const float f12 = h ? t0.y : c.x, f13 = h ? t0.z : c.y, f14 = h ? t0.w : c.z, f15 = h ? t1.x : t0.x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o.xb0[r] = kpn_elu(a2[0][r]) + lat0[r];
+    o.xb0[12] += f12; o.xb0[13] += f13; o.xb0[14] += f14; o.xb0[15] += f15;
+    o.xb1[0] = kpn_elu(a2[1][0]) + (h ? 0.0f : t1.y);
+    o.xb1[1] = kpn_elu(a2[1][1]) + (h ? 0.0f : t1.z);
+    o.xb1[2] = kpn_elu(a2[1][2]) + (h ? 0.0f : t1.w);
+}
+
+__global__ __launch_bounds__(256, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                       const float* __restrict__ xscr, int mode, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int count = *count_ptr;
+    const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
+    const int V = sc.V;
+    const float ani = wp[kpn_scalar_off() + 0];  // |ani_al|
+
+    for (int t = wave; t < ntiles; t += nwaves) {
+        const int ci_raw = t * KPN_TILE + p;
+        const int ci = ci_raw < count ? ci_raw : count - 1;
+        const int64_t n = list[ci];
+        float P[3], D[3];
+        kpn_get_point(ps, n, P, D);
+
+        // ---- pass 1 over views: boundary-smooth pooling weights (model.py:752-759) and the IBR
+        //      blend weights' min/sum (model.py:1287-1289); mask == 1 in every view for listed points
+        float pwsum = 0.0f, emin = 3.0e38f;
+        for (int v = 0; v < V; ++v) {
+            const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+            const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+            const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
+            float w3[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
+                w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
+            }
+            pwsum = KADD(pwsum, KMUL(KMUL(w3[0], w3[1]), w3[2]));
+            const float* cp = tb + KPN_TBL_CPOS;
+            float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+            const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+            const float dot = kpn_dot3(cr[0] / nrm, cr[1] / nrm, cr[2] / nrm, D[0], D[1], D[2]);
+            emin = fminf(emin, expf(KMUL(ani, KSUB(dot, 1.0f))));
+        }
+        // ---- pooled mean / var over views of the 64-vector (utils.py:731-748), two passes ----
+        float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
+#pragma unroll
+        for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
+        float esum = 0.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int v = 0; v < V; ++v) {
+                const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+                const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+                const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
+                float w3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
+                    w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
+                }
+                const float pw = KMUL(KMUL(w3[0], w3[1]), w3[2]) / KADD(pwsum, 1e-6f);
+                if (pass == 0) {  // IBR blend-weight normaliser
+                    const float* cp = tb + KPN_TBL_CPOS;
+                    float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+                    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+                    const float dot = kpn_dot3(cr[0] / nrm, cr[1] / nrm, cr[2] / nrm, D[0], D[1], D[2]);
+                    esum = KADD(esum, KSUB(expf(KMUL(ani, KSUB(dot, 1.0f))), emin));
+                }
+                const float4* src = reinterpret_cast<const float4*>(xscr) + ((size_t)(t * V + v) * 8) * 64 + lane;
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    const float4 x = src[q4 * 64];
+                    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q4 + e;
+                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xs[e]));
+                        else { const float d = KSUB(xs[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
+                    }
+                }
+            }
+        }
+        // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587) ----
+        float sdf_raw, rad;
+        {
+            float a64[32];
+            kpn_f32x16 acc[2];
+            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G2_0), h, acc);
+            kpn_mfma_layer_regs<64, 2>(wp + kpn_seg_woff(SEG_G2_0), lane, pooled, acc);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a64[16 * b + r] = kpn_softplus100(acc[b][r]);
+            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G2_1), h, acc);
+            kpn_mfma_layer_regs<32, 2>(wp + kpn_seg_woff(SEG_G2_1), lane, a64, acc);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a64[16 * b + r] = kpn_softplus100(acc[b][r]);
+            kpn_f32x16 o2[1];
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_G2_2), h, o2);
+            kpn_mfma_layer_regs<32, 1>(wp + kpn_seg_woff(SEG_G2_2), lane, a64, o2);
+            sdf_raw = o2[0][0];  // rows 0,1 live in regs 0,1 of the h=0 lanes
+            rad = o2[0][1];
+        }
+        // ---- ibr_compress_gfeat 128 -> 24 (model.py:819), rows already in x' order ----
+        float lat0[16];
+        {
+            kpn_f32x16 acc[1];
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_CMP), h, acc);
+            kpn_mfma_layer_regs<64, 1>(wp + kpn_seg_woff(SEG_CMP), lane, pooled, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
+        }
+        // ---- IBR head (model.py:1267-1302).  fused mean/var over views of x' (utils.py:91-95) ----
+        float mv[40];  // K-steps: mean' (16 + 3 + pad), var' (16 + 3 + pad)
+#pragma unroll
+        for (int i = 0; i < 40; ++i) mv[i] = 0.0f;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int v = 0; v < V; ++v) {
+                kpn_ibr_view iv;
+                kpn_ibr_view_inputs(sc, wp, v, lane, h, P, D, lat0, iv);
+                const float wv = KSUB(expf(KMUL(ani, KSUB(iv.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
+#pragma unroll
+                for (int i = 0; i < 19; ++i) {
+                    const float x = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
+                    if (pass == 0) mv[i] = KADD(mv[i], KMUL(x, wv));
+                    else { const float d = KSUB(x, mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
+                }
+            }
+        }
+        // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
+        kpn_f32x16 base[2];
+        kpn_load_bias<2>(wp + kpn_seg_boff(SEG_BL_0A), h, base);
+        kpn_mfma_layer_regs<40, 2>(wp + kpn_seg_woff(SEG_BL_0A), lane, mv, base);
+
+        // online softmax over views of the colour logits, blending the SOURCE colours (model.py:1300-1301)
+        float lmax = -3.0e38f, lden = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            kpn_ibr_view iv;
+            kpn_ibr_view_inputs(sc, wp, v, lane, h, P, D, lat0, iv);
+            const float wv = KSUB(expf(KMUL(ani, KSUB(iv.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
+            float xin[20];
+#pragma unroll
+            for (int i = 0; i < 19; ++i) xin[i] = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
+            xin[19] = 0.0f;
+            kpn_f32x16 a[2] = {base[0], base[1]};
+            kpn_mfma_layer_regs<20, 2>(wp + kpn_seg_woff(SEG_BL_0B), lane, xin, a);  // base_layer.0 (x part)
+            float h32[32];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h32[16 * b + r] = kpn_elu(a[b][r]);
+            kpn_f32x16 xa[1];
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_BL_1), h, xa);
+            kpn_mfma_layer_regs<32, 1>(wp + kpn_seg_woff(SEG_BL_1), lane, h32, xa);  // base_layer.2
+            float x[16], tin[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = kpn_elu(xa[0][r]); tin[r] = x[r] * wv; }  // :1292-1294
+            kpn_f32x16 va[1];
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V1_0), h, va);
+            kpn_mfma_layer_regs<16, 1>(wp + kpn_seg_woff(SEG_V1_0), lane, tin, va);  // vis_layer1.0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
+            kpn_f32x16 vb[2];
+            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_V1_1), h, vb);
+            kpn_mfma_layer_regs<16, 2>(wp + kpn_seg_woff(SEG_V1_1), lane, tin, vb);  // vis_layer1.2 (33 rows)
+            const float visr = __shfl(kpn_elu(vb[1][0]), p);                     // row 32 sits in lane p (h=0)
+            const float sv = kpn_sigmoid(visr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = x[r] + kpn_elu(vb[0][r]); tin[r] = x[r] * sv; }  // :1295-1297 (mask = 1)
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V2_0), h, va);
+            kpn_mfma_layer_regs<16, 1>(wp + kpn_seg_woff(SEG_V2_0), lane, tin, va);  // vis_layer2.0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V2_1), h, va);
+            kpn_mfma_layer_regs<16, 1>(wp + kpn_seg_woff(SEG_V2_1), lane, tin, va);  // vis_layer2.2 (1 row)
+            const float vis = kpn_sigmoid(__shfl(va[0][0], p));                  // :1297
+            float oin[20];  // out_layer.0 input [x32 | vis | ray_diff4]  (:1300)
+            oin[19] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oin[r] = x[r];
+            oin[16] = h ? iv.rd[0] : vis;
+            oin[17] = h ? iv.rd[2] : iv.rd[1];
+            oin[18] = h ? 0.0f : iv.rd[3];
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_0), h, va);
+            kpn_mfma_layer_regs<20, 1>(wp + kpn_seg_woff(SEG_O_0), lane, oin, va);
+            float o8[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o8[r] = kpn_elu(va[0][r]);
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_1), h, va);
+            kpn_mfma_layer_regs<8, 1>(wp + kpn_seg_woff(SEG_O_1), lane, o8, va);
+            float o4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = kpn_elu(va[0][r]);
+            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_2), h, va);
+            kpn_mfma_layer_regs<4, 1>(wp + kpn_seg_woff(SEG_O_2), lane, o4, va);
+            const float logit = va[0][0];  // valid in h=0 lanes
+            const float nmax = fmaxf(lmax, logit);
+            const float sc_old = expf(lmax - nmax), pn = expf(logit - nmax);
+            lden = lden * sc_old + pn;
+            c0 = c0 * sc_old + iv.rgb[0] * pn; c1 = c1 * sc_old + iv.rgb[1] * pn; c2 = c2 * sc_old + iv.rgb[2] * pn;
+            lmax = nmax;
+        }
+        if (h == 0 && ci_raw < count) {
+            float* o = out + n * 5;
+            if (mode == 1) { o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw; }  // eval_func with mask = 1
+            else { o[0] = sdf_raw; o[1] = rad; }
+            o[2] = c0 / lden; o[3] = c1 / lden; o[4] = c2 / lden;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lane-map self test: D = A(32x2) * B(2x32) with asymmetric operands, written out row-major.
+__global__ void k_selftest_mfma(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Dm) {
+    const int lane = threadIdx.x & 63;
+    const float a = A[(lane & 31) * 2 + (lane >> 5)];
+    const float b = B[(lane >> 5) * 32 + (lane & 31)];
+    kpn_f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Dm[KPN_ROWMAP(r, lane >> 5) * 32 + (lane & 31)] = c[r];
+}

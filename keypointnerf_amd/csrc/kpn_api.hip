@@ -1,0 +1,504 @@
+// kpn_api.hip — C ABI (include/kpnerf.h): weight packing, scene preparation, stage ops and the
+// hierarchical render pipeline.  Host code only launches kernels on the caller's stream; it never
+// synchronises or allocates (except kpn_selftest_mfma, a diagnostic).
+#include <string>
+#include <vector>
+
+#include "../../include/kpnerf.h"
+#include "kpn_device.h"
+
+// kernels (ray_kernels.hip / field_kernels.hip)
+#include "ray_kernels.hip"
+#include "field_kernels.hip"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define KPN_REQUIRE(cond, msg) do { if (!(cond)) return fail(KPN_EINVAL, std::string(msg) + " [" #cond "]"); } while (0)
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(KPN_ELAUNCH, std::string(what) + ": " + hipGetErrorString(e));
+    return KPN_OK;
+}
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+extern "C" int kpn_abi_version(void) { return KPN_ABI_VERSION; }
+extern "C" const char* kpn_last_error(void) { return g_err.c_str(); }
+extern "C" int kpn_is_device_build(void) {
+#ifdef KPN_SIMT_EMU
+    return 0;
+#else
+    return 1;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+namespace {
+enum { P_G1_0, P_G1_1, P_G1_2, P_G1_3, P_G2_0, P_G2_1, P_G2_2, P_CMP, P_RE_0, P_RE_1, P_BL_0, P_BL_1, P_V1_0, P_V1_1,
+       P_V2_0, P_V2_1, P_O_0, P_O_1, P_O_2, P_COUNT };
+const int plain_dims[P_COUNT][2] = {{128, 232}, {128, 128}, {120, 136}, {64, 120}, {64, 128}, {64, 64}, {2, 64},
+                                    {24, 128},  {16, 4},    {35, 16},   {64, 105}, {32, 64},  {32, 32}, {33, 32},
+                                    {32, 32},   {1, 32},    {16, 37},   {8, 16},   {1, 8}};
+struct Plain { const float* w[P_COUNT]; const float* b[P_COUNT]; float ani_al; };
+void bind_plain(const float* flat, Plain& pl) {
+    const float* p = flat;
+    for (int l = 0; l < P_COUNT; ++l) {
+        pl.w[l] = p; p += plain_dims[l][0] * plain_dims[l][1];
+        pl.b[l] = p; p += plain_dims[l][0];
+    }
+    pl.ani_al = *p;
+}
+// chained input: K-step s = 16*block + r is input feature 32*block + rowmap(r, h)
+inline int chain_feature(int s, int h) { return 32 * (s / 16) + KPN_ROWMAP(s % 16, h); }
+// x' order of the 35-vector: rows 0..23 = lat (orig 11..34), 24..26 = rgb (orig 0..2), 27..34 = tex (orig 3..10)
+inline int xprime_to_orig(int q) { return q < 24 ? 11 + q : (q < 27 ? q - 24 : q - 24); }
+// x' K-steps (20): s<16 -> row rowmap(s,h); s = 16..18 -> row 32 + rowmap(s-16, h); s = 19 -> pad
+inline int xstep_row(int s, int h) { return s < 16 ? KPN_ROWMAP(s, h) : (s < 19 ? 32 + KPN_ROWMAP(s - 16, h) : 9999); }
+
+template <class FMap, class OMap>
+void pack_segment(float* packed, int seg, const float* W, const float* b, int out_dim, int in_dim, FMap fmap, OMap omap,
+                  bool with_bias = true) {
+    const int KS = kpn_seg_shapes[seg].ks, NOB = kpn_seg_shapes[seg].nob, G = kpn_seg_shapes[seg].g;
+    const int NF = G * NOB;
+    float* w = packed + kpn_seg_woff(seg);
+    float* bb = packed + kpn_seg_boff(seg);
+    for (int s = 0; s < KS; ++s)
+        for (int ob = 0; ob < NOB; ++ob)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                const int orow = omap(ob * 32 + i);
+                const int f = fmap(s, h);
+                float val = 0.0f;
+                if (orow >= 0 && orow < out_dim && f >= 0 && f < in_dim) val = W[(size_t)orow * in_dim + f];
+                w[((size_t)(s / G) * 64 + lane) * NF + (s % G) * NOB + ob] = val;
+            }
+    for (int ob = 0; ob < NOB; ++ob)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int orow = omap(ob * 32 + KPN_ROWMAP(r, h));
+                bb[(ob * 2 + h) * 16 + r] = (with_bias && orow >= 0 && orow < out_dim) ? b[orow] : 0.0f;
+            }
+}
+float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
+}  // namespace
+
+extern "C" size_t kpn_plain_weight_floats(void) {
+    size_t n = 1;
+    for (int l = 0; l < P_COUNT; ++l) n += (size_t)plain_dims[l][0] * plain_dims[l][1] + plain_dims[l][0];
+    return n;
+}
+extern "C" size_t kpn_packed_weight_floats(void) { return (size_t)kpn_packed_floats(); }
+
+extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
+    KPN_REQUIRE(plain_host && packed_host, "null pointer");
+    Plain pl;
+    bind_plain(plain_host, pl);
+    auto ident = [](int row) { return row; };
+    auto chain = [](int s, int h) { return chain_feature(s, h); };
+    float* P = packed_host;
+    // layers1.0: part A, K-steps 0..83 keypoint encoding (j = s/7 -> keypoint j+12h, t = s%7 -> PE block t:
+    // feature t*24 + kp, spatial.py:36-39,117); part B, 32 K-steps: geometry channel 32h + s (feature 168 + c)
+    pack_segment(P, SEG_G1_0A, pl.w[P_G1_0], pl.b[P_G1_0], 128, 232,
+                 [](int s, int h) { return (s % 7) * 24 + (s / 7) + 12 * h; }, ident);
+    pack_segment(P, SEG_G1_0B, pl.w[P_G1_0], pl.b[P_G1_0], 128, 232, [](int s, int h) { return 168 + 32 * h + s; }, ident,
+                 /*with_bias=*/false);
+    pack_segment(P, SEG_G1_1, pl.w[P_G1_1], pl.b[P_G1_1], 128, 128, chain, ident);
+    // layers1.2: [128 chained | hd channel 4h + (s-64)]
+    pack_segment(P, SEG_G1_2, pl.w[P_G1_2], pl.b[P_G1_2], 120, 136,
+                 [](int s, int h) { return s < 64 ? chain_feature(s, h) : 128 + 4 * h + (s - 64); }, ident);
+    pack_segment(P, SEG_G1_3, pl.w[P_G1_3], pl.b[P_G1_3], 64, 120, chain, ident);
+    // layers2.0: [mean64 | var64], each in chained order
+    pack_segment(P, SEG_G2_0, pl.w[P_G2_0], pl.b[P_G2_0], 64, 128,
+                 [](int s, int h) { return s < 32 ? chain_feature(s, h) : 64 + chain_feature(s - 32, h); }, ident);
+    pack_segment(P, SEG_G2_1, pl.w[P_G2_1], pl.b[P_G2_1], 64, 64, chain, ident);
+    pack_segment(P, SEG_G2_2, pl.w[P_G2_2], pl.b[P_G2_2], 2, 64, chain, ident);
+    // ibr_compress_gfeat: same input as layers2.0; output rows already in x' order (row q<24 = lat q)
+    pack_segment(P, SEG_CMP, pl.w[P_CMP], pl.b[P_CMP], 24, 128,
+                 [](int s, int h) { return s < 32 ? chain_feature(s, h) : 64 + chain_feature(s - 32, h); }, ident);
+    pack_segment(P, SEG_RE_0, pl.w[P_RE_0], pl.b[P_RE_0], 16, 4, [](int s, int h) { return s < 2 ? 2 * s + h : -1; }, ident);
+    // ray_encoder.2: output rows permuted to x' order
+    pack_segment(P, SEG_RE_1, pl.w[P_RE_1], pl.b[P_RE_1], 35, 16, chain,
+                 [](int q) { return q < 35 ? xprime_to_orig(q) : -1; });
+    // base_layer.0 columns: [mean35 | var35 | x35] (model.py:1292)
+    pack_segment(P, SEG_BL_0A, pl.w[P_BL_0], pl.b[P_BL_0], 64, 105,
+                 [](int s, int h) {
+                     const int q = xstep_row(s % 20, h);
+                     return q < 35 ? (s / 20) * 35 + xprime_to_orig(q) : -1;
+                 }, ident);
+    pack_segment(P, SEG_BL_0B, pl.w[P_BL_0], pl.b[P_BL_0], 64, 105,
+                 [](int s, int h) { const int q = xstep_row(s, h); return q < 35 ? 70 + xprime_to_orig(q) : -1; }, ident,
+                 /*with_bias=*/false);
+    pack_segment(P, SEG_BL_1, pl.w[P_BL_1], pl.b[P_BL_1], 32, 64, chain, ident);
+    pack_segment(P, SEG_V1_0, pl.w[P_V1_0], pl.b[P_V1_0], 32, 32, chain, ident);
+    pack_segment(P, SEG_V1_1, pl.w[P_V1_1], pl.b[P_V1_1], 33, 32, chain, ident);
+    pack_segment(P, SEG_V2_0, pl.w[P_V2_0], pl.b[P_V2_0], 32, 32, chain, ident);
+    pack_segment(P, SEG_V2_1, pl.w[P_V2_1], pl.b[P_V2_1], 1, 32, chain, ident);
+    // out_layer.0 columns: [x32 | vis | ray_diff4] (model.py:1300); extra K-steps 16,17,18
+    pack_segment(P, SEG_O_0, pl.w[P_O_0], pl.b[P_O_0], 16, 37,
+                 [](int s, int h) {
+                     if (s < 16) return chain_feature(s, h);
+                     const int f = 32 + 2 * (s - 16) + h;
+                     return (s < 19 && f < 37) ? f : -1;
+                 }, ident);
+    pack_segment(P, SEG_O_1, pl.w[P_O_1], pl.b[P_O_1], 8, 16, chain, ident);
+    pack_segment(P, SEG_O_2, pl.w[P_O_2], pl.b[P_O_2], 1, 8, chain, ident);
+    // scalars: |ani_al| (model.py:1287) and layers2(0), the query() result of a fully masked point
+    float* sc = P + kpn_scalar_off();
+    sc[0] = fabsf(pl.ani_al);
+    {
+        float a[64], b2[64], o2[2];
+        for (int o = 0; o < 64; ++o) a[o] = softplus100_host(pl.b[P_G2_0][o]);
+        for (int o = 0; o < 64; ++o) {
+            float acc = 0.0f;
+            for (int i = 0; i < 64; ++i) acc += pl.w[P_G2_1][o * 64 + i] * a[i];
+            b2[o] = softplus100_host(acc + pl.b[P_G2_1][o]);
+        }
+        for (int o = 0; o < 2; ++o) {
+            float acc = 0.0f;
+            for (int i = 0; i < 64; ++i) acc += pl.w[P_G2_2][o * 64 + i] * b2[i];
+            o2[o] = acc + pl.b[P_G2_2][o];
+        }
+        sc[1] = o2[0]; sc[2] = o2[1]; sc[3] = 0.0f;
+    }
+    return KPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scene
+namespace {
+struct SceneLayout { size_t table, rgbm, geo0, geo1, tex, total; };  // float offsets
+SceneLayout scene_layout(const kpn_scene_desc* d) {
+    SceneLayout L;
+    size_t o = 0;
+    L.table = o; o += align_up((size_t)d->n_views * KPN_TBL_STRIDE, 64);
+    L.rgbm = o; o += align_up((size_t)d->n_views * d->src_h * d->src_w * 4, 64);
+    L.geo0 = o; o += align_up((size_t)d->n_views * d->geo0_h * d->geo0_w * 64, 64);
+    L.geo1 = o; o += align_up((size_t)d->n_views * d->geo1_h * d->geo1_w * 8, 64);
+    L.tex = o; o += align_up((size_t)d->n_views * d->tex_h * d->tex_w * 8, 64);
+    L.total = o;
+    return L;
+}
+int check_desc(const kpn_scene_desc* d) {
+    KPN_REQUIRE(d != nullptr, "scene desc is null");
+    KPN_REQUIRE(d->n_views >= 1 && d->n_views <= KPN_MAX_VIEWS, "n_views out of range");
+    KPN_REQUIRE(d->src_h > 1 && d->src_w > 1 && d->geo0_h > 1 && d->geo0_w > 1 && d->geo1_h > 1 && d->geo1_w > 1 &&
+                d->tex_h > 1 && d->tex_w > 1, "map sizes must be > 1");
+    KPN_REQUIRE(d->zfar > d->znear && d->nml_scale > 0.0f && d->sigma > 0.0f, "bad scalar parameters");
+    KPN_REQUIRE(d->KRT && d->extrin && d->kpt3d && d->img && d->geo0 && d->geo1 && d->tex, "null scene tensor");
+    KPN_REQUIRE(d->disable_fg_mask || d->fg_mask, "fg_mask is null");
+    return KPN_OK;
+}
+kpn_scene_dev scene_dev(const kpn_scene_desc* d, const void* ws) {
+    const SceneLayout L = scene_layout(d);
+    const float* base = static_cast<const float*>(ws);
+    kpn_scene_dev s;
+    s.V = d->n_views; s.H = d->src_h; s.W = d->src_w;
+    s.g0h = d->geo0_h; s.g0w = d->geo0_w; s.g1h = d->geo1_h; s.g1w = d->geo1_w; s.th = d->tex_h; s.tw = d->tex_w;
+    s.disable_fg_mask = d->disable_fg_mask;
+    s.znear = d->znear; s.zfar = d->zfar; s.nml_scale = d->nml_scale;
+    s.two_sigma2 = (float)(2.0 * ((double)d->sigma * (double)d->sigma));  // spatial.py:114
+    s.table = base + L.table; s.rgbm = base + L.rgbm; s.geo0 = base + L.geo0; s.geo1 = base + L.geo1; s.tex = base + L.tex;
+    return s;
+}
+}  // namespace
+
+extern "C" size_t kpn_scene_workspace_bytes(const kpn_scene_desc* d) {
+    if (check_desc(d) != KPN_OK) return 0;
+    return scene_layout(d).total * sizeof(float);
+}
+
+extern "C" int kpn_scene_prepare(const kpn_scene_desc* d, void* scene_ws, void* stream) {
+    if (int e = check_desc(d)) return e;
+    KPN_REQUIRE(scene_ws != nullptr, "scene workspace is null");
+    const SceneLayout L = scene_layout(d);
+    float* base = static_cast<float*>(scene_ws);
+    const int V = d->n_views;
+    KPN_LAUNCH(k_scene_table, dim3(1), dim3(64), stream, V, d->KRT, d->extrin, d->kpt3d, base + L.table);
+    const int64_t HW = (int64_t)d->src_h * d->src_w;
+    KPN_LAUNCH(k_pack_rgbm, grid1d(V * HW, 256), dim3(256), stream, (int64_t)(V * HW), HW, d->img,
+               d->disable_fg_mask ? (const uint8_t*)nullptr : d->fg_mask, base + L.rgbm);
+    const int64_t hw0 = (int64_t)d->geo0_h * d->geo0_w, hw1 = (int64_t)d->geo1_h * d->geo1_w, hwt = (int64_t)d->tex_h * d->tex_w;
+    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hw0 * 64, 256), dim3(256), stream, (int64_t)(V * hw0 * 64), 64, hw0, d->geo0, base + L.geo0);
+    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hw1 * 8, 256), dim3(256), stream, (int64_t)(V * hw1 * 8), 8, hw1, d->geo1, base + L.geo1);
+    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hwt * 8, 256), dim3(256), stream, (int64_t)(V * hwt * 8), 8, hwt, d->tex, base + L.tex);
+    return check_launch("kpn_scene_prepare");
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage ops
+extern "C" int kpn_ray_bbox_intersection(const float* bounds, const float* orig, const float* direct, int64_t R,
+                                         float* near_o, float* far_o, uint8_t* hit_o, void* stream) {
+    KPN_REQUIRE(bounds && orig && direct && near_o && far_o && hit_o, "null pointer");
+    KPN_REQUIRE(R >= 0, "negative ray count");
+    if (R == 0) return KPN_OK;
+    KPN_LAUNCH(k_ray_bbox, grid1d(R, 256), dim3(256), stream, R, bounds, orig, direct, near_o, far_o, hit_o);
+    return check_launch("kpn_ray_bbox_intersection");
+}
+
+extern "C" int kpn_make_rays(const float* K, const float* RT, float znear, float zfar, const float* bounds, int32_t x0,
+                             int32_t y0, int32_t step, int32_t nx, int32_t ny, float* dirs, float* cam_pos,
+                             float* near_o, float* far_o, void* stream) {
+    KPN_REQUIRE(K && RT && bounds && dirs && cam_pos && near_o && far_o, "null pointer");
+    KPN_REQUIRE(nx > 0 && ny > 0 && step > 0, "bad pixel grid");
+    KPN_LAUNCH(k_make_rays, grid1d((int64_t)nx * ny, 256), dim3(256), stream, K, RT, znear, zfar, bounds, (int)x0, (int)y0,
+               (int)step, (int)nx, (int)ny, dirs, cam_pos, near_o, far_o);
+    return check_launch("kpn_make_rays");
+}
+
+extern "C" int kpn_importance_sample(const float* contrib, const float* z, const float* u, int64_t R, int32_t Dm2,
+                                     int32_t n, float* out, void* stream) {
+    KPN_REQUIRE(contrib && z && out, "null pointer");
+    KPN_REQUIRE(Dm2 >= 1 && Dm2 + 1 <= KPN_IS_MAXD, "bin count out of range (<= 128)");
+    KPN_REQUIRE(n >= 1 && R >= 0, "bad sizes");
+    if (R == 0) return KPN_OK;
+    KPN_LAUNCH(k_importance, grid1d(R, 64), dim3(64), stream, R, (int)Dm2, (int)n, contrib, z, u, out);
+    return check_launch("kpn_importance_sample");
+}
+
+extern "C" int kpn_rgba2out(const float* rgba, const float* z, int64_t R, int32_t S, float* color, float* depth,
+                            float* alpha, float* contrib, float* sdf, void* stream) {
+    KPN_REQUIRE(rgba && z && color && depth && alpha && sdf, "null pointer");
+    KPN_REQUIRE(S >= 1 && S <= 64 * KPN_MAX_PER_LANE, "samples per ray out of range (<= 512)");
+    if (R <= 0) return R == 0 ? KPN_OK : fail(KPN_EINVAL, "negative ray count");
+    const int64_t blocks = (R + 3) / 4;  // 4 waves per block, one ray per wave per iteration
+    KPN_LAUNCH(k_rgba2out, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), stream, R, (int)S, rgba, z, color,
+               depth, alpha, contrib, sdf);
+    return check_launch("kpn_rgba2out");
+}
+
+// ---------------------------------------------------------------------------------------------
+// field query
+namespace {
+struct QueryLayout { size_t count, list, xscr, total; };  // byte offsets
+QueryLayout query_layout(int64_t N, int V) {
+    QueryLayout L;
+    size_t o = 0;
+    L.count = o; o += 256;
+    L.list = o; o += align_up((size_t)N * sizeof(int), 256);
+    const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
+    L.xscr = o; o += align_up(ntiles * (size_t)V * 8 * 64 * sizeof(float4), 256);
+    L.total = o;
+    return L;
+}
+int field_grid_blocks() {
+    // persistent grid: 256 CUs x 2 blocks of 256 threads (launch_bounds(256,2) -> 8 waves per CU)
+#ifdef KPN_SIMT_EMU
+    return 8;
+#else
+    return 512;
+#endif
+}
+// ---- measurement hooks ----
+#ifndef KPN_SIMT_EMU
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    int* counts_host = nullptr;   // pinned
+    size_t used = 0, cap = 0;
+    int V = 0;
+};
+static ProfState g_prof;
+#endif
+
+int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
+              uint8_t* valid, void* ws, void* stream) {
+    const QueryLayout L = query_layout(N, sc.V);
+    char* base = static_cast<char*>(ws);
+    int* count = reinterpret_cast<int*>(base + L.count);
+    int* list = reinterpret_cast<int*>(base + L.list);
+    float* xscr = reinterpret_cast<float*>(base + L.xscr);
+    hipMemsetAsync(count, 0, sizeof(int), (hipStream_t)stream);
+    KPN_LAUNCH(k_mask_compact, grid1d(N, 256), dim3(256), stream, sc, ps, N, mode, wp + kpn_scalar_off(), out, valid, list, count);
+    const int blocks = field_grid_blocks();
+#ifndef KPN_SIMT_EMU
+    const bool prof = g_prof.on && g_prof.used < g_prof.cap;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
+#endif
+    KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, xscr);
+#ifndef KPN_SIMT_EMU
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
+        (void)hipMemcpyAsync(g_prof.counts_host + g_prof.used, count, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        g_prof.V = sc.V;
+        ++g_prof.used;
+    }
+#endif
+    KPN_LAUNCH(k_fuse_color, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count,
+               (const float*)xscr, mode, out);
+    return check_launch("field query");
+}
+}  // namespace
+
+extern "C" size_t kpn_query_workspace_bytes(int64_t N, int32_t V) {
+    if (N <= 0 || V <= 0) return 0;
+    return query_layout(N, V).total;
+}
+
+extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts,
+                         const float* view, int32_t mode, float* out, uint8_t* valid, void* ws, size_t ws_bytes,
+                         void* stream) {
+    if (int e = check_desc(d)) return e;
+    KPN_REQUIRE(scene_ws && wp && pts && view && out && ws, "null pointer");
+    KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (raw query) or 1 (eval_func)");
+    KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
+    if (N == 0) return KPN_OK;
+    if (ws_bytes < query_layout(N, d->n_views).total) return fail(KPN_EWORKSPACE, "query workspace too small");
+    kpn_points ps{pts, view, nullptr, nullptr, nullptr, 1};
+    return run_field(scene_dev(d, scene_ws), ps, wp, N, mode, out, valid, ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hierarchical render
+namespace {
+struct RenderLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, rgba, contrib, color, depth, alpha, sdf, query, total; int64_t chunk; };
+int64_t pick_chunk(const kpn_render_args* a) {
+    const int64_t R = (int64_t)a->nx * a->ny;
+    int64_t c = a->chunk_rays > 0 ? a->chunk_rays : 16384;
+    return c < R ? c : R;
+}
+RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
+    RenderLayout L;
+    const int64_t R = (int64_t)a->nx * a->ny;
+    const int64_t C = pick_chunk(a);
+    const int64_t Sfull = a->n_coarse + (a->fine ? a->n_fine : 0);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
+    L.chunk = C;
+    L.cam_pos = take(64);
+    L.dirs = take((size_t)R * 3 * 4);
+    L.nearv = take((size_t)R * 4);
+    L.farv = take((size_t)R * 4);
+    L.zc = take((size_t)C * a->n_coarse * 4);
+    L.zf = take((size_t)C * Sfull * 4);
+    L.rgba = take((size_t)C * Sfull * 5 * 4);
+    L.contrib = take((size_t)C * Sfull * 4);
+    L.color = take((size_t)C * 3 * 4);
+    L.depth = take((size_t)C * 4);
+    L.alpha = take((size_t)C * 4);
+    L.sdf = take((size_t)C * 4);
+    L.query = take(query_layout(C * Sfull, d->n_views).total);
+    L.total = o;
+    return L;
+}
+int check_render(const kpn_render_args* a) {
+    KPN_REQUIRE(a != nullptr, "render args null");
+    KPN_REQUIRE(a->K && a->RT && a->bounds, "null camera/bounds");
+    KPN_REQUIRE(a->nx > 0 && a->ny > 0 && a->step > 0, "bad pixel grid");
+    KPN_REQUIRE(a->n_coarse >= 3 && a->n_coarse <= 128, "sample_per_ray_c must be in [3,128]");
+    KPN_REQUIRE(!a->fine || (a->n_fine >= 1 && a->n_fine <= 128), "sample_per_ray_f must be in [1,128]");
+    KPN_REQUIRE((int64_t)a->nx * a->ny < (1ll << 31), "too many rays");
+    return KPN_OK;
+}
+}  // namespace
+
+// scatter of per-chunk (rays, C) results into the planar (C, ny*nx) outputs
+__global__ void k_store_planar(int64_t r0, int64_t n, int64_t R, int C, const float* __restrict__ src, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    dst[(int64_t)c * R + r0 + r] = src[i];
+}
+
+extern "C" size_t kpn_render_workspace_bytes(const kpn_scene_desc* d, const kpn_render_args* a) {
+    if (check_desc(d) != KPN_OK || check_render(a) != KPN_OK) return 0;
+    return render_layout(d, a).total;
+}
+
+extern "C" int kpn_render_rays(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (int e = check_render(a)) return e;
+    KPN_REQUIRE(scene_ws && wp && ws, "null pointer");
+    const RenderLayout L = render_layout(d, a);
+    if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "render workspace too small");
+    char* base = static_cast<char*>(ws);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    const kpn_scene_dev sc = scene_dev(d, scene_ws);
+    const int64_t R = (int64_t)a->nx * a->ny;
+    const int Sc = a->n_coarse, Sf = a->fine ? a->n_fine : 0, Sfull = Sc + Sf;
+    KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
+               (int)a->step, (int)a->nx, (int)a->ny, F(L.dirs), F(L.cam_pos), F(L.nearv), F(L.farv));
+    for (int64_t r0 = 0; r0 < R; r0 += L.chunk) {
+        const int64_t n = (R - r0) < L.chunk ? (R - r0) : L.chunk;
+        const float* dirs = F(L.dirs) + r0 * 3;
+        KPN_LAUNCH(k_coarse_z, grid1d(n * Sc, 256), dim3(256), stream, n, Sc, (const float*)(F(L.nearv) + r0),
+                   (const float*)(F(L.farv) + r0), F(L.zc));
+        kpn_points ps{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc};
+        if (int e = run_field(sc, ps, wp, n * Sc, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;   // model.py:1062
+        if (int e = kpn_rgba2out(F(L.rgba), F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
+        if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
+        if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
+        if (a->alpha) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha);
+        if (a->fine) {
+            KPN_LAUNCH(k_fine_samples, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), F(L.zf));
+            kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull};
+            if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;  // :1082
+            if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
+            if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);
+            if (a->depth_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth_fine);
+            if (a->alpha_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha_fine);
+            if (a->sdf) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.sdf), a->sdf);
+        }
+    }
+    return check_launch("kpn_render_rays");
+}
+
+extern "C" int kpn_profile_enable(int32_t on) {
+#ifndef KPN_SIMT_EMU
+    if (on && g_prof.cap == 0) {
+        g_prof.cap = 8192;
+        g_prof.ev.resize(2 * g_prof.cap);
+        for (auto& e : g_prof.ev) if (hipEventCreate(&e) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventCreate failed");
+        if (hipHostMalloc((void**)&g_prof.counts_host, g_prof.cap * sizeof(int), 0) != hipSuccess)
+            return fail(KPN_ELAUNCH, "hipHostMalloc failed");
+    }
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+#endif
+    return KPN_OK;
+}
+extern "C" int kpn_profile_collect(double* ms_out, int64_t* launches_out, int64_t* rows_out) {
+    KPN_REQUIRE(ms_out && launches_out && rows_out, "null pointer");
+    *ms_out = 0.0; *launches_out = 0; *rows_out = 0;
+#ifndef KPN_SIMT_EMU
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventSynchronize failed");
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventElapsedTime failed");
+        *ms_out += ms;
+        *rows_out += (int64_t)g_prof.counts_host[i] * g_prof.V;
+    }
+    *launches_out = (int64_t)g_prof.used;
+    g_prof.used = 0;
+#endif
+    return KPN_OK;
+}
+extern "C" double kpn_flops_per_row(void) { return 2.0 * 70080.0; }
+
+extern "C" double kpn_flops_per_point(int32_t V) {
+    // algorithmic MACs: per (point,view) 70,080 (layers1) + 13,256 (IBR head);
+    // per point 12,416 (layers2) + 3,072 (compress)
+    return 2.0 * ((70080.0 + 13256.0) * V + 12416.0 + 3072.0);
+}
+
+extern "C" int kpn_selftest_mfma(float* scratch, void* stream, float* max_err_host) {
+    KPN_REQUIRE(scratch && max_err_host, "null pointer");
+    float A[64], B[64], Dm[1024];
+    for (int i = 0; i < 64; ++i) { A[i] = 0.37f * i - 7.0f + 0.011f * i * i; B[i] = 3.0f - 0.23f * i + (i % 5) * 0.7f; }
+    hipMemcpyAsync(scratch, A, sizeof(A), hipMemcpyHostToDevice, (hipStream_t)stream);
+    hipMemcpyAsync(scratch + 64, B, sizeof(B), hipMemcpyHostToDevice, (hipStream_t)stream);
+    KPN_LAUNCH(k_selftest_mfma, dim3(1), dim3(64), stream, (const float*)scratch, (const float*)(scratch + 64), scratch + 128);
+    hipMemcpyAsync(Dm, scratch + 128, sizeof(Dm), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    hipStreamSynchronize((hipStream_t)stream);
+    float me = 0.0f;
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            const float ref = fmaf(A[i * 2 + 1], B[32 + j], A[i * 2] * B[j]);
+            me = fmaxf(me, fabsf(ref - Dm[i * 32 + j]));
+        }
+    *max_err_host = me;
+    if (int e = check_launch("kpn_selftest_mfma")) return e;
+    return me < 1e-3f ? KPN_OK : fail(KPN_ELAUNCH, "MFMA lane map mismatch");
+}

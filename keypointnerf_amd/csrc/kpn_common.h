@@ -1,0 +1,96 @@
+// kpn_common.h — shared definitions of the gfx950 ray-march kernels.
+//
+// Written for CDNA4 only: 64-lane wavefronts, v_mfma_f32_32x32x2_f32, no CUDA/other-backend paths.
+// The single build-mode switch, KPN_SIMT_EMU, selects the host wave64 emulator used by the CPU test
+// suite (tests/simt/simt.h); it replaces the launch statement and a handful of intrinsics, never the
+// kernel logic.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef KPN_SIMT_EMU
+#include <hip/hip_runtime.h>
+typedef float kpn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float kpn_f32x4 __attribute__((ext_vector_type(4)));
+#define KPN_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
+__device__ __forceinline__ float kpn_fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float kpn_fast_log(float x) { return __logf(x); }
+#else
+#include <math.h>
+static inline float kpn_fast_exp(float x) { return expf(x); }
+static inline float kpn_fast_log(float x) { return logf(x); }
+#endif
+
+#define KPN_NKPT 24
+#define KPN_MAXV 16
+#define KPN_WAVE 64
+#define KPN_TILE 32   // points per wave tile = N dimension of v_mfma_f32_32x32x2_f32
+
+// ---------------------------------------------------------------------------------------------
+// Prepared scene (device workspace), all offsets in floats from the workspace base:
+//   table : V x KPN_TBL_STRIDE
+//   rgbm  : V x H x W x 4      [r,g,b,fg]   (model.py:737,806 sample the mask and the image)
+//   geo0  : V x g0h x g0w x 64 (channels last: one tap = one 256-B line)
+//   geo1  : V x g1h x g1w x 8
+//   tex   : V x th  x tw  x 8
+#define KPN_TBL_STRIDE 112
+#define KPN_TBL_KRT 0      // 3 rows x [m0 m1 m2 t]
+#define KPN_TBL_EXT 12     // 3 rows x [r0 r1 r2 t]
+#define KPN_TBL_CPOS 24    // source camera centre
+#define KPN_TBL_KCAM 28    // 24 x 3 keypoints in this camera's frame
+
+struct kpn_scene_dev {
+    int32_t V, H, W, g0h, g0w, g1h, g1w, th, tw, disable_fg_mask;
+    float znear, zfar, nml_scale, two_sigma2;
+    const float* table;
+    const float* rgbm;
+    const float* geo0;
+    const float* geo1;
+    const float* tex;
+};
+
+// ---------------------------------------------------------------------------------------------
+// MFMA weight segments.  One segment = one Linear layer (or a column slice of one) streamed as the
+// A operand of v_mfma_f32_32x32x2_f32 in the transposed formulation  out^T = W * in^T :
+//   A (32 out-rows x 2 k), lane l holds A[i = l&31][k = l>>5]
+//   B (2 k x 32 points),   lane l holds B[k = l>>5][j = l&31]   <- the activations, point j = l&31
+//   D (32 x 32),           lane l, reg r holds D[row = (r&3)+8(r>>2)+4(l>>5)][col = l&31]
+// so after a layer, lane (p = l&31, h = l>>5) owns output rows rowmap(r,h) of point p, and the next
+// layer consumes them straight from registers as its B operand at K-step s = 16*block + r: lanes<32
+// supply input feature 32*block+rowmap(r,0), lanes>=32 feature 32*block+rowmap(r,1).  The host packer
+// (kpn_pack_weights) permutes the weight columns to match; the K order of a dot product is free.
+// Stream layout of a segment: K-steps are taken in groups of G; W part [KS/G groups][64 lanes][G*NOB]
+// (a lane's A operands of one group are contiguous: G*NOB/4 dwordx4 loads, a wavefront reads one
+// contiguous block per group), then the bias part [NOB][2 halves][16 regs].
+enum {
+    SEG_G1_0A, SEG_G1_0B, SEG_G1_1, SEG_G1_2, SEG_G1_3,  // geometry MLP layers1 (per point x view)
+    SEG_G2_0, SEG_G2_1, SEG_G2_2, SEG_CMP,               // layers2 + ibr_compress_gfeat (per point)
+    SEG_RE_0, SEG_RE_1, SEG_BL_0A, SEG_BL_0B, SEG_BL_1,  // IBR head
+    SEG_V1_0, SEG_V1_1, SEG_V2_0, SEG_V2_1, SEG_O_0, SEG_O_1, SEG_O_2,
+    SEG_COUNT
+};
+struct kpn_seg_shape { int ks, nob, g; };
+// layers1.0 is split into its keypoint-encoding part (12 groups of 7 K-steps = one keypoint pair per
+// group) and its 64-channel feature part; x'-ordered 35-vectors take 20 K-steps (16 + 3 + 1 pad).
+#define KPN_SEG_SHAPES                                                                                      \
+    {84, 4, 7}, {32, 4, 4}, {64, 4, 4}, {68, 4, 4}, {64, 2, 4}, {64, 2, 4}, {32, 2, 4}, {32, 1, 4}, {64, 1, 4}, \
+    {4, 1, 4}, {8, 2, 4}, {40, 2, 4}, {20, 2, 4}, {32, 1, 4}, {16, 1, 4}, {16, 2, 4}, {16, 1, 4}, {16, 1, 4},     \
+    {20, 1, 4}, {8, 1, 4}, {4, 1, 4}
+static constexpr kpn_seg_shape kpn_seg_shapes[SEG_COUNT] = {KPN_SEG_SHAPES};
+
+constexpr int kpn_seg_wfloats(int seg) { return kpn_seg_shapes[seg].ks * kpn_seg_shapes[seg].nob * 64; }
+constexpr int kpn_seg_bfloats(int seg) { return kpn_seg_shapes[seg].nob * 32; }
+constexpr int kpn_seg_woff(int seg) {
+    int o = 0;
+    for (int i = 0; i < seg; ++i) o += kpn_seg_wfloats(i) + kpn_seg_bfloats(i);
+    return o;
+}
+constexpr int kpn_seg_boff(int seg) { return kpn_seg_woff(seg) + kpn_seg_wfloats(seg); }
+// scalars appended after the segments: [0] = |ani_al|, [1..2] = layers2(0) = (sdf_raw, rad) of a point
+// that is masked in every view, [3] pad
+constexpr int kpn_scalar_off() { return kpn_seg_woff(SEG_COUNT); }
+constexpr int kpn_packed_floats() { return kpn_scalar_off() + 4; }
+
+// row of the 32x32 D tile held by register r of a lane in half h
+#define KPN_ROWMAP(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

@@ -1,0 +1,171 @@
+// kpn_device.h — device-side helpers shared by the ray and field kernels (gfx950, wave64).
+#pragma once
+#include "kpn_common.h"
+
+// "geometry" arithmetic: separate IEEE multiply/add (no FMA contraction) so that projections, ray
+// set-up, AABB tests and mask thresholds are bit-identical to the scalar restatement they are tested
+// against (validity masks are discrete decisions; everything downstream depends on them).
+#define KMUL(a, b) __fmul_rn((a), (b))
+#define KADD(a, b) __fadd_rn((a), (b))
+#define KSUB(a, b) __fadd_rn((a), -(b))
+__device__ __forceinline__ float kpn_dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return KADD(KADD(KMUL(a0, b0), KMUL(a1, b1)), KMUL(a2, b2));
+}
+
+__device__ __forceinline__ float kpn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Softplus(beta=100, threshold=20), reference src/utils.py:523-524.  log(1+e^t)/100: the /100 makes
+// the fast exp/log's ~1e-6 relative error an absolute error < 1e-8.
+__device__ __forceinline__ float kpn_softplus100(float x) {
+    const float t = x * 100.0f;
+    const float sp = kpn_fast_log(1.0f + kpn_fast_exp(t)) * 0.01f;
+    return (t > 20.0f) ? x : sp;
+}
+__device__ __forceinline__ float kpn_elu(float x) { return x > 0.0f ? x : (kpn_fast_exp(x) - 1.0f); }
+
+// ---------------------------------------------------------------------------------------------
+// Projection of a world point into source view `tb` (per-view table): reference src/model.py:713-729.
+struct kpn_proj {
+    float xn, yn, zn;  // normalised to [-1,1]
+    int in;            // inside the view volume (xy within +-1.01, z >= znear)
+};
+__device__ __forceinline__ kpn_proj kpn_project(const float* __restrict__ tb, float px, float py, float pz,
+                                                const kpn_scene_dev& sc) {
+    const float* M = tb + KPN_TBL_KRT;
+    const float vx = KADD(kpn_dot3(px, py, pz, M[0], M[1], M[2]), M[3]);
+    const float vy = KADD(kpn_dot3(px, py, pz, M[4], M[5], M[6]), M[7]);
+    const float vz = KADD(kpn_dot3(px, py, pz, M[8], M[9], M[10]), M[11]);
+    const float x = vx / vz, y = vy / vz;
+    kpn_proj q;
+    q.xn = KSUB(KMUL(2.0f, x / KSUB((float)sc.W, 1.0f)), 1.0f);
+    q.yn = KSUB(KMUL(2.0f, y / KSUB((float)sc.H, 1.0f)), 1.0f);
+    q.zn = KSUB(KMUL(2.0f, KSUB(vz, sc.znear)) / KSUB(sc.zfar, sc.znear), 1.0f);
+    const float eps = 1e-2f;
+    q.in = (q.xn >= -1.0f - eps) && (q.xn <= 1.0f + eps) && (q.yn >= -1.0f - eps) && (q.yn <= 1.0f + eps) &&
+           (q.zn >= -1.0f);
+    return q;
+}
+
+// Bilinear taps of F.grid_sample(bilinear, border, align_corners=True) (reference src/utils.py:74-89)
+// on an h x w map: pixel offsets (y*w+x) of the 4 taps and their weights.  After the border clip the
+// +1 neighbours can only leave the map when their weight is exactly 0, so they are clamped instead
+// of skipped.
+struct kpn_taps {
+    int o00, o01, o10, o11;
+    float w00, w01, w10, w11;  // nw, ne, sw, se
+};
+__device__ __forceinline__ kpn_taps kpn_make_taps(float xn, float yn, int h, int w) {
+    float ix = KMUL(KADD(xn, 1.0f) / 2.0f, (float)(w - 1));
+    float iy = KMUL(KADD(yn, 1.0f) / 2.0f, (float)(h - 1));
+    ix = fminf(fmaxf(ix, 0.0f), (float)(w - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(h - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float x1f = fx + 1.0f, y1f = fy + 1.0f;
+    kpn_taps t;
+    t.w00 = KMUL(KSUB(x1f, ix), KSUB(y1f, iy));
+    t.w01 = KMUL(KSUB(ix, fx), KSUB(y1f, iy));
+    t.w10 = KMUL(KSUB(x1f, ix), KSUB(iy, fy));
+    t.w11 = KMUL(KSUB(ix, fx), KSUB(iy, fy));
+    const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    t.o00 = y0 * w + x0; t.o01 = y0 * w + x1; t.o10 = y1 * w + x0; t.o11 = y1 * w + x1;
+    return t;
+}
+// 4 consecutive channels of a channels-last map (C floats per pixel) starting at channel c0
+__device__ __forceinline__ float4 kpn_tap4(const float* __restrict__ map, int C, int c0, const kpn_taps& t) {
+    const float4 a = *reinterpret_cast<const float4*>(map + (size_t)t.o00 * C + c0);
+    const float4 b = *reinterpret_cast<const float4*>(map + (size_t)t.o01 * C + c0);
+    const float4 c = *reinterpret_cast<const float4*>(map + (size_t)t.o10 * C + c0);
+    const float4 d = *reinterpret_cast<const float4*>(map + (size_t)t.o11 * C + c0);
+    float4 r;  // same tap order as ATen: nw, ne, sw, se
+    r.x = KADD(KADD(KADD(KMUL(a.x, t.w00), KMUL(b.x, t.w01)), KMUL(c.x, t.w10)), KMUL(d.x, t.w11));
+    r.y = KADD(KADD(KADD(KMUL(a.y, t.w00), KMUL(b.y, t.w01)), KMUL(c.y, t.w10)), KMUL(d.y, t.w11));
+    r.z = KADD(KADD(KADD(KMUL(a.z, t.w00), KMUL(b.z, t.w01)), KMUL(c.z, t.w10)), KMUL(d.z, t.w11));
+    r.w = KADD(KADD(KADD(KMUL(a.w, t.w00), KMUL(b.w, t.w01)), KMUL(c.w, t.w10)), KMUL(d.w, t.w11));
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One Linear layer on the matrix cores (see kpn_common.h for the operand maps and stream layout).
+//   wseg : segment base; A stream [KS/G][64][G*NOB], bias [NOB][2][16]
+//   acc[ob][r]: 32-row output block ob.
+// The K loop is fully unrolled (B operands are registers) but software-pipelined by hand in groups of
+// G K-steps: the next group's A operands are fetched (dwordx4) and its B operands produced while the
+// current group's MFMAs issue, and a scheduling barrier closes every group — left alone, the
+// compiler hoists all ~1e3 weight loads of a layer to its top and spills them.
+template <int N>
+struct kpn_ic { static constexpr int value = N; };
+template <int I, int N, class F>
+__device__ __forceinline__ void kpn_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(kpn_ic<I>{});
+        kpn_static_for<I + 1, N>(f);
+    }
+}
+#ifdef KPN_SIMT_EMU
+#define KPN_SCHED_BARRIER() ((void)0)
+#define KPN_PIN_POINTER(p) ((void)0)
+#else
+#define KPN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// an opaque re-definition of a (wave-uniform) pointer: loads through it cannot be hoisted above this point
+#define KPN_PIN_POINTER(p) asm volatile("" : "+s"(p))
+#endif
+
+template <int NOB>
+__device__ __forceinline__ void kpn_load_bias(const float* __restrict__ bseg, int h, kpn_f32x16 (&acc)[NOB]) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const float4* b4 = reinterpret_cast<const float4*>(bseg + (ob * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = b4[q];
+            acc[ob][4 * q + 0] = b.x; acc[ob][4 * q + 1] = b.y; acc[ob][4 * q + 2] = b.z; acc[ob][4 * q + 3] = b.w;
+        }
+    }
+}
+template <int NF>
+__device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, int lane, float (&w)[NF]) {
+    static_assert(NF % 4 == 0, "a lane's operands of one group are whole float4s");
+    const float4* src = reinterpret_cast<const float4*>(gbase) + lane * (NF / 4);
+#pragma unroll
+    for (int q = 0; q < NF / 4; ++q) {
+        const float4 v = src[q];
+        w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+}
+// in_fn(kpn_ic<g>, float (&x)[G]) produces the B operands of K-steps [g*G, (g+1)*G)
+template <int KS, int NOB, int G, class InFn>
+__device__ __forceinline__ void kpn_mfma_layer(const float* __restrict__ wseg, int lane, InFn&& in_fn,
+                                               kpn_f32x16 (&acc)[NOB]) {
+    static_assert(KS % G == 0, "K-steps come in whole groups");
+    constexpr int NG = KS / G, NF = G * NOB;
+    float w[2][NF], x[2][G];
+    kpn_load_group<NF>(wseg, lane, w[0]);
+    in_fn(kpn_ic<0>{}, x[0]);
+    kpn_static_for<0, NG>([&](auto gi) {
+        constexpr int g = decltype(gi)::value;
+        constexpr int cur = g & 1, nxt = cur ^ 1;
+        if constexpr (g + 1 < NG) {
+            const float* gp = wseg + (size_t)(g + 1) * 64 * NF;
+            KPN_PIN_POINTER(gp);
+            kpn_load_group<NF>(gp, lane, w[nxt]);
+            in_fn(kpn_ic<g + 1>{}, x[nxt]);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][i * NOB + ob], x[cur][i], acc[ob], 0, 0, 0);
+        KPN_SCHED_BARRIER();
+    });
+}
+// B operands taken from a register array: K-step s reads src[s]
+template <int KS, int NOB, int G = 4, int NSRC>
+__device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ wseg, int lane, const float (&src)[NSRC],
+                                                    kpn_f32x16 (&acc)[NOB]) {
+    static_assert(NSRC >= KS, "operand array too short");
+    kpn_mfma_layer<KS, NOB, G>(wseg, lane, [&](auto gi, float (&x)[G]) {
+        constexpr int g = decltype(gi)::value;
+#pragma unroll
+        for (int i = 0; i < G; ++i) x[i] = src[g * G + i];
+    }, acc);
+}

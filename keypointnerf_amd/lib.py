@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI in include/kpnerf.h — the stub a maintainer of the (pure-Python)
+reference would add to call the gfx950 library.
+
+The product library is ``keypointnerf_amd/_lib/libkpnerf_hip.so`` (built by ``build.py`` /
+``__graft_entry__.build()``, hipcc --offload-arch=gfx950).  There is NO fallback: if it is missing
+or cannot be loaded, ``get_library()`` raises.  ``KpnLibrary(path)`` can bind any library exporting
+the same ABI; the CPU test-suite uses that to drive the host SIMT-emulator build of the very same
+kernel sources (tests/simt) with numpy buffers — never through this module's default path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "_lib", "libkpnerf_hip.so")
+
+c_f = ctypes.c_float
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+
+class SceneDesc(ctypes.Structure):
+    """struct kpn_scene_desc"""
+    _fields_ = [(n, c_i32) for n in ("n_views", "src_h", "src_w", "geo0_h", "geo0_w", "geo1_h", "geo1_w", "tex_h",
+                                     "tex_w", "disable_fg_mask")] + \
+               [(n, c_f) for n in ("znear", "zfar", "nml_scale", "sigma")] + \
+               [(n, c_p) for n in ("KRT", "extrin", "kpt3d", "img", "fg_mask", "geo0", "geo1", "tex")]
+
+
+class RenderArgs(ctypes.Structure):
+    """struct kpn_render_args"""
+    _fields_ = [(n, c_p) for n in ("K", "RT", "bounds")] + [("znear", c_f), ("zfar", c_f)] + \
+               [(n, c_i32) for n in ("x0", "y0", "step", "nx", "ny", "n_coarse", "n_fine", "fine", "chunk_rays")] + \
+               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")]
+
+
+# name -> (restype, argtypes); mirrors include/kpnerf.h one to one
+_SIGNATURES = {
+    "kpn_abi_version": (ctypes.c_int, []),
+    "kpn_last_error": (ctypes.c_char_p, []),
+    "kpn_is_device_build": (ctypes.c_int, []),
+    "kpn_plain_weight_floats": (c_sz, []),
+    "kpn_packed_weight_floats": (c_sz, []),
+    "kpn_pack_weights": (ctypes.c_int, [c_p, c_p]),
+    "kpn_scene_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc)]),
+    "kpn_scene_prepare": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p]),
+    "kpn_ray_bbox_intersection": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "kpn_make_rays": (ctypes.c_int, [c_p, c_p, c_f, c_f, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
+    "kpn_importance_sample": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p, c_p]),
+    "kpn_rgba2out": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "kpn_query_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "kpn_query": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_sz, c_p]),
+    "kpn_render_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),
+    "kpn_render_rays": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs), c_p, c_sz, c_p]),
+    "kpn_flops_per_point": (ctypes.c_double, [c_i32]),
+    "kpn_flops_per_row": (ctypes.c_double, []),
+    "kpn_profile_enable": (ctypes.c_int, [c_i32]),
+    "kpn_profile_collect": (ctypes.c_int, [c_p, c_p, c_p]),
+    "kpn_selftest_mfma": (ctypes.c_int, [c_p, c_p, c_p]),
+}
+ABI_VERSION = 1
+
+
+class KpnError(RuntimeError):
+    pass
+
+
+class KpnLibrary:
+    def __init__(self, path):
+        if not os.path.isfile(path):
+            raise KpnError(
+                f"{path} not found: the HIP library has not been built. Run `python build.py` "
+                f"(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        v = self.kpn_abi_version()
+        if v != ABI_VERSION:
+            raise KpnError(f"{path}: ABI version {v}, binding expects {ABI_VERSION}")
+
+    def check(self, code):
+        if code != 0:
+            raise KpnError(f"kpnerf error {code}: {self.kpn_last_error().decode()}")
+
+    def exported_symbols(self):
+        return sorted(_SIGNATURES)
+
+
+_default = None
+
+
+def get_library():
+    """The gfx950 product library; raises KpnError if it is not built (no fallback)."""
+    global _default
+    if _default is None:
+        lib = KpnLibrary(DEFAULT_LIB)
+        if not lib.kpn_is_device_build():
+            raise KpnError(f"{DEFAULT_LIB} is not a device build")
+        _default = lib
+    return _default

@@ -1,0 +1,232 @@
+"""PyTorch-facing operators of the gfx950 ray-march library (device tensors in, device tensors out).
+
+Each function mirrors one callable of the reference (names, argument meaning, shapes, error
+behaviour) and forwards to the C ABI in include/kpnerf.h on torch's CURRENT HIP stream:
+
+    ray_bbox_intersection  <- KeypointNeRF.ray_bbox_intersection  (reference src/model.py:1178-1237)
+    importance_sample      <- KeypointNeRF.importance_sample      (src/model.py:1110-1148)
+    rgba2out               <- KeypointNeRF.rgba2out               (src/model.py:1150-1176)
+    query                  <- KeypointNeRF.query                  (src/model.py:690-843, eval mode)
+    render_rays            <- KeypointNeRF.batch_render_pifu_nerf (src/model.py:942-1108, eval branch)
+
+torch is plumbing here (device memory, streams); the arithmetic is in csrc/*.hip.  Every op raises if
+its tensors are not on a HIP device or the library is missing — there is no CPU/eager fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as kl
+from .weights import effective_weights, flatten_plain
+
+_f32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=_f32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); keypointnerf_amd has no CPU path")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------------
+class PackedWeights:
+    """Hot-path parameters packed for the kernels; built from the reference's state dict / module."""
+
+    def __init__(self, state_dict_or_module, device="cuda"):
+        sd = state_dict_or_module.state_dict() if hasattr(state_dict_or_module, "state_dict") else state_dict_or_module
+        L = kl.get_library()
+        plain = flatten_plain(effective_weights(sd))
+        if plain.size != L.kpn_plain_weight_floats():
+            raise ValueError("unexpected hot-path parameter count")
+        packed = np.zeros(L.kpn_packed_weight_floats(), np.float32)
+        L.check(L.kpn_pack_weights(plain.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p)))
+        self.tensor = torch.from_numpy(packed).to(device)
+
+
+class PreparedScene:
+    """kpn_scene_desc + the prepared (channels-last) device workspace for one set of source views.
+
+    Arguments are the reference's own objects (reference src/model.py:336-355, 653-680):
+    img (V,3,H,W); cam dict {KRT,(K),extrin|sp_data['extrin'],width,height,znear,zfar,nml_scale};
+    feat_geo [ (V,64,h0,w0), (V,8,h1,w1) ]; feat_tex (V,8,ht,wt); sp_data {kpt3d (1,24,3), extrin (V,4,4)};
+    src_foreground_mask (1,V,1,H,W) bool.
+    """
+
+    def __init__(self, img, cam, feat_geo, feat_tex, sp_data, src_foreground_mask, disable_fg_mask=False, sigma=0.1):
+        L = kl.get_library()
+        self.img = _dev(img, "img")
+        V, C, H, W = self.img.shape
+        if C != 3:
+            raise ValueError("img must be (V,3,H,W)")
+        if not isinstance(feat_geo, (list, tuple)) or len(feat_geo) != 2:
+            raise ValueError("feat_geo must be the list [ (V,64,h,w), (V,8,h,w) ] of HGFilterV2")
+        self.geo0, self.geo1, self.tex = _dev(feat_geo[0], "feat_geo[0]"), _dev(feat_geo[1], "feat_geo[1]"), _dev(feat_tex, "feat_tex")
+        if self.geo0.shape[:2] != (V, 64) or self.geo1.shape[:2] != (V, 8) or self.tex.shape[:2] != (V, 8):
+            raise ValueError("feature maps must be (V,64,..), (V,8,..), (V,8,..)")
+        self.KRT = _dev(cam["KRT"], "cam['KRT']").reshape(V, 4, 4)
+        extrin = sp_data["extrin"] if "extrin" in sp_data else cam["extrin"]
+        self.extrin = _dev(extrin, "extrin").reshape(V, 4, 4)
+        kpt = _dev(sp_data["kpt3d"], "kpt3d")
+        if kpt.numel() != 72:
+            raise ValueError("kpt3d must be (1,24,3): batch size 1 and 24 keypoints (reference src/model.py:938, configs/zju.json:44)")
+        self.kpt3d = kpt.reshape(24, 3)
+        if int(cam["width"]) != W or int(cam["height"]) != H:
+            raise ValueError("cam width/height must match the source images")
+        if disable_fg_mask:
+            self.fg = None
+        else:
+            m = src_foreground_mask
+            if not m.is_cuda:
+                raise RuntimeError("src_foreground_mask must live on the GPU")
+            self.fg = (m.reshape(V, H, W) != 0).to(torch.uint8).contiguous()
+        d = kl.SceneDesc()
+        d.n_views, d.src_h, d.src_w = V, H, W
+        d.geo0_h, d.geo0_w = self.geo0.shape[-2:]
+        d.geo1_h, d.geo1_w = self.geo1.shape[-2:]
+        d.tex_h, d.tex_w = self.tex.shape[-2:]
+        d.disable_fg_mask = int(bool(disable_fg_mask))
+        d.znear, d.zfar = float(cam["znear"]), float(cam["zfar"])
+        d.nml_scale, d.sigma = float(cam.get("nml_scale", 100.0)), float(sigma)
+        d.KRT, d.extrin, d.kpt3d = self.KRT.data_ptr(), self.extrin.data_ptr(), self.kpt3d.data_ptr()
+        d.img, d.geo0, d.geo1, d.tex = self.img.data_ptr(), self.geo0.data_ptr(), self.geo1.data_ptr(), self.tex.data_ptr()
+        d.fg_mask = self.fg.data_ptr() if self.fg is not None else None
+        self.desc = d
+        self.n_views = V
+        nbytes = L.kpn_scene_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            raise kl.KpnError(L.kpn_last_error().decode())
+        self.ws = torch.empty(nbytes // 4, dtype=_f32, device=self.img.device)
+        L.check(L.kpn_scene_prepare(ctypes.byref(d), _p(self.ws), _stream()))
+
+
+# ------------------------------------------------------------------------------------------------
+def ray_bbox_intersection(bounds, orig, direct):
+    """bounds (1,2,3), orig (1,1,3), direct (1,R,3) -> near (1,R,1), far (1,R,1), hit (1,R,1) bool."""
+    L = kl.get_library()
+    b, o, d = _dev(bounds, "bounds").reshape(2, 3), _dev(orig, "orig").reshape(3), _dev(direct, "direct").reshape(-1, 3)
+    R = d.shape[0]
+    near, far = torch.empty(R, dtype=_f32, device=d.device), torch.empty(R, dtype=_f32, device=d.device)
+    hit = torch.empty(R, dtype=torch.uint8, device=d.device)
+    L.check(L.kpn_ray_bbox_intersection(_p(b), _p(o), _p(d), R, _p(near), _p(far), _p(hit), _stream()))
+    return near.view(1, R, 1), far.view(1, R, 1), hit.view(1, R, 1).bool()
+
+
+def importance_sample(contrib, z, sample_per_ray, uniform=False, u=None):
+    """contrib (B,R,D-2), z (B,R,D-1) -> (B,R,sample_per_ray).  uniform=True uses linspace(0,1,n)
+    (reference src/model.py:1126); otherwise `u` (B,R,n) — drawn with torch.rand if not given (:1129)."""
+    L = kl.get_library()
+    c, zz = _dev(contrib, "contrib"), _dev(z, "z")
+    assert c.shape[-1] == zz.shape[-1] - 1  # same assert as the reference, src/model.py:1119
+    B, R, Dm2 = c.shape
+    n = int(sample_per_ray)
+    if uniform:
+        uu = None
+    else:
+        uu = _dev(u, "u").reshape(B * R, n) if u is not None else torch.rand(B * R, n, device=c.device)
+    out = torch.empty(B, R, n, dtype=_f32, device=c.device)
+    L.check(L.kpn_importance_sample(_p(c), _p(zz), _p(uu), B * R, Dm2, n, _p(out), _stream()))
+    return out
+
+
+def rgba2out(rgba, z):
+    """rgba (B,R,S,5), z (B,R,S) -> color (B,R,3), depth (B,R), alpha (B,R), contrib (B,R,S), sdf (B,R)."""
+    L = kl.get_library()
+    q, zz = _dev(rgba, "rgba"), _dev(z, "z")
+    B, R, S = zz.shape
+    if q.shape != (B, R, S, 5):
+        raise ValueError("rgba must be (B,R,S,5)")
+    dv = q.device
+    color = torch.empty(B, R, 3, dtype=_f32, device=dv)
+    depth, alpha, sdf = (torch.empty(B, R, dtype=_f32, device=dv) for _ in range(3))
+    contrib = torch.empty(B, R, S, dtype=_f32, device=dv)
+    L.check(L.kpn_rgba2out(_p(q), _p(zz), B * R, S, _p(color), _p(depth), _p(alpha), _p(contrib), _p(sdf), _stream()))
+    return color, depth, alpha, contrib, sdf
+
+
+def query(scene, weights, pts, view, mode=0):
+    """pts (1,N,3), view (1,N,3) -> out (1,N,5), valid (1,N,1) bool.  mode 0 = KeypointNeRF.query's
+    [sdf_raw, rad, rgb]; mode 1 = eval_func(query) = [sigma, sdf, rgb] (reference src/model.py:978-997)."""
+    L = kl.get_library()
+    p, v = _dev(pts, "pts").reshape(-1, 3), _dev(view, "view").reshape(-1, 3)
+    if p.shape != v.shape:
+        raise ValueError("pts and view must have the same shape")
+    N = p.shape[0]
+    out = torch.empty(N, 5, dtype=_f32, device=p.device)
+    valid = torch.empty(N, dtype=torch.uint8, device=p.device)
+    nb = L.kpn_query_workspace_bytes(N, scene.n_views)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=p.device)
+    L.check(L.kpn_query(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), N, _p(p), _p(v), int(mode), _p(out),
+                        _p(valid), _p(ws), nb, _stream()))
+    return out.view(1, N, 5), valid.view(1, N, 1).bool()
+
+
+class RenderPlan:
+    """Pre-allocated outputs + workspace for repeated renders of one pixel grid (no per-call allocation)."""
+
+    def __init__(self, scene, grid, n_coarse, n_fine, fine=True, chunk_rays=0, device=None):
+        L = kl.get_library()
+        x0, y0, step, nx, ny = (int(g) for g in grid)
+        dv = device or scene.ws.device
+        self.grid, self.fine = (x0, y0, step, nx, ny), bool(fine)
+        self.out = {"tex_fg": torch.empty(1, 3, ny, nx, dtype=_f32, device=dv), "depth": torch.empty(1, ny, nx, dtype=_f32, device=dv),
+                    "alpha": torch.empty(1, ny, nx, dtype=_f32, device=dv)}
+        if fine:
+            self.out.update({"tex_fg_fine": torch.empty(1, 3, ny, nx, dtype=_f32, device=dv),
+                             "depth_fine": torch.empty(1, ny, nx, dtype=_f32, device=dv),
+                             "alpha_fine": torch.empty(1, ny, nx, dtype=_f32, device=dv),
+                             "sdf": torch.empty(1, ny, nx, dtype=_f32, device=dv)})
+        a = kl.RenderArgs()
+        a.x0, a.y0, a.step, a.nx, a.ny = x0, y0, step, nx, ny
+        a.n_coarse, a.n_fine, a.fine, a.chunk_rays = int(n_coarse), int(n_fine), int(bool(fine)), int(chunk_rays)
+        for k, v in self.out.items():
+            setattr(a, k, v.data_ptr())
+        self.args = a
+        # K/RT/bounds pointers are filled per call; sizes do not depend on them
+        dummy = torch.zeros(16, dtype=_f32, device=dv)
+        a.K = a.RT = a.bounds = dummy.data_ptr()
+        self.nbytes = L.kpn_render_workspace_bytes(ctypes.byref(scene.desc), ctypes.byref(a))
+        if self.nbytes == 0:
+            raise kl.KpnError(L.kpn_last_error().decode())
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=dv)
+
+    def n_rays(self):
+        return self.grid[3] * self.grid[4]
+
+
+def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=64, fine=True, chunk_rays=0, plan=None):
+    """Eval-mode batch_render_pifu_nerf for the pixel grid (x0, y0, step, nx, ny) of the target camera
+    cam_tar {K (1,4,4), RT (1,4,4), znear, zfar}.  Returns the reference's out dict (B=1):
+    tex_fg (1,3,ny,nx), depth/alpha (1,ny,nx) [, tex_fg_fine, depth_fine, alpha_fine, sdf]."""
+    L = kl.get_library()
+    if plan is None:
+        plan = RenderPlan(scene, grid, n_coarse, n_fine, fine, chunk_rays)
+    K, RT, b = _dev(cam_tar["K"], "cam_tar['K']").reshape(4, 4), _dev(cam_tar["RT"], "cam_tar['RT']").reshape(4, 4), _dev(bounds, "bounds").reshape(2, 3)
+    a = plan.args
+    a.K, a.RT, a.bounds = K.data_ptr(), RT.data_ptr(), b.data_ptr()
+    a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    L.check(L.kpn_render_rays(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), _p(plan.ws),
+                              plan.nbytes, _stream()))
+    plan._keep = (K, RT, b)  # keep the small tensors alive until the stream has consumed them
+    return plan.out
+
+
+def selftest_mfma():
+    """Checks on the device that v_mfma_f32_32x32x2_f32 has the operand/result lane maps the kernels assume."""
+    L = kl.get_library()
+    scratch = torch.zeros(65536, dtype=_f32, device="cuda")
+    err = ctypes.c_float(0.0)
+    rc = L.kpn_selftest_mfma(_p(scratch), _stream(), ctypes.byref(err))
+    return rc, err.value

@@ -1,0 +1,196 @@
+"""Parity tests proper (-m gpu): the HIP kernels, called through the C ABI, against
+(a) the committed golden vectors produced by the reference itself, (b) the CPU oracle on seeded
+inputs, (c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: north_star demands <= 1e-4 abs on RGB / alpha; the tests use 1e-4 on final images and
+tighter bounds on per-stage quantities (all fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_io import CASES, TILED_CASE, load_case, load_weights, pixel_list
+
+pytestmark = pytest.mark.gpu
+RGBA_TOL = 1e-4
+
+
+def _cuda(obj):
+    from keypointnerf_amd.synthetic import to_device
+    return to_device(obj, "cuda")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from keypointnerf_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def golden_weights(ops):
+    sd = load_weights()
+    return sd, ops.PackedWeights(sd)
+
+
+def _prep(ops, scene, **kw):
+    s = _cuda(scene)
+    return s, ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"], **kw)
+
+
+def test_native_library_is_loaded(ops):
+    from keypointnerf_amd import lib
+    L = lib.get_library()
+    assert L.kpn_is_device_build() == 1
+    with open("/proc/self/maps") as f:
+        assert "libkpnerf_hip.so" in f.read()
+
+
+def test_mfma_lane_map(ops):
+    rc, err = ops.selftest_mfma()
+    assert rc == 0 and err < 1e-4, (rc, err)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage_ops_vs_golden(ops, case):
+    _, cfg, g = load_case(case)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    near, far, hit = ops.ray_bbox_intersection(t("ray_bbox_intersection.0.bounds"), t("ray_bbox_intersection.0.orig"),
+                                               t("ray_bbox_intersection.0.direct"))
+    assert (hit.cpu().numpy() == g["ray_bbox_intersection.0.hit"]).all()
+    np.testing.assert_allclose(near.cpu().numpy(), g["ray_bbox_intersection.0.near"], atol=2e-6)
+    np.testing.assert_allclose(far.cpu().numpy(), g["ray_bbox_intersection.0.far"], atol=2e-6)
+    for i in (0, 1):
+        color, depth, alpha, contrib, sdf = ops.rgba2out(t(f"rgba2out.{i}.rgba"), t(f"rgba2out.{i}.z"))
+        np.testing.assert_allclose(color.cpu().numpy(), g[f"rgba2out.{i}.color"], atol=3e-6)
+        np.testing.assert_allclose(alpha.cpu().numpy(), g[f"rgba2out.{i}.alpha"], atol=3e-6)
+        np.testing.assert_allclose(contrib.cpu().numpy(), g[f"rgba2out.{i}.contrib"], atol=2e-6)
+        np.testing.assert_allclose(depth.cpu().numpy(), g[f"rgba2out.{i}.depth"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(sdf.cpu().numpy(), g[f"rgba2out.{i}.sdf"], rtol=2e-5, atol=2e-6)
+    from tests.test_oracle_vs_golden import assert_samples_close
+    out = ops.importance_sample(t("importance_sample.0.contrib"), t("importance_sample.0.z"), cfg["Sf"], uniform=True)
+    assert_samples_close(out.cpu().numpy()[0], g["importance_sample.0.out"][0], g["importance_sample.0.z"][0])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_query_vs_golden(ops, golden_weights, case):
+    scene, cfg, g = load_case(case)
+    _, ps = _prep(ops, scene)
+    for i in (0, 1):
+        out, valid = ops.query(ps, golden_weights[1], torch.from_numpy(g[f"query.{i}.pts"]).cuda(),
+                               torch.from_numpy(g[f"query.{i}.view"]).cuda(), mode=0)
+        out, valid = out.cpu().numpy()[0], valid.cpu().numpy().reshape(-1)
+        ref, rvalid = g[f"query.{i}.out"][0], g[f"query.{i}.valid"][0].reshape(-1)
+        assert (valid == rvalid).all()
+        err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+        assert err[:, :2].max() < 2e-5
+        assert err[valid].max() < 2e-5
+        assert np.quantile(err[~valid], 0.99) < 2e-5  # see tests/test_oracle_vs_golden.py::test_query
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_render_vs_golden(ops, golden_weights, case):
+    scene, cfg, g = load_case(case)
+    s, ps = _prep(ops, scene)
+    step = 2 ** (cfg["level"] - 1)
+    ny, nx = s["cam_tar"]["height"] // step, s["cam_tar"]["width"] // step
+    out = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny),
+                          n_coarse=cfg["Sc"], n_fine=cfg["Sf"], fine=True, chunk_rays=200)
+    for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+        assert np.abs(out[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, k
+    for k in ("depth", "depth_fine", "sdf"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), g["out." + k], rtol=2e-4, atol=2e-4)
+
+
+def test_full_frame_equals_reference_tiles(ops, golden_weights):
+    """render_pifu_nerf's 2^(level-1) x 2^(level-1) strided tiles + pixel_shuffle (reference
+    src/model.py:916-938) == one full-frame launch."""
+    scene, cfg, g = load_case(TILED_CASE)
+    s, ps = _prep(ops, scene)
+    H, W = s["cam_tar"]["height"], s["cam_tar"]["width"]
+    out = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(0, 0, 1, W, H), n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+    for k in ("tex_fg", "tex_fg_fine", "alpha", "alpha_fine"):
+        assert np.abs(out[k][0].cpu().numpy().reshape(g["out." + k].shape) - g["out." + k]).max() <= RGBA_TOL, k
+
+
+@pytest.mark.parametrize("n_views,mask,src_hw,tar_hw,Sc,Sf", [(3, "ellipsoid", (128, 128), (64, 64), 32, 32),   # C1-like
+                                                            (1, "dense", (64, 96), (24, 20), 16, 16),
+                                                            (10, "dense", (64, 64), (20, 24), 12, 20)])  # C5's view count
+def test_render_vs_oracle(ops, n_views, mask, src_hw, tar_hw, Sc, Sf):
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    from oracle import oracle
+    sd = random_hotpath_state_dict(seed=11 + n_views)
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=tar_hw, mask=mask, seed=20 + n_views)
+    s, ps = _prep(ops, scene)
+    w = ops.PackedWeights(sd)
+    H, W = tar_hw
+    out = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, W, H), n_coarse=Sc, n_fine=Sf, chunk_rays=1000)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
+    ref = oracle.render_rays(oracle.OracleScene(scene), oracle.flat_weights(sd), scene["cam_tar"], scene["bounds"], pix, Sc, Sf)
+    assert 0.02 < ref["alpha_fine"].mean() < 0.98  # a non-degenerate scene
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(out[k][0].permute(1, 2, 0).reshape(-1, 3).cpu().numpy() - ref[k]).max() <= RGBA_TOL, k
+    for k in ("alpha", "alpha_fine"):
+        assert np.abs(out[k].reshape(-1).cpu().numpy() - ref[k]).max() <= RGBA_TOL, k
+
+
+def test_query_edge_cases(ops, golden_weights):
+    from keypointnerf_amd import lib
+    scene, cfg, g = load_case(CASES[0])
+    _, ps = _prep(ops, scene)
+    pts = torch.from_numpy(g["query.0.pts"]).cuda()
+    view = torch.from_numpy(g["query.0.view"]).cuda()
+    # empty input
+    out, valid = ops.query(ps, golden_weights[1], pts[:, :0], view[:, :0])
+    assert out.shape == (1, 0, 5) and valid.shape == (1, 0, 1)
+    # ragged sizes (not a multiple of the 32-point tile / 64-lane wave) and point-order independence
+    ref_full, v_full = ops.query(ps, golden_weights[1], pts, view)
+    for n in (1, 31, 33, 1000):
+        o, v = ops.query(ps, golden_weights[1], pts[:, :n], view[:, :n])
+        assert torch.equal(o, ref_full[:, :n]) and torch.equal(v, v_full[:, :n])
+    perm = torch.randperm(pts.shape[1], device="cuda")
+    o, v = ops.query(ps, golden_weights[1], pts[:, perm], view[:, perm])
+    assert torch.equal(o, ref_full[:, perm])  # every point is evaluated independently, bit for bit
+    # all points outside every frustum -> nothing valid, constant result
+    far_pts = pts * 0 + torch.tensor([0.0, 50.0, 0.0], device="cuda")
+    o, v = ops.query(ps, golden_weights[1], far_pts, view, mode=1)
+    assert not v.any() and (o[..., 0] == 0).all() and torch.allclose(o[..., 1], torch.tensor(0.001, device="cuda"))
+    # CPU tensors are refused (no fallback)
+    with pytest.raises(RuntimeError):
+        ops.query(ps, golden_weights[1], pts.cpu(), view.cpu())
+    # bad arguments come back as errors, not as garbage
+    with pytest.raises(lib.KpnError):
+        ops.render_rays(ps, golden_weights[1], _cuda(scene)["cam_tar"], _cuda(scene)["bounds"], grid=(0, 0, 1, 8, 8), n_coarse=2, n_fine=8)
+
+
+def test_full_size_properties(ops):
+    """BASELINE configs[1] size (512x512 target, V=3, 64+64): properties that need no oracle."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    sd = random_hotpath_state_dict(seed=3)
+    scene = make_scene(n_views=3, src_hw=(512, 512), tar_hw=(512, 512), mask="ellipsoid", seed=1, device="cuda")
+    ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"], scene["src_foreground_mask"])
+    w = ops.PackedWeights(sd)
+    a = {k: v.clone() for k, v in ops.render_rays(ps, w, scene["cam_tar"], scene["bounds"], grid=(0, 0, 1, 512, 512)).items()}
+    for k, v in a.items():
+        assert torch.isfinite(v).all(), k
+    assert (a["alpha_fine"] >= -1e-6).all() and (a["alpha_fine"] <= 1 + 1e-5).all()
+    assert (a["tex_fg_fine"] >= -1e-5).all() and (a["tex_fg_fine"] <= 1 + 1e-5).all()  # convex blend of [0,1] colours x alpha
+    assert 0.02 < a["alpha_fine"].mean() < 0.9
+    # idempotence / chunk invariance: a different internal chunking gives bit-identical images
+    b = ops.render_rays(ps, w, scene["cam_tar"], scene["bounds"], grid=(0, 0, 1, 512, 512), chunk_rays=5000)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # tile consistency: the reference's strided tile (level 4: step 8, offset (3,5)) is a sub-lattice of the frame
+    t = ops.render_rays(ps, w, scene["cam_tar"], scene["bounds"], grid=(3, 5, 8, 64, 64))
+    assert torch.equal(t["tex_fg_fine"], a["tex_fg_fine"][:, :, 5::8, 3::8])
+    assert torch.equal(t["alpha_fine"], a["alpha_fine"][:, 5::8, 3::8])
+    # rays that never enter the visual hull composite to exactly zero
+    dead = a["alpha_fine"] == 0
+    assert dead.any() and (a["tex_fg_fine"].permute(0, 2, 3, 1)[dead] == 0).all()
+    # linearity in the source colours: rgb is a convex combination of sampled source pixels, so scaling
+    # the images by 0.5 scales the output by 0.5 only if the blend weights ignore colour — they do not
+    # (rgb feeds the IBR head), so instead check the black-image case: zero sources render black
+    img0 = scene["img"] * 0
+    ps0 = ops.PreparedScene(img0, scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"], scene["src_foreground_mask"])
+    z = ops.render_rays(ps0, w, scene["cam_tar"], scene["bounds"], grid=(0, 0, 4, 128, 128))
+    assert (z["tex_fg_fine"] == 0).all() and z["alpha_fine"].max() > 0.05

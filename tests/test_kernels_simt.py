@@ -1,0 +1,92 @@
+"""The HIP kernel sources executed on the CPU by the wave64 SIMT emulator (tests/simt), through the same
+C ABI, against the golden vectors of the reference and against the oracle.  This validates kernel logic
+(lane maps, weight permutation, compaction, sampler, compositor) in the GPU-less build container; the
+-m gpu tests repeat the comparison on the real device."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import simt_harness as sh
+from tests.golden_io import CASES, load_case, load_weights
+from tests.test_oracle_vs_golden import assert_samples_close
+
+
+@pytest.fixture(scope="module")
+def env():
+    lib = sh.simt_lib()
+    sd = load_weights()
+    return lib, sh.pack_weights(lib, sd), oracle.flat_weights(sd)
+
+
+def test_mfma_emulation_selftest(env):
+    import ctypes
+    lib = env[0]
+    scratch = np.zeros(65536, np.float32)
+    err = ctypes.c_float(1.0)
+    assert lib.kpn_selftest_mfma(sh.ptr(scratch), None, ctypes.byref(err)) == 0 and err.value < 1e-4
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stage_kernels(env, case):
+    import ctypes
+    lib = env[0]
+    _, cfg, g = load_case(case)
+    b, o, d = (sh.f32(g[f"ray_bbox_intersection.0.{k}"]) for k in ("bounds", "orig", "direct"))
+    R = d.shape[1]
+    near, far, hit = np.zeros(R, np.float32), np.zeros(R, np.float32), np.zeros(R, np.uint8)
+    lib.check(lib.kpn_ray_bbox_intersection(sh.ptr(b), sh.ptr(o), sh.ptr(d), R, sh.ptr(near), sh.ptr(far), sh.ptr(hit), None))
+    on, of, oh = oracle.ray_bbox_intersection(b, o, d)
+    assert (hit.astype(bool) == oh).all() and np.array_equal(near, on) and np.array_equal(far, of)  # bit-exact vs oracle
+    assert (hit.astype(bool) == g["ray_bbox_intersection.0.hit"].reshape(-1)).all()
+    # compositor
+    rgba, z = sh.f32(g["rgba2out.1.rgba"][0]), sh.f32(g["rgba2out.1.z"][0])
+    R, S = z.shape
+    color, depth, alpha, contrib, sdf = (np.zeros(s, np.float32) for s in ((R, 3), R, R, (R, S), R))
+    lib.check(lib.kpn_rgba2out(sh.ptr(rgba), sh.ptr(z), R, S, sh.ptr(color), sh.ptr(depth), sh.ptr(alpha), sh.ptr(contrib), sh.ptr(sdf), None))
+    np.testing.assert_allclose(color, g["rgba2out.1.color"][0], atol=3e-6)
+    np.testing.assert_allclose(alpha, g["rgba2out.1.alpha"][0], atol=3e-6)
+    np.testing.assert_allclose(contrib, g["rgba2out.1.contrib"][0], atol=2e-6)
+    np.testing.assert_allclose(depth, g["rgba2out.1.depth"][0], rtol=2e-5, atol=2e-5)
+    # sampler
+    c, zm = sh.f32(g["importance_sample.0.contrib"][0]), sh.f32(g["importance_sample.0.z"][0])
+    out = np.zeros((c.shape[0], cfg["Sf"]), np.float32)
+    lib.check(lib.kpn_importance_sample(sh.ptr(c), sh.ptr(zm), None, c.shape[0], c.shape[1], cfg["Sf"], sh.ptr(out), None))
+    assert np.array_equal(out, oracle.importance_sample(c, zm, cfg["Sf"]))  # same sequential cdf -> bit-exact vs oracle
+    assert_samples_close(out, g["importance_sample.0.out"][0], zm)
+    u = np.random.default_rng(0).random((c.shape[0], 7), dtype=np.float32)
+    out = np.zeros((c.shape[0], 7), np.float32)
+    lib.check(lib.kpn_importance_sample(sh.ptr(c), sh.ptr(zm), sh.ptr(u), c.shape[0], c.shape[1], 7, sh.ptr(out), None))
+    assert np.array_equal(out, oracle.importance_sample(c, zm, 7, u=u))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_field_kernels_vs_golden_and_oracle(env, case):
+    lib, packed, wflat = env
+    scene, cfg, g = load_case(case)
+    hs = sh.HostScene(lib, scene)
+    pts, view = g["query.1.pts"][0], g["query.1.view"][0]
+    rvalid = g["query.1.valid"][0].reshape(-1)
+    idx = np.sort(np.concatenate([np.nonzero(rvalid)[0][:150], np.nonzero(~rvalid)[0][:50]]))
+    for mode in (0, 1):
+        out, valid = sh.query(lib, hs, packed, pts[idx], view[idx], mode=mode)
+        ref, ov = oracle.query(oracle.OracleScene(scene), wflat, pts[idx], view[idx], apply_eval_func=bool(mode))
+        assert (valid == ov).all() and (valid == rvalid[idx]).all()
+        assert np.abs(out - ref)[valid].max() < 1e-5
+        assert np.abs(out - ref)[:, :2].max() < 1e-5
+    gold = g["query.1.out"][0][idx]
+    out, valid = sh.query(lib, hs, packed, pts[idx], view[idx], mode=0)
+    assert (np.abs(out - gold)[valid] / np.maximum(1, np.abs(gold[valid]))).max() < 2e-5
+
+
+def test_render_pipeline_vs_golden(env):
+    lib, packed, _ = env
+    scene, cfg, g = load_case("case_c_v3_offaxis")  # smallest case: 576 rays x (8 + 16)
+    hs = sh.HostScene(lib, scene)
+    step = 2 ** (cfg["level"] - 1)
+    ny, nx = scene["cam_tar"]["height"] // step, scene["cam_tar"]["width"] // step
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (cfg["stride_j"], cfg["stride_i"], step, nx, ny),
+                  cfg["Sc"], cfg["Sf"], chunk_rays=200)  # 576 rays -> chunks of 200,200,176
+    for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+        assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k
+    for k in ("depth", "depth_fine", "sdf"):
+        np.testing.assert_allclose(o[k], g["out." + k][0], rtol=2e-4, atol=2e-4)
