@@ -1,6 +1,7 @@
 // kpn_api.hip — C ABI (include/kpnerf.h): weight packing, scene preparation, stage ops and the
 // hierarchical render pipeline.  Host code only launches kernels on the caller's stream; it never
 // synchronises or allocates (except kpn_selftest_mfma, a diagnostic).
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -339,10 +340,10 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
                          const float* view, int32_t mode, float* out, uint8_t* valid, void* ws, size_t ws_bytes,
                          void* stream) {
     if (int e = check_desc(d)) return e;
-    KPN_REQUIRE(scene_ws && wp && pts && view && out && ws, "null pointer");
     KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (raw query) or 1 (eval_func)");
     KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
-    if (N == 0) return KPN_OK;
+    if (N == 0) return KPN_OK;  // empty input: nothing to do (pointers may be null)
+    KPN_REQUIRE(scene_ws && wp && pts && view && out && ws, "null pointer");
     if (ws_bytes < query_layout(N, d->n_views).total) return fail(KPN_EWORKSPACE, "query workspace too small");
     kpn_points ps{pts, view, nullptr, nullptr, nullptr, 1};
     return run_field(scene_dev(d, scene_ws), ps, wp, N, mode, out, valid, ws, stream);
@@ -487,11 +488,16 @@ extern "C" int kpn_selftest_mfma(float* scratch, void* stream, float* max_err_ho
     KPN_REQUIRE(scratch && max_err_host, "null pointer");
     float A[64], B[64], Dm[1024];
     for (int i = 0; i < 64; ++i) { A[i] = 0.37f * i - 7.0f + 0.011f * i * i; B[i] = 3.0f - 0.23f * i + (i % 5) * 0.7f; }
-    hipMemcpyAsync(scratch, A, sizeof(A), hipMemcpyHostToDevice, (hipStream_t)stream);
-    hipMemcpyAsync(scratch + 64, B, sizeof(B), hipMemcpyHostToDevice, (hipStream_t)stream);
+    // diagnostic: fully synchronous (pageable host buffers), every runtime call checked
+#define KPN_HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(KPN_ELAUNCH, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+    for (int i = 0; i < 1024; ++i) Dm[i] = -12345.0f;
+    KPN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    KPN_HIP_TRY(hipMemcpy(scratch, A, sizeof(A), hipMemcpyHostToDevice));
+    KPN_HIP_TRY(hipMemcpy(scratch + 64, B, sizeof(B), hipMemcpyHostToDevice));
     KPN_LAUNCH(k_selftest_mfma, dim3(1), dim3(64), stream, (const float*)scratch, (const float*)(scratch + 64), scratch + 128);
-    hipMemcpyAsync(Dm, scratch + 128, sizeof(Dm), hipMemcpyDeviceToHost, (hipStream_t)stream);
-    hipStreamSynchronize((hipStream_t)stream);
+    if (int e = check_launch("k_selftest_mfma launch")) return e;
+    KPN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    KPN_HIP_TRY(hipMemcpy(Dm, scratch + 128, sizeof(Dm), hipMemcpyDeviceToHost));
     float me = 0.0f;
     for (int i = 0; i < 32; ++i)
         for (int j = 0; j < 32; ++j) {
@@ -500,5 +506,12 @@ extern "C" int kpn_selftest_mfma(float* scratch, void* stream, float* max_err_ho
         }
     *max_err_host = me;
     if (int e = check_launch("kpn_selftest_mfma")) return e;
-    return me < 1e-3f ? KPN_OK : fail(KPN_ELAUNCH, "MFMA lane map mismatch");
+    if (!(me < 1e-3f)) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "MFMA lane map mismatch: max err %g, D[0][0]=%g (ref %g), D[5][7]=%g (ref %g)", (double)me,
+                 (double)Dm[0], (double)fmaf(A[1], B[32], A[0] * B[0]), (double)Dm[5 * 32 + 7],
+                 (double)fmaf(A[11], B[39], A[10] * B[7]));
+        return fail(KPN_ELAUNCH, buf);
+    }
+    return KPN_OK;
 }

@@ -10,6 +10,12 @@ kernel sources (tests/simt) with numpy buffers — never through this module's d
 import ctypes
 import os
 
+# torch first: PyTorch-ROCm ships its own libamdhip64.so.7.  The library must bind to THE SAME HIP
+# runtime instance as torch (device pointers and streams are shared), which the dynamic loader
+# guarantees by SONAME once torch's copy is already in the process.  Loading libkpnerf_hip.so first
+# would pull /opt/rocm's runtime in as a second instance ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "_lib", "libkpnerf_hip.so")
 

@@ -166,6 +166,8 @@ def query(scene, weights, pts, view, mode=0):
     N = p.shape[0]
     out = torch.empty(N, 5, dtype=_f32, device=p.device)
     valid = torch.empty(N, dtype=torch.uint8, device=p.device)
+    if N == 0:
+        return out.view(1, 0, 5), valid.view(1, 0, 1).bool()
     nb = L.kpn_query_workspace_bytes(N, scene.n_views)
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=p.device)
     L.check(L.kpn_query(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), N, _p(p), _p(v), int(mode), _p(out),
@@ -228,5 +230,8 @@ def selftest_mfma():
     L = kl.get_library()
     scratch = torch.zeros(65536, dtype=_f32, device="cuda")
     err = ctypes.c_float(0.0)
+    torch.cuda.synchronize()
     rc = L.kpn_selftest_mfma(_p(scratch), _stream(), ctypes.byref(err))
+    if rc != 0:
+        print("selftest_mfma:", L.kpn_last_error().decode())
     return rc, err.value

@@ -205,6 +205,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 #define hipMemcpyHostToDevice 1
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyDeviceToHost 2
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
