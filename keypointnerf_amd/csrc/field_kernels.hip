@@ -107,25 +107,27 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
         const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
 
-        // ---- layers1.0 : [168 keypoint encoding | 64 geometry channels] -> 128, softplus ----
-        float act[68];
+        // Activations are applied lazily: layer L+1 takes softplus(acc_L[...]) group by group as its B
+        // operands, so the transcendental work interleaves with the MFMAs instead of forming a
+        // VALU-only phase between layers.
+        // ---- layers1.0 : [168 keypoint encoding | 64 geometry channels] -> 128 ----
+        kpn_f32x16 a0[4];
         {
             const float* E = tb + KPN_TBL_EXT;  // camera-space position, spatial.py:76
             const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
             const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
             const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
-            kpn_f32x16 acc[4];
-            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_0A), h, acc);
+            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_0A), h, a0);
             // group j = keypoint j + 12h: 7 encoding values (spatial.py:110-118), produced while the
             // previous keypoint's 28 MFMAs issue
             kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
                 constexpr int j = decltype(gi)::value;
                 const float dx = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
                 const float d2 = KADD(KADD(KMUL(dx, dx), KMUL(dy, dy)), KMUL(dz, dz));
-                const float w = expf(-d2 / sc.two_sigma2);
+                const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                sincosf(KMUL(dz, pe_pi), &s1, &c1);
+                kpn_sincos(KMUL(dz, pe_pi), s1, c1);
                 // sin/cos(2y), sin/cos(4y): the reference's arguments are exactly 2y and 4y
                 // (float32(2*pi) == 2*float32(pi)), so the double-angle identities apply to them
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
@@ -134,47 +136,48 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
                 x[1] = s1 * w; x[2] = c1 * w;
                 x[3] = s2 * w; x[4] = c2 * w;
                 x[5] = s4 * w; x[6] = c4 * w;
-            }, acc);
+            }, a0);
             const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);  // model.py:763-765
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
             kpn_mfma_layer<32, 4, 4>(wp + kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp);
                 x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
-            }, acc);
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[16 * b + r] = kpn_softplus100(acc[b][r]);
+            }, a0);
         }
-        // ---- layers1.1 : 128 -> 128, softplus ----
-        {
-            kpn_f32x16 acc[4];
-            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_1), h, acc);
-            kpn_mfma_layer_regs<64, 4>(wp + kpn_seg_woff(SEG_G1_1), lane, act, acc);
+        // ---- layers1.1 : softplus(128) -> 128 ----
+        kpn_f32x16 a1[4];
+        kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_1), h, a1);
+        kpn_mfma_layer<64, 4, 4>(wp + kpn_seg_woff(SEG_G1_1), lane, [&](auto gi, float (&x)[4]) {
+            constexpr int g = decltype(gi)::value;
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[16 * b + r] = kpn_softplus100(acc[b][r]);
-        }
-        // ---- layers1.2 : [128 | 8 hd channels] -> 120, softplus (skip connection, utils.py:706-713) ----
+            for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a0[g / 4][(g % 4) * 4 + i]);
+        }, a1);
+        // ---- layers1.2 : [softplus(128) | 8 hd channels] -> 120 (skip connection, utils.py:706-713) ----
+        kpn_f32x16 a2[4];
         {
             const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
-            act[64] = f.x; act[65] = f.y; act[66] = f.z; act[67] = f.w;
-            kpn_f32x16 acc[4];
-            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_2), h, acc);
-            kpn_mfma_layer_regs<68, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, act, acc);
+            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_2), h, a2);
+            kpn_mfma_layer<68, 4, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                if constexpr (g < 16) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) act[16 * b + r] = kpn_softplus100(acc[b][r]);
+                    for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a1[g / 4][(g % 4) * 4 + i]);
+                } else {
+                    x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
+                }
+            }, a2);
         }
-        // ---- layers1.3 : 120 -> 64, linear ----
+        // ---- layers1.3 : softplus(120) -> 64, linear ----
         {
             kpn_f32x16 acc[2];
             kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G1_3), h, acc);
-            kpn_mfma_layer_regs<64, 2>(wp + kpn_seg_woff(SEG_G1_3), lane, act, acc);
+            kpn_mfma_layer<64, 2, 4>(wp + kpn_seg_woff(SEG_G1_3), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a2[g / 4][(g % 4) * 4 + i]);
+            }, acc);
             float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * 8) * 64 + lane;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -187,25 +190,47 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per-view inputs of the IBR head for this lane's point (query_color, model.py:806-832)
+// Per-view inputs of the IBR head for this lane's point (query_color, model.py:806-832), in two steps:
+// the gather (projection, bilinear taps, ray-direction difference: VALU + memory only) and the
+// ray_encoder MLP (MFMA).  With V <= 3 the gathers of all views are issued up front.
+struct kpn_view_gather {
+    float pw;       // un-normalised boundary-smooth pooling weight (model.py:752-758)
+    float rgb[3];   // sampled source colour
+    float fadd[7];  // this lane's rgb/tex entries of x': regs 12..15 of block 0, regs 0..2 of block 1
+    float rd[4];    // ray_diff = [direction(3), dot]
+};
 struct kpn_ibr_view {
     float xb0[16];  // x' rows rowmap(r,h): x' = [lat24 | rgb3 | tex8] + ray_encoder(ray_diff)   (block 0)
     float xb1[3];   // x' rows 32..34 (h == 0 lanes only)
-    float rd[4];    // ray_diff = [direction(3), dot]
-    float rgb[3];   // sampled source colour
 };
 
-__device__ __forceinline__ void kpn_ibr_view_inputs(const kpn_scene_dev& sc, const float* __restrict__ wp, int v,
-                                                    int lane, int h, const float (&P)[3], const float (&D)[3],
-                                                    const float (&lat0)[16], kpn_ibr_view& o) {
+// Boundary-smooth pooling weight of one view (model.py:752-759, mask == 1), un-normalised
+__device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
+    const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
+    float w3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
+        w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
+    }
+    return KMUL(KMUL(w3[0], w3[1]), w3[2]);
+}
+
+__device__ __forceinline__ void kpn_gather_view(const kpn_scene_dev& sc, int v, int h, const float (&P)[3],
+                                                const float (&D)[3], kpn_view_gather& o) {
     const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
     const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+    o.pw = kpn_pix_weight(q);
     const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
     const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
     o.rgb[0] = c.x; o.rgb[1] = c.y; o.rgb[2] = c.z;
     const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
     const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
     const float4 t0 = kpn_tap4(tx, 8, 0, tt), t1 = kpn_tap4(tx, 8, 4, tt);       // model.py:818
+    // x' order is [lat24 | rgb3 | tex8]: rows 24..27 live in regs 12..15 of the h=0 lanes, rows 28..31 in
+    // regs 12..15 of h=1, rows 32..34 in block 1 regs 0..2 of h=0
+    o.fadd[0] = h ? t0.y : c.x; o.fadd[1] = h ? t0.z : c.y; o.fadd[2] = h ? t0.w : c.z; o.fadd[3] = h ? t1.x : t0.x;
+    o.fadd[4] = h ? 0.0f : t1.y; o.fadd[5] = h ? 0.0f : t1.z; o.fadd[6] = h ? 0.0f : t1.w;
     // ray-direction difference, model.py:823-832
     const float* cp = tb + KPN_TBL_CPOS;
     float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
@@ -216,30 +241,33 @@ __device__ __forceinline__ void kpn_ibr_view_inputs(const kpn_scene_dev& sc, con
     const float rc = fmaxf(rn, 1e-6f);
     o.rd[0] = r0 / rc; o.rd[1] = r1 / rc; o.rd[2] = r2 / rc;
     o.rd[3] = kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]);
-    // ray_encoder: Linear(4,16) ELU Linear(16,35) ELU  (model.py:1246,1279)
-    const float in4[4] = {h ? o.rd[1] : o.rd[0], h ? o.rd[3] : o.rd[2], 0.0f, 0.0f};
+}
+
+// ray_encoder: Linear(4,16) ELU Linear(16,35) ELU (model.py:1246,1279), then x' = rgb_feat' + dir' (:1281-1284)
+__device__ __forceinline__ void kpn_encode_view(const float* __restrict__ wl, int lane, int h, const kpn_view_gather& g,
+                                                const float (&lat0)[16], kpn_ibr_view& o) {
+    const float in4[4] = {h ? g.rd[1] : g.rd[0], h ? g.rd[3] : g.rd[2], 0.0f, 0.0f};
     kpn_f32x16 a1[1];
-    kpn_load_bias<1>(wp + kpn_seg_boff(SEG_RE_0), h, a1);
-    kpn_mfma_layer_regs<4, 1>(wp + kpn_seg_woff(SEG_RE_0), lane, in4, a1);
+    kpn_load_bias<1>(wl + kpn_seg_boff(SEG_RE_0), h, a1);
+    kpn_mfma_layer_regs<4, 1, 4, 1>(wl + kpn_seg_woff(SEG_RE_0), lane, in4, a1);
     float in8[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) in8[r] = kpn_elu(a1[0][r]);
     kpn_f32x16 a2[2];
-    kpn_load_bias<2>(wp + kpn_seg_boff(SEG_RE_1), h, a2);
-    kpn_mfma_layer_regs<8, 2>(wp + kpn_seg_woff(SEG_RE_1), lane, in8, a2);
-    // x' = rgb_feat' + dir'  (model.py:1281-1284) in the permuted order [lat24 | rgb3 | tex8]:
-    // rows 24..27 live in regs 12..15 of the h=0 lanes, rows 28..31 in regs 12..15 of h=1, rows 32..34
-    // in block 1 regs 0..2 of h=0
-    const float f12 = h ? t0.y : c.x, f13 = h ? t0.z : c.y, f14 = h ? t0.w : c.z, f15 = h ? t1.x : t0.x;
+    kpn_load_bias<2>(wl + kpn_seg_boff(SEG_RE_1), h, a2);
+    kpn_mfma_layer_regs<8, 2, 4, 1>(wl + kpn_seg_woff(SEG_RE_1), lane, in8, a2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o.xb0[r] = kpn_elu(a2[0][r]) + lat0[r];
-    o.xb0[12] += f12; o.xb0[13] += f13; o.xb0[14] += f14; o.xb0[15] += f15;
-    o.xb1[0] = kpn_elu(a2[1][0]) + (h ? 0.0f : t1.y);
-    o.xb1[1] = kpn_elu(a2[1][1]) + (h ? 0.0f : t1.z);
-    o.xb1[2] = kpn_elu(a2[1][2]) + (h ? 0.0f : t1.w);
+    o.xb0[12] += g.fadd[0]; o.xb0[13] += g.fadd[1]; o.xb0[14] += g.fadd[2]; o.xb0[15] += g.fadd[3];
+    o.xb1[0] = kpn_elu(a2[1][0]) + g.fadd[4];
+    o.xb1[1] = kpn_elu(a2[1][1]) + g.fadd[5];
+    o.xb1[2] = kpn_elu(a2[1][2]) + g.fadd[6];
 }
 
-__global__ __launch_bounds__(256, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+// VC > 0: requires V <= VC; the views' gathers, their 64-vectors from k_geo_rows and their x' vectors stay in
+// registers (fully unrolled over views).  VC == 0: any V <= KPN_MAXV, per-view data are recomputed per pass.
+template <int VC>
+__global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        const float* __restrict__ xscr, int mode, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -249,7 +277,18 @@ __global__ __launch_bounds__(256, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
     const int V = sc.V;
-    const float ani = wp[kpn_scalar_off() + 0];  // |ani_al|
+    constexpr int NV = VC > 0 ? VC : 1;
+    // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
+    // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
+    __shared__ __attribute__((aligned(16))) float wlds[kpn_k2_floats()];
+    {
+        const float4* src = reinterpret_cast<const float4*>(wp + kpn_k2_base());
+        float4* dst = reinterpret_cast<float4*>(wlds);
+        for (int i = threadIdx.x; i < kpn_k2_floats() / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* wl = wlds - kpn_k2_base();
+    const float ani = wl[kpn_scalar_off() + 0];  // |ani_al|
 
     for (int t = wave; t < ntiles; t += nwaves) {
         const int ci_raw = t * KPN_TILE + p;
@@ -258,84 +297,49 @@ __global__ __launch_bounds__(256, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         float P[3], D[3];
         kpn_get_point(ps, n, P, D);
 
-        // ---- pass 1 over views: boundary-smooth pooling weights (model.py:752-759) and the IBR
-        //      blend weights' min/sum (model.py:1287-1289); mask == 1 in every view for listed points
-        float pwsum = 0.0f, emin = 3.0e38f;
-        for (int v = 0; v < V; ++v) {
-            const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-            const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
-            const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
-            float w3[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
-                w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
-            }
-            pwsum = KADD(pwsum, KMUL(KMUL(w3[0], w3[1]), w3[2]));
-            const float* cp = tb + KPN_TBL_CPOS;
-            float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
-            const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-            const float dot = kpn_dot3(cr[0] / nrm, cr[1] / nrm, cr[2] / nrm, D[0], D[1], D[2]);
-            emin = fminf(emin, expf(KMUL(ani, KSUB(dot, 1.0f))));
-        }
+        // ---- pooling-weight normaliser (model.py:759; mask == 1 in every view for listed points) ----
+        float pwsum = 0.0f;
+        for (int v = 0; v < V; ++v)
+            pwsum = KADD(pwsum, kpn_pix_weight(kpn_project(sc.table + (size_t)v * KPN_TBL_STRIDE, P[0], P[1], P[2], sc)));
         // ---- pooled mean / var over views of the 64-vector (utils.py:731-748), two passes ----
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
 #pragma unroll
         for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-        float esum = 0.0f;
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
-                const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-                const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
-                const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
-                float w3[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
-                    w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
-                }
-                const float pw = KMUL(KMUL(w3[0], w3[1]), w3[2]) / KADD(pwsum, 1e-6f);
-                if (pass == 0) {  // IBR blend-weight normaliser
-                    const float* cp = tb + KPN_TBL_CPOS;
-                    float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
-                    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-                    const float dot = kpn_dot3(cr[0] / nrm, cr[1] / nrm, cr[2] / nrm, D[0], D[1], D[2]);
-                    esum = KADD(esum, KSUB(expf(KMUL(ani, KSUB(dot, 1.0f))), emin));
-                }
+                const kpn_proj q = kpn_project(sc.table + (size_t)v * KPN_TBL_STRIDE, P[0], P[1], P[2], sc);
+                const float pw = kpn_pix_weight(q) / KADD(pwsum, 1e-6f);
                 const float4* src = reinterpret_cast<const float4*>(xscr) + ((size_t)(t * V + v) * 8) * 64 + lane;
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) {
                     const float4 x = src[q4 * 64];
-                    const float xs[4] = {x.x, x.y, x.z, x.w};
+                    const float xe[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * q4 + e;
-                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xs[e]));
-                        else { const float d = KSUB(xs[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
+                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
+                        else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
                     }
                 }
             }
-        }
-        // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587) ----
+        // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
         {
-            float a64[32];
-            kpn_f32x16 acc[2];
-            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G2_0), h, acc);
-            kpn_mfma_layer_regs<64, 2>(wp + kpn_seg_woff(SEG_G2_0), lane, pooled, acc);
+            kpn_f32x16 h0[2], h1[2], o2[1];
+            kpn_load_bias<2>(wl + kpn_seg_boff(SEG_G2_0), h, h0);
+            kpn_mfma_layer_regs<64, 2, 4, 1>(wl + kpn_seg_woff(SEG_G2_0), lane, pooled, h0);
+            kpn_load_bias<2>(wl + kpn_seg_boff(SEG_G2_1), h, h1);
+            kpn_mfma_layer<32, 2, 4, 1>(wl + kpn_seg_woff(SEG_G2_1), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(h0[g / 4][(g % 4) * 4 + i]);
+            }, h1);
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_G2_2), h, o2);
+            kpn_mfma_layer<32, 1, 4, 1>(wl + kpn_seg_woff(SEG_G2_2), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a64[16 * b + r] = kpn_softplus100(acc[b][r]);
-            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G2_1), h, acc);
-            kpn_mfma_layer_regs<32, 2>(wp + kpn_seg_woff(SEG_G2_1), lane, a64, acc);
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a64[16 * b + r] = kpn_softplus100(acc[b][r]);
-            kpn_f32x16 o2[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_G2_2), h, o2);
-            kpn_mfma_layer_regs<32, 1>(wp + kpn_seg_woff(SEG_G2_2), lane, a64, o2);
+                for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(h1[g / 4][(g % 4) * 4 + i]);
+            }, o2);
             sdf_raw = o2[0][0];  // rows 0,1 live in regs 0,1 of the h=0 lanes
             rad = o2[0][1];
         }
@@ -343,100 +347,137 @@ __global__ __launch_bounds__(256, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         float lat0[16];
         {
             kpn_f32x16 acc[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_CMP), h, acc);
-            kpn_mfma_layer_regs<64, 1>(wp + kpn_seg_woff(SEG_CMP), lane, pooled, acc);
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_CMP), h, acc);
+            kpn_mfma_layer_regs<64, 1, 4, 1>(wl + kpn_seg_woff(SEG_CMP), lane, pooled, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }
-        // ---- IBR head (model.py:1267-1302).  fused mean/var over views of x' (utils.py:91-95) ----
-        float mv[40];  // K-steps: mean' (16 + 3 + pad), var' (16 + 3 + pad)
+        // ---- IBR head (model.py:1267-1302) ----
+        // blend weights (model.py:1287-1289): w_v = (e_v - min_v e) / (sum + 1e-8), e_v = exp(|a|(dot_v - 1))
+        kpn_view_gather gv[NV];
+        kpn_ibr_view ivs[NV];
+        float emin = 3.0e38f, esum = 0.0f;
+        if constexpr (VC > 0) {
+#pragma unroll
+            for (int v = 0; v < VC; ++v)
+                if (v < V) {
+                    kpn_gather_view(sc, v, h, P, D, gv[v]);
+                    kpn_encode_view(wl, lane, h, gv[v], lat0, ivs[v]);
+                    emin = fminf(emin, kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))));
+                }
+#pragma unroll
+            for (int v = 0; v < VC; ++v)
+                if (v < V) esum = KADD(esum, KSUB(kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))), emin));
+        } else {
+            for (int pass = 0; pass < 2; ++pass)
+                for (int v = 0; v < V; ++v) {
+                    const float* cp = sc.table + (size_t)v * KPN_TBL_STRIDE + KPN_TBL_CPOS;
+                    float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+                    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+                    const float dot = kpn_dot3(cr[0] / nrm, cr[1] / nrm, cr[2] / nrm, D[0], D[1], D[2]);
+                    const float e = kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f)));
+                    if (pass == 0) emin = fminf(emin, e); else esum = KADD(esum, KSUB(e, emin));
+                }
+        }
+        // fused mean/var over views of x' (utils.py:91-95): K-steps mean' (16 + 3 + pad), var' (16 + 3 + pad)
+        float mv[40];
 #pragma unroll
         for (int i = 0; i < 40; ++i) mv[i] = 0.0f;
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int v = 0; v < V; ++v) {
-                kpn_ibr_view iv;
-                kpn_ibr_view_inputs(sc, wp, v, lane, h, P, D, lat0, iv);
-                const float wv = KSUB(expf(KMUL(ani, KSUB(iv.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
+        auto stats = [&](int pass, const kpn_view_gather& g, const kpn_ibr_view& iv) {
+            const float wv = KSUB(kpn_fast_exp(KMUL(ani, KSUB(g.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
 #pragma unroll
-                for (int i = 0; i < 19; ++i) {
-                    const float x = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
-                    if (pass == 0) mv[i] = KADD(mv[i], KMUL(x, wv));
-                    else { const float d = KSUB(x, mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
+            for (int i = 0; i < 19; ++i) {
+                const float x = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
+                if (pass == 0) mv[i] = KADD(mv[i], KMUL(x, wv));
+                else { const float d = KSUB(x, mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
+            }
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            if constexpr (VC > 0) {
+#pragma unroll
+                for (int v = 0; v < VC; ++v) if (v < V) stats(pass, gv[v], ivs[v]);
+            } else {
+                for (int v = 0; v < V; ++v) {
+                    kpn_gather_view(sc, v, h, P, D, gv[0]);
+                    kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
+                    stats(pass, gv[0], ivs[0]);
                 }
             }
         }
         // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
         kpn_f32x16 base[2];
-        kpn_load_bias<2>(wp + kpn_seg_boff(SEG_BL_0A), h, base);
-        kpn_mfma_layer_regs<40, 2>(wp + kpn_seg_woff(SEG_BL_0A), lane, mv, base);
+        kpn_load_bias<2>(wl + kpn_seg_boff(SEG_BL_0A), h, base);
+        kpn_mfma_layer_regs<40, 2, 4, 1>(wl + kpn_seg_woff(SEG_BL_0A), lane, mv, base);
 
-        // online softmax over views of the colour logits, blending the SOURCE colours (model.py:1300-1301)
+        // per view: rest of the head; online softmax over views of the colour logits, blending the
+        // SOURCE colours (model.py:1300-1301)
         float lmax = -3.0e38f, lden = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-        for (int v = 0; v < V; ++v) {
-            kpn_ibr_view iv;
-            kpn_ibr_view_inputs(sc, wp, v, lane, h, P, D, lat0, iv);
-            const float wv = KSUB(expf(KMUL(ani, KSUB(iv.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
+        auto head = [&](const kpn_view_gather& g, const kpn_ibr_view& iv) {
+            const float wv = KSUB(kpn_fast_exp(KMUL(ani, KSUB(g.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
             float xin[20];
 #pragma unroll
             for (int i = 0; i < 19; ++i) xin[i] = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
             xin[19] = 0.0f;
             kpn_f32x16 a[2] = {base[0], base[1]};
-            kpn_mfma_layer_regs<20, 2>(wp + kpn_seg_woff(SEG_BL_0B), lane, xin, a);  // base_layer.0 (x part)
-            float h32[32];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h32[16 * b + r] = kpn_elu(a[b][r]);
+            kpn_mfma_layer_regs<20, 2, 4, 1>(wl + kpn_seg_woff(SEG_BL_0B), lane, xin, a);  // base_layer.0 (x part)
             kpn_f32x16 xa[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_BL_1), h, xa);
-            kpn_mfma_layer_regs<32, 1>(wp + kpn_seg_woff(SEG_BL_1), lane, h32, xa);  // base_layer.2
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_BL_1), h, xa);
+            kpn_mfma_layer<32, 1, 4, 1>(wl + kpn_seg_woff(SEG_BL_1), lane, [&](auto gi, float (&x)[4]) {  // base_layer.2
+                constexpr int gq = decltype(gi)::value;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = kpn_elu(a[gq / 4][(gq % 4) * 4 + i]);
+            }, xa);
             float x[16], tin[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = kpn_elu(xa[0][r]); tin[r] = x[r] * wv; }  // :1292-1294
-            kpn_f32x16 va[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V1_0), h, va);
-            kpn_mfma_layer_regs<16, 1>(wp + kpn_seg_woff(SEG_V1_0), lane, tin, va);  // vis_layer1.0
+            kpn_f32x16 va[1], vb[1];
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_V1_0), h, va);
+            kpn_mfma_layer_regs<16, 1, 4, 1>(wl + kpn_seg_woff(SEG_V1_0), lane, tin, va);  // vis_layer1.0
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
-            kpn_f32x16 vb[2];
-            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_V1_1), h, vb);
-            kpn_mfma_layer_regs<16, 2>(wp + kpn_seg_woff(SEG_V1_1), lane, tin, vb);  // vis_layer1.2 (33 rows)
-            const float visr = __shfl(kpn_elu(vb[1][0]), p);                     // row 32 sits in lane p (h=0)
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_V1_1), h, vb);
+            kpn_mfma_layer_regs<16, 1, 4, 1>(wl + kpn_seg_woff(SEG_V1_1), lane, tin, vb);  // vis_layer1.2 rows 0..31 (res)
+            const float visr = kpn_elu(kpn_row_dot(wl + kpn_row_off(ROW_V1_VIS), h, tin));   // row 32 (vis)
             const float sv = kpn_sigmoid(visr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = x[r] + kpn_elu(vb[0][r]); tin[r] = x[r] * sv; }  // :1295-1297 (mask = 1)
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V2_0), h, va);
-            kpn_mfma_layer_regs<16, 1>(wp + kpn_seg_woff(SEG_V2_0), lane, tin, va);  // vis_layer2.0
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_V2_0), h, va);
+            kpn_mfma_layer_regs<16, 1, 4, 1>(wl + kpn_seg_woff(SEG_V2_0), lane, tin, va);  // vis_layer2.0
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V2_1), h, va);
-            kpn_mfma_layer_regs<16, 1>(wp + kpn_seg_woff(SEG_V2_1), lane, tin, va);  // vis_layer2.2 (1 row)
-            const float vis = kpn_sigmoid(__shfl(va[0][0], p));                  // :1297
+            const float vis = kpn_sigmoid(kpn_row_dot(wl + kpn_row_off(ROW_V2_1), h, tin));  // vis_layer2.2 + Sigmoid
             float oin[20];  // out_layer.0 input [x32 | vis | ray_diff4]  (:1300)
-            oin[19] = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) oin[r] = x[r];
-            oin[16] = h ? iv.rd[0] : vis;
-            oin[17] = h ? iv.rd[2] : iv.rd[1];
-            oin[18] = h ? 0.0f : iv.rd[3];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_0), h, va);
-            kpn_mfma_layer_regs<20, 1>(wp + kpn_seg_woff(SEG_O_0), lane, oin, va);
+            oin[16] = h ? g.rd[0] : vis;
+            oin[17] = h ? g.rd[2] : g.rd[1];
+            oin[18] = h ? 0.0f : g.rd[3];
+            oin[19] = 0.0f;
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_O_0), h, va);
+            kpn_mfma_layer_regs<20, 1, 4, 1>(wl + kpn_seg_woff(SEG_O_0), lane, oin, va);
             float o8[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) o8[r] = kpn_elu(va[0][r]);
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_1), h, va);
-            kpn_mfma_layer_regs<8, 1>(wp + kpn_seg_woff(SEG_O_1), lane, o8, va);
-            float o4[4];
+            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_O_1), h, va);
+            kpn_mfma_layer_regs<8, 1, 4, 1>(wl + kpn_seg_woff(SEG_O_1), lane, o8, va);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o4[r] = kpn_elu(va[0][r]);
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_2), h, va);
-            kpn_mfma_layer_regs<4, 1>(wp + kpn_seg_woff(SEG_O_2), lane, o4, va);
-            const float logit = va[0][0];  // valid in h=0 lanes
+            for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
+            const float logit = kpn_row_dot(wl + kpn_row_off(ROW_O_2), h, tin);  // out_layer.4
             const float nmax = fmaxf(lmax, logit);
-            const float sc_old = expf(lmax - nmax), pn = expf(logit - nmax);
+            const float sc_old = kpn_fast_exp(lmax - nmax), pn = kpn_fast_exp(logit - nmax);
             lden = lden * sc_old + pn;
-            c0 = c0 * sc_old + iv.rgb[0] * pn; c1 = c1 * sc_old + iv.rgb[1] * pn; c2 = c2 * sc_old + iv.rgb[2] * pn;
+            c0 = c0 * sc_old + g.rgb[0] * pn; c1 = c1 * sc_old + g.rgb[1] * pn; c2 = c2 * sc_old + g.rgb[2] * pn;
             lmax = nmax;
+        };
+        if constexpr (VC > 0) {
+#pragma unroll
+            for (int v = 0; v < VC; ++v) if (v < V) head(gv[v], ivs[v]);
+        } else {
+            for (int v = 0; v < V; ++v) {
+                kpn_gather_view(sc, v, h, P, D, gv[0]);
+                kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
+                head(gv[0], ivs[0]);
+            }
         }
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;

@@ -132,9 +132,8 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
                  /*with_bias=*/false);
     pack_segment(P, SEG_BL_1, pl.w[P_BL_1], pl.b[P_BL_1], 32, 64, chain, ident);
     pack_segment(P, SEG_V1_0, pl.w[P_V1_0], pl.b[P_V1_0], 32, 32, chain, ident);
-    pack_segment(P, SEG_V1_1, pl.w[P_V1_1], pl.b[P_V1_1], 33, 32, chain, ident);
+    pack_segment(P, SEG_V1_1, pl.w[P_V1_1], pl.b[P_V1_1], 32, 32, chain, ident);  // rows 0..31 (res); row 32 (vis) below
     pack_segment(P, SEG_V2_0, pl.w[P_V2_0], pl.b[P_V2_0], 32, 32, chain, ident);
-    pack_segment(P, SEG_V2_1, pl.w[P_V2_1], pl.b[P_V2_1], 1, 32, chain, ident);
     // out_layer.0 columns: [x32 | vis | ray_diff4] (model.py:1300); extra K-steps 16,17,18
     pack_segment(P, SEG_O_0, pl.w[P_O_0], pl.b[P_O_0], 16, 37,
                  [](int s, int h) {
@@ -143,7 +142,16 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
                      return (s < 19 && f < 37) ? f : -1;
                  }, ident);
     pack_segment(P, SEG_O_1, pl.w[P_O_1], pl.b[P_O_1], 8, 16, chain, ident);
-    pack_segment(P, SEG_O_2, pl.w[P_O_2], pl.b[P_O_2], 1, 8, chain, ident);
+    // single-output layers as row vectors over the chained features of one 32-row block
+    auto pack_row = [&](int row, const float* W, int in_dim, float bias) {
+        float* r = P + kpn_row_off(row);
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < 16; ++k) { const int f = KPN_ROWMAP(k, h); r[h * 16 + k] = f < in_dim ? W[f] : 0.0f; }
+        r[32] = bias; r[33] = r[34] = r[35] = 0.0f;
+    };
+    pack_row(ROW_V1_VIS, pl.w[P_V1_1] + 32 * 32, 32, pl.b[P_V1_1][32]);
+    pack_row(ROW_V2_1, pl.w[P_V2_1], 32, pl.b[P_V2_1][0]);
+    pack_row(ROW_O_2, pl.w[P_O_2], 8, pl.b[P_O_2][0]);
     // scalars: |ani_al| (model.py:1287) and layers2(0), the query() result of a fully masked point
     float* sc = P + kpn_scalar_off();
     sc[0] = fabsf(pl.ani_al);
@@ -302,6 +310,13 @@ struct ProfState {
 static ProfState g_prof;
 #endif
 
+int fuse_grid_blocks() {
+#ifdef KPN_SIMT_EMU
+    return 4;
+#else
+    return 256;
+#endif
+}
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
               uint8_t* valid, void* ws, void* stream) {
     const QueryLayout L = query_layout(N, sc.V);
@@ -325,8 +340,13 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         ++g_prof.used;
     }
 #endif
-    KPN_LAUNCH(k_fuse_color, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count,
-               (const float*)xscr, mode, out);
+    const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
+    if (sc.V <= 3)  // per-view IBR inputs cached in registers
+        KPN_LAUNCH(k_fuse_color<3>, dim3(fblocks), dim3(512), stream, sc, ps, wp, (const int*)list, (const int*)count,
+                   (const float*)xscr, mode, out);
+    else
+        KPN_LAUNCH(k_fuse_color<0>, dim3(fblocks), dim3(512), stream, sc, ps, wp, (const int*)list, (const int*)count,
+                   (const float*)xscr, mode, out);
     return check_launch("field query");
 }
 }  // namespace
@@ -353,15 +373,23 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
 // hierarchical render
 namespace {
 struct RenderLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, rgba, contrib, color, depth, alpha, sdf, query, total; int64_t chunk; };
-int64_t pick_chunk(const kpn_render_args* a) {
+int64_t pick_chunk(const kpn_scene_desc* d, const kpn_render_args* a) {
+    // default: as many rays per pass as keep the row scratch (points x views x 256 B) under 4 GiB, at
+    // most 65536 — large passes amortise the tail of the persistent field kernels
     const int64_t R = (int64_t)a->nx * a->ny;
-    int64_t c = a->chunk_rays > 0 ? a->chunk_rays : 16384;
+    int64_t c = a->chunk_rays;
+    if (c <= 0) {
+        const int64_t Sfull = a->n_coarse + (a->fine ? a->n_fine : 0);
+        c = (4ll << 30) / (Sfull * d->n_views * 256) / 4096 * 4096;
+        if (c < 4096) c = 4096;
+        if (c > 65536) c = 65536;
+    }
     return c < R ? c : R;
 }
 RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
     RenderLayout L;
     const int64_t R = (int64_t)a->nx * a->ny;
-    const int64_t C = pick_chunk(a);
+    const int64_t C = pick_chunk(d, a);
     const int64_t Sfull = a->n_coarse + (a->fine ? a->n_fine : 0);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };

@@ -14,13 +14,23 @@ typedef float kpn_f32x16 __attribute__((ext_vector_type(16)));
 typedef float kpn_f32x4 __attribute__((ext_vector_type(4)));
 #define KPN_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
-__device__ __forceinline__ float kpn_fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float kpn_fast_log(float x) { return __logf(x); }
+// raw v_exp_f32 / v_log_f32 (base 2, ~1 ulp, no denormal fix-ups: callers keep arguments in range)
+__device__ __forceinline__ float kpn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float kpn_log2(float x) { return __builtin_amdgcn_logf(x); }
+typedef const __attribute__((address_space(1))) kpn_f32x4* kpn_gptr4;  // global (not flat) loads
+typedef const __attribute__((address_space(3))) kpn_f32x4* kpn_lptr4;  // LDS loads (ds_read_b128)
+#define KPN_GLOBAL4(p) ((kpn_gptr4)(p))
+#define KPN_LDS4(p) ((kpn_lptr4)(p))
 #else
 #include <math.h>
-static inline float kpn_fast_exp(float x) { return expf(x); }
-static inline float kpn_fast_log(float x) { return logf(x); }
+static inline float kpn_exp2(float x) { return exp2f(x); }
+static inline float kpn_log2(float x) { return log2f(x); }
+typedef const kpn_f32x4* kpn_gptr4;
+typedef const kpn_f32x4* kpn_lptr4;
+#define KPN_GLOBAL4(p) ((kpn_gptr4)(p))
+#define KPN_LDS4(p) ((kpn_lptr4)(p))
 #endif
+__device__ __forceinline__ float kpn_fast_exp(float x) { return kpn_exp2(x * 1.44269504088896341f); }
 
 #define KPN_NKPT 24
 #define KPN_MAXV 16
@@ -67,7 +77,7 @@ enum {
     SEG_G1_0A, SEG_G1_0B, SEG_G1_1, SEG_G1_2, SEG_G1_3,  // geometry MLP layers1 (per point x view)
     SEG_G2_0, SEG_G2_1, SEG_G2_2, SEG_CMP,               // layers2 + ibr_compress_gfeat (per point)
     SEG_RE_0, SEG_RE_1, SEG_BL_0A, SEG_BL_0B, SEG_BL_1,  // IBR head
-    SEG_V1_0, SEG_V1_1, SEG_V2_0, SEG_V2_1, SEG_O_0, SEG_O_1, SEG_O_2,
+    SEG_V1_0, SEG_V1_1, SEG_V2_0, SEG_O_0, SEG_O_1,
     SEG_COUNT
 };
 struct kpn_seg_shape { int ks, nob, g; };
@@ -75,8 +85,7 @@ struct kpn_seg_shape { int ks, nob, g; };
 // group) and its 64-channel feature part; x'-ordered 35-vectors take 20 K-steps (16 + 3 + 1 pad).
 #define KPN_SEG_SHAPES                                                                                      \
     {84, 4, 7}, {32, 4, 4}, {64, 4, 4}, {68, 4, 4}, {64, 2, 4}, {64, 2, 4}, {32, 2, 4}, {32, 1, 4}, {64, 1, 4}, \
-    {4, 1, 4}, {8, 2, 4}, {40, 2, 4}, {20, 2, 4}, {32, 1, 4}, {16, 1, 4}, {16, 2, 4}, {16, 1, 4}, {16, 1, 4},     \
-    {20, 1, 4}, {8, 1, 4}, {4, 1, 4}
+    {4, 1, 4}, {8, 2, 4}, {40, 2, 4}, {20, 2, 4}, {32, 1, 4}, {16, 1, 4}, {16, 1, 4}, {16, 1, 4}, {20, 1, 4}, {8, 1, 4}
 static constexpr kpn_seg_shape kpn_seg_shapes[SEG_COUNT] = {KPN_SEG_SHAPES};
 
 constexpr int kpn_seg_wfloats(int seg) { return kpn_seg_shapes[seg].ks * kpn_seg_shapes[seg].nob * 64; }
@@ -90,7 +99,15 @@ constexpr int kpn_seg_boff(int seg) { return kpn_seg_woff(seg) + kpn_seg_wfloats
 // scalars appended after the segments: [0] = |ani_al|, [1..2] = layers2(0) = (sdf_raw, rad) of a point
 // that is masked in every view, [3] pad
 constexpr int kpn_scalar_off() { return kpn_seg_woff(SEG_COUNT); }
-constexpr int kpn_packed_floats() { return kpn_scalar_off() + 4; }
+// single-output layers are VALU dot products over a lane's 16 chained features + one cross-half add:
+// row vector layout [2 halves][16 regs] weights, then [bias, 0, 0, 0]
+enum { ROW_V1_VIS, ROW_V2_1, ROW_O_2, ROW_COUNT };  // vis_layer1.2 row 32, vis_layer2.2, out_layer.4
+constexpr int kpn_row_off(int row) { return kpn_scalar_off() + 4 + row * 36; }
+constexpr int kpn_packed_floats() { return kpn_row_off(ROW_COUNT); }
+// everything k_fuse_color reads (segments SEG_G2_0.., scalars, row vectors) is one contiguous region
+// of 136.8 KB: it is copied into LDS once per (persistent) workgroup
+constexpr int kpn_k2_base() { return kpn_seg_woff(SEG_G2_0); }
+constexpr int kpn_k2_floats() { return kpn_packed_floats() - kpn_k2_base(); }
 
 // row of the 32x32 D tile held by register r of a lane in half h
 #define KPN_ROWMAP(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

@@ -12,13 +12,29 @@ __device__ __forceinline__ float kpn_dot3(float a0, float a1, float a2, float b0
     return KADD(KADD(KMUL(a0, b0), KMUL(a1, b1)), KMUL(a2, b2));
 }
 
-__device__ __forceinline__ float kpn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float kpn_sigmoid(float x) { return 1.0f / (1.0f + kpn_fast_exp(-x)); }
 // Softplus(beta=100, threshold=20), reference src/utils.py:523-524.  log(1+e^t)/100: the /100 makes
 // the fast exp/log's ~1e-6 relative error an absolute error < 1e-8.
 __device__ __forceinline__ float kpn_softplus100(float x) {
-    const float t = x * 100.0f;
-    const float sp = kpn_fast_log(1.0f + kpn_fast_exp(t)) * 0.01f;
-    return (t > 20.0f) ? x : sp;
+    const float sp = kpn_log2(1.0f + kpn_exp2(x * 144.269504088896341f)) * 6.93147180559945309e-3f;  // ln2/100
+    return (x * 100.0f > 20.0f) ? x : sp;
+}
+// sin and cos of y (radians), |y| up to a few hundred: quadrant reduction by a three-term Cody-Waite
+// split of pi/2 and degree-7/8 minimax polynomials on [-pi/4, pi/4] (about 1 ulp).  Register-light,
+// unlike the libm sincosf with its Payne-Hanek slow path, which made the keypoint encoding spill.
+__device__ __forceinline__ void kpn_sincos(float y, float& s, float& c) {
+    const float k = rintf(y * 0.636619772367581343f);
+    float r = fmaf(k, -1.5703125f, y);
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188216e-8f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(r2 * r, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(r2, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
 }
 __device__ __forceinline__ float kpn_elu(float x) { return x > 0.0f ? x : (kpn_fast_exp(x) - 1.0f); }
 
@@ -104,7 +120,15 @@ __device__ __forceinline__ void kpn_static_for(F&& f) {
 #ifdef KPN_SIMT_EMU
 #define KPN_SCHED_BARRIER() ((void)0)
 #define KPN_PIN_POINTER(p) ((void)0)
+#define KPN_FENCE_RW(v) ((void)0)
+#define KPN_FENCE_R(v) ((void)0)
 #else
+// Empty volatile asm statements keep their program order.  "+v"(acc) after a group's MFMAs makes the
+// next group's MFMAs depend on it (the DAG scheduler otherwise reorders MFMAs of different
+// accumulators across the whole unrolled layer and spills their operands); "v"(w) makes the prefetched
+// operands of the NEXT group be waited for here, i.e. one group (>= 1k cycles of MFMA) after issue.
+#define KPN_FENCE_RW(v) asm volatile("" : "+v"(v))
+#define KPN_FENCE_R(v) asm volatile("" ::"v"(v))
 #define KPN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // an opaque re-definition of a (wave-uniform) pointer: loads through it cannot be hoisted above this point
 #define KPN_PIN_POINTER(p) asm volatile("" : "+s"(p))
@@ -122,50 +146,76 @@ __device__ __forceinline__ void kpn_load_bias(const float* __restrict__ bseg, in
         }
     }
 }
-template <int NF>
-__device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, int lane, float (&w)[NF]) {
-    static_assert(NF % 4 == 0, "a lane's operands of one group are whole float4s");
-    const float4* src = reinterpret_cast<const float4*>(gbase) + lane * (NF / 4);
+// MEM = 0: the stream is in global memory (L2-resident); MEM = 1: in LDS
+template <int NQ, int MEM>
+__device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, int lane, kpn_f32x4 (&w)[NQ]) {
+    if constexpr (MEM == 0) {
+        const kpn_gptr4 src = KPN_GLOBAL4(gbase) + lane * NQ;
 #pragma unroll
-    for (int q = 0; q < NF / 4; ++q) {
-        const float4 v = src[q];
-        w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        for (int q = 0; q < NQ; ++q) w[q] = src[q];
+    } else {
+        const kpn_lptr4 src = KPN_LDS4(gbase) + lane * NQ;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) w[q] = src[q];
     }
 }
 // in_fn(kpn_ic<g>, float (&x)[G]) produces the B operands of K-steps [g*G, (g+1)*G)
-template <int KS, int NOB, int G, class InFn>
+template <int KS, int NOB, int G, int MEM = 0, class InFn>
 __device__ __forceinline__ void kpn_mfma_layer(const float* __restrict__ wseg, int lane, InFn&& in_fn,
                                                kpn_f32x16 (&acc)[NOB]) {
     static_assert(KS % G == 0, "K-steps come in whole groups");
-    constexpr int NG = KS / G, NF = G * NOB;
-    float w[2][NF], x[2][G];
-    kpn_load_group<NF>(wseg, lane, w[0]);
+    static_assert((G * NOB) % 4 == 0, "a lane's operands of one group are whole float4s");
+    constexpr int NG = KS / G, NQ = G * NOB / 4;
+    kpn_f32x4 w[2][NQ];
+    float x[2][G];
+    kpn_load_group<NQ, MEM>(wseg, lane, w[0]);
     in_fn(kpn_ic<0>{}, x[0]);
     kpn_static_for<0, NG>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
         constexpr int cur = g & 1, nxt = cur ^ 1;
         if constexpr (g + 1 < NG) {
-            const float* gp = wseg + (size_t)(g + 1) * 64 * NF;
-            KPN_PIN_POINTER(gp);
-            kpn_load_group<NF>(gp, lane, w[nxt]);
+            const float* gp = wseg + (size_t)(g + 1) * 64 * (4 * NQ);
+            if constexpr (MEM == 0) KPN_PIN_POINTER(gp);
+            kpn_load_group<NQ, MEM>(gp, lane, w[nxt]);
             in_fn(kpn_ic<g + 1>{}, x[nxt]);
         }
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob)
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][i * NOB + ob], x[cur][i], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][(i * NOB + ob) / 4][(i * NOB + ob) % 4], x[cur][i],
+                                                               acc[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) KPN_FENCE_RW(acc[ob]);
+        if constexpr (g + 1 < NG) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) KPN_FENCE_R(w[nxt][q]);
+        }
         KPN_SCHED_BARRIER();
     });
 }
 // B operands taken from a register array: K-step s reads src[s]
-template <int KS, int NOB, int G = 4, int NSRC>
+template <int KS, int NOB, int G = 4, int MEM = 0, int NSRC>
 __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ wseg, int lane, const float (&src)[NSRC],
                                                     kpn_f32x16 (&acc)[NOB]) {
     static_assert(NSRC >= KS, "operand array too short");
-    kpn_mfma_layer<KS, NOB, G>(wseg, lane, [&](auto gi, float (&x)[G]) {
+    kpn_mfma_layer<KS, NOB, G, MEM>(wseg, lane, [&](auto gi, float (&x)[G]) {
         constexpr int g = decltype(gi)::value;
 #pragma unroll
         for (int i = 0; i < G; ++i) x[i] = src[g * G + i];
     }, acc);
+}
+
+// A single-output Linear over a lane's 16 chained features: both halves of a point add their partial
+// dot products (lanes p and p+32) and every lane gets  W[row,:].x + b.
+__device__ __forceinline__ float kpn_row_dot(const float* __restrict__ rowvec, int h, const float (&x)[16]) {
+    const float4* w4 = reinterpret_cast<const float4*>(rowvec + h * 16);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 w = w4[q];
+        acc = fmaf(w.x, x[4 * q + 0], acc); acc = fmaf(w.y, x[4 * q + 1], acc);
+        acc = fmaf(w.z, x[4 * q + 2], acc); acc = fmaf(w.w, x[4 * q + 3], acc);
+    }
+    return acc + __shfl_xor(acc, 32) + rowvec[32];
 }
