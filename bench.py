@@ -12,7 +12,7 @@ shard over ranks, weak scaling) and the finished RGB images are all-gathered ove
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel k_geo_rows (fp32
 MFMA bound; duration measured live with HIP events on the launch stream, see kpn_profile_*), and
 "cpu_baseline": the CPU oracle ("port") timed on this host's cores on a bounded sample of the same
-workload (one reference tile = 4096 strided rays of the same frame).
+workload (a strided sub-lattice of the same frame sized for ~15 s of CPU work).
 """
 import argparse
 import ctypes
@@ -41,27 +41,38 @@ def parse():
     ap.add_argument("--mask", default="ellipsoid", choices=["ellipsoid", "dense"])
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rays", type=int, default=4096)
+    ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = size the CPU sample for ~15 s")
     return ap.parse_args()
 
 
-def cpu_baseline(args, scene_cpu, sd):
-    """Oracle (C restatement, OpenMP) on one reference tile: stride res/64 sub-lattice of the frame."""
+def cpu_baseline(args, scene_cpu, sd, target_s=15.0):
+    """Oracle (C restatement, OpenMP over points) on a strided sub-lattice of the SAME frame, sized from a
+    short probe so that the timed run is about `target_s` seconds of CPU work."""
     import numpy as np
     from oracle import oracle
-    step = max(1, args.res // 64)
-    n = int(round(args.cpu_sample_rays ** 0.5))
-    ys, xs = np.meshgrid(np.arange(n) * step, np.arange(n) * step, indexing="ij")
-    pix = np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.int32)
     osc = oracle.OracleScene(scene_cpu)
     wflat = oracle.flat_weights(sd)
-    oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix[:64], args.samples, args.samples)  # warm
-    t0 = time.perf_counter()
-    oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples)
-    dt = time.perf_counter() - t0
+
+    def lattice(n):
+        step = max(1, args.res // n)
+        ys, xs = np.meshgrid(np.arange(n) * step, np.arange(n) * step, indexing="ij")
+        return np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.int32), step
+
+    def run(pix):
+        t0 = time.perf_counter()
+        oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples)
+        return time.perf_counter() - t0
+
+    pix, _ = lattice(32)
+    run(pix[:64])                      # warm-up (library load, page-in)
+    probe = run(pix)                   # 1024 rays spread over the frame
+    n = int(min(args.res, max(32, (1024 * target_s / max(probe, 1e-3)) ** 0.5))) if args.cpu_sample_rays <= 0 else int(args.cpu_sample_rays ** 0.5)
+    n = max(32, n // 32 * 32)
+    pix, step = lattice(n)
+    dt = run(pix)
     return {"value": pix.shape[0] / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{pix.shape[0]} rays (one {n}x{n} strided tile, step {step}) of the same frame, "
-                      f"{args.samples}+{args.samples} samples, {dt:.1f} s, OpenMP over points"}
+            "sample": f"{pix.shape[0]} rays ({n}x{n} lattice, step {step}) of the same frame, {args.samples}+{args.samples} "
+                      f"samples/ray, {dt:.1f} s of wall time, C oracle with OpenMP over points on {os.cpu_count()} hardware threads"}
 
 
 def main():
@@ -130,6 +141,12 @@ def main():
     if rank == 0:
         flops_row = L.kpn_flops_per_row()
         achieved = (rows.value * flops_row) / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # HBM bytes per launch of k_geo_rows: PMC-measured bytes per row (profiles/geo_rows_traffic.json, from
+        # separate rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950 note) x rows per launch of THIS run
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "geo_rows_traffic.json")
+        if os.path.exists(tj) and launches.value > 0:
+            traffic = json.load(open(tj))["hbm_bytes_per_row"] * rows.value / launches.value
         alpha_mean = float(out["alpha_fine"].mean())
         line = {
             "metric": "rendered rays/sec (64 coarse + 64 fine samples/ray = 192 field evaluations/ray)",
@@ -144,7 +161,8 @@ def main():
                        "valid_rows_per_step": rows.value / max(1, args.steps),
                        "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},
             "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": 256.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "algorithmic_flop_per_row": flops_row,
                          "kernel_time_share": (ms.value * 1e-3) / dt},
