@@ -40,12 +40,13 @@ def parse():
     ap.add_argument("--samples", type=int, default=64, help="coarse = fine samples per ray")
     ap.add_argument("--mask", default="ellipsoid", choices=["ellipsoid", "dense"])
     ap.add_argument("--chunk-rays", type=int, default=0)
+    ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = size the CPU sample for ~15 s")
     return ap.parse_args()
 
 
-def cpu_baseline(args, scene_cpu, sd, target_s=15.0):
+def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
     """Oracle (C restatement, OpenMP over points) on a strided sub-lattice of the SAME frame, sized from a
     short probe so that the timed run is about `target_s` seconds of CPU work."""
     import numpy as np
@@ -60,7 +61,7 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0):
 
     def run(pix):
         t0 = time.perf_counter()
-        oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples)
+        oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples, fine=fine)
         return time.perf_counter() - t0
 
     pix, _ = lattice(32)
@@ -102,7 +103,9 @@ def main():
     w = ops.PackedWeights(sd, device=dev)
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
                            scene["src_foreground_mask"])
-    plan = ops.RenderPlan(ps, (0, 0, 1, res, res), args.samples, args.samples, fine=True, chunk_rays=args.chunk_rays)
+    fine = not args.no_fine
+    evals_per_ray = args.samples * (3 if fine else 1)
+    plan = ops.RenderPlan(ps, (0, 0, 1, res, res), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
     gather_buf = torch.empty(world, 3, res, res, device=dev) if world > 1 else None
 
     def step(i):
@@ -147,17 +150,18 @@ def main():
         tj = os.path.join(ROOT, "profiles", "geo_rows_traffic.json")
         if os.path.exists(tj) and launches.value > 0:
             traffic = json.load(open(tj))["hbm_bytes_per_row"] * rows.value / launches.value
-        alpha_mean = float(out["alpha_fine"].mean())
+        alpha_mean = float(out["alpha_fine" if fine else "alpha"].mean())
         line = {
-            "metric": "rendered rays/sec (64 coarse + 64 fine samples/ray = 192 field evaluations/ray)",
+            "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray = {evals_per_ray} field evaluations/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {res}x{res} novel view, {args.views} source views {res}x{res}, "
-                                   f"{args.samples} coarse + {args.samples} fine samples/ray, {args.mask} fg mask, "
+            "config": {"workload": f"{'configs[1]' if (fine and args.views == 3 and args.samples == 64 and res == 512) else 'custom'}: "
+                                   f"{res}x{res} novel view, {args.views} source views {res}x{res}, "
+                                   f"{args.samples} coarse" + (f" + {args.samples} fine" if fine else "") + f" samples/ray, {args.mask} fg mask, "
                                    f"seeded synthetic scene, random-init hot-path weights",
-                       "rays_per_step": rays_per_step, "field_evals_per_ray": 3 * args.samples,
-                       "sampled_points_per_sec": value * 3 * args.samples,
+                       "rays_per_step": rays_per_step, "field_evals_per_ray": evals_per_ray,
+                       "sampled_points_per_sec": value * evals_per_ray,
                        "valid_rows_per_step": rows.value / max(1, args.steps),
                        "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},
             "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -168,7 +172,7 @@ def main():
                          "kernel_time_share": (ms.value * 1e-3) / dt},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, scene_cpu, sd)
+            line["cpu_baseline"] = cpu_baseline(args, scene_cpu, sd, fine=fine)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
 // the lane's 32-register result (block b = q4/4, regs 4*(q4%4)..+3) — lane-contiguous 1-KB stores.
 __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                      const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                     float* __restrict__ xscr) {
+                                                     int* __restrict__ tickets, float* __restrict__ xscr) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -96,8 +96,26 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
     const int nwork = ntiles * sc.V;
     const float pe_pi = 3.14159274101257324f;  // float32(pi), spatial.py:42-47
+    // the four bias blocks (448 floats) sit in LDS for the lifetime of the persistent workgroup: a layer
+    // starts with a ds_read instead of an exposed L2 round trip
+    __shared__ __attribute__((aligned(16))) float bias_s[4][128];
+    {
+        const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
+        for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
+            const int sg = i >> 7, k = i & 127;
+            bias_s[sg][k] = k < kpn_seg_bfloats(segs[sg]) ? wp[kpn_seg_boff(segs[sg]) + k] : 0.0f;
+        }
+    }
+    __syncthreads();
 
-    for (int wi = wave; wi < nwork; wi += nwaves) {
+    // work items are drawn from a device-wide ticket counter (zeroed by the launcher): waves on CUs that run
+    // slower simply draw fewer tiles, which removes the tail of a static round-robin assignment
+    (void)wave; (void)nwaves;
+    for (;;) {
+        int wi = 0;
+        if (lane == 0) wi = atomicAdd(tickets + 0, 1);
+        wi = __shfl(wi, 0);
+        if (wi >= nwork) break;
         const int t = wi / sc.V, v = wi - t * sc.V;
         int ci = t * KPN_TILE + p;
         if (ci >= count) ci = count - 1;  // pad lanes recompute the last point; their result is never read
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
             const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
             const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
-            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_0A), h, a0);
+            kpn_load_bias<4>(bias_s[0], h, a0);
             // group j = keypoint j + 12h: 7 encoding values (spatial.py:110-118), produced while the
             // previous keypoint's 28 MFMAs issue
             kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         }
         // ---- layers1.1 : softplus(128) -> 128 ----
         kpn_f32x16 a1[4];
-        kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_1), h, a1);
+        kpn_load_bias<4>(bias_s[1], h, a1);
         kpn_mfma_layer<64, 4, 4>(wp + kpn_seg_woff(SEG_G1_1), lane, [&](auto gi, float (&x)[4]) {
             constexpr int g = decltype(gi)::value;
 #pragma unroll
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         {
             const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
-            kpn_load_bias<4>(wp + kpn_seg_boff(SEG_G1_2), h, a2);
+            kpn_load_bias<4>(bias_s[2], h, a2);
             kpn_mfma_layer<68, 4, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 if constexpr (g < 16) {
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         // ---- layers1.3 : softplus(120) -> 64, linear ----
         {
             kpn_f32x16 acc[2];
-            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_G1_3), h, acc);
+            kpn_load_bias<2>(bias_s[3], h, acc);
             kpn_mfma_layer<64, 2, 4>(wp + kpn_seg_woff(SEG_G1_3), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
@@ -269,7 +287,8 @@ __device__ __forceinline__ void kpn_encode_view(const float* __restrict__ wl, in
 template <int VC>
 __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                       const float* __restrict__ xscr, int mode, float* __restrict__ out) {
+                                                       int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
+                                                       float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -290,7 +309,12 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
     const float* wl = wlds - kpn_k2_base();
     const float ani = wl[kpn_scalar_off() + 0];  // |ani_al|
 
-    for (int t = wave; t < ntiles; t += nwaves) {
+    (void)wave; (void)nwaves;
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(tickets + 1, 1);
+        t = __shfl(t, 0);
+        if (t >= ntiles) break;
         const int ci_raw = t * KPN_TILE + p;
         const int ci = ci_raw < count ? ci_raw : count - 1;
         const int64_t n = list[ci];

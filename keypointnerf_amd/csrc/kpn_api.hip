@@ -2,6 +2,7 @@
 // hierarchical render pipeline.  Host code only launches kernels on the caller's stream; it never
 // synchronises or allocates (except kpn_selftest_mfma, a diagnostic).
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -295,7 +296,8 @@ int field_grid_blocks() {
 #ifdef KPN_SIMT_EMU
     return 8;
 #else
-    return 512;
+    static int blocks = [] { const char* e = getenv("KPN_GEO_BLOCKS"); return e ? atoi(e) : 512; }();  // tuning knob
+    return blocks;
 #endif
 }
 // ---- measurement hooks ----
@@ -324,14 +326,14 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
-    hipMemsetAsync(count, 0, sizeof(int), (hipStream_t)stream);
+    hipMemsetAsync(count, 0, 4 * sizeof(int), (hipStream_t)stream);  // [0] valid count, [1] k_geo_rows tickets, [2] k_fuse_color tickets
     KPN_LAUNCH(k_mask_compact, grid1d(N, 256), dim3(256), stream, sc, ps, N, mode, wp + kpn_scalar_off(), out, valid, list, count);
     const int blocks = field_grid_blocks();
 #ifndef KPN_SIMT_EMU
     const bool prof = g_prof.on && g_prof.used < g_prof.cap;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
 #endif
-    KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, xscr);
+    KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
 #ifndef KPN_SIMT_EMU
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
@@ -343,10 +345,10 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
     if (sc.V <= 3)  // per-view IBR inputs cached in registers
         KPN_LAUNCH(k_fuse_color<3>, dim3(fblocks), dim3(512), stream, sc, ps, wp, (const int*)list, (const int*)count,
-                   (const float*)xscr, mode, out);
+                   count + 1, (const float*)xscr, mode, out);
     else
         KPN_LAUNCH(k_fuse_color<0>, dim3(fblocks), dim3(512), stream, sc, ps, wp, (const int*)list, (const int*)count,
-                   (const float*)xscr, mode, out);
+                   count + 1, (const float*)xscr, mode, out);
     return check_launch("field query");
 }
 }  // namespace

@@ -16,6 +16,9 @@ __device__ __forceinline__ float kpn_sigmoid(float x) { return 1.0f / (1.0f + kp
 // Softplus(beta=100, threshold=20), reference src/utils.py:523-524.  log(1+e^t)/100: the /100 makes
 // the fast exp/log's ~1e-6 relative error an absolute error < 1e-8.
 __device__ __forceinline__ float kpn_softplus100(float x) {
+#ifdef KPN_ABLATE_ACT  // timing experiment only: wrong results
+    return x;
+#endif
     const float sp = kpn_log2(1.0f + kpn_exp2(x * 144.269504088896341f)) * 6.93147180559945309e-3f;  // ln2/100
     return (x * 100.0f > 20.0f) ? x : sp;
 }
@@ -119,6 +122,7 @@ __device__ __forceinline__ void kpn_static_for(F&& f) {
 }
 #ifdef KPN_SIMT_EMU
 #define KPN_SCHED_BARRIER() ((void)0)
+#define KPN_SCHED_GROUP(mask, n) ((void)0)
 #define KPN_PIN_POINTER(p) ((void)0)
 #define KPN_FENCE_RW(v) ((void)0)
 #define KPN_FENCE_R(v) ((void)0)
@@ -130,6 +134,8 @@ __device__ __forceinline__ void kpn_static_for(F&& f) {
 #define KPN_FENCE_RW(v) asm volatile("" : "+v"(v))
 #define KPN_FENCE_R(v) asm volatile("" ::"v"(v))
 #define KPN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// scheduling pipeline inside a group region: first the next group's operand fetches, then the MFMAs
+#define KPN_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 // an opaque re-definition of a (wave-uniform) pointer: loads through it cannot be hoisted above this point
 #define KPN_PIN_POINTER(p) asm volatile("" : "+s"(p))
 #endif
@@ -150,9 +156,15 @@ __device__ __forceinline__ void kpn_load_bias(const float* __restrict__ bseg, in
 template <int NQ, int MEM>
 __device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, int lane, kpn_f32x4 (&w)[NQ]) {
     if constexpr (MEM == 0) {
+#ifdef KPN_ABLATE_WLOAD  // timing experiment only (wrong results): no weight traffic at all
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const float f = 1e-3f * (float)(lane + q); w[q] = kpn_f32x4{f, -f, f, -f}; }
+        (void)gbase;
+#else
         const kpn_gptr4 src = KPN_GLOBAL4(gbase) + lane * NQ;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) w[q] = src[q];
+#endif
     } else {
         const kpn_lptr4 src = KPN_LDS4(gbase) + lane * NQ;
 #pragma unroll
@@ -190,6 +202,15 @@ __device__ __forceinline__ void kpn_mfma_layer(const float* __restrict__ wseg, i
         if constexpr (g + 1 < NG) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) KPN_FENCE_R(w[nxt][q]);
+            KPN_SCHED_GROUP(MEM == 0 ? 0x020 : 0x100, NQ);  // VMEM reads (global) / DS reads (LDS) of the next group first
+            // then this group's MFMAs, each followed by a few of the VALU / transcendental instructions that
+            // produce the next group's B operands, so that no VALU clump leaves the matrix pipe idle
+#pragma unroll
+            for (int i = 0; i < G * NOB; ++i) {
+                KPN_SCHED_GROUP(0x008, 1);
+                KPN_SCHED_GROUP(0x002, 3);
+                KPN_SCHED_GROUP(0x400, 1);
+            }
         }
         KPN_SCHED_BARRIER();
     });
