@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
     if (is_valid) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)n;
 }
 
+// Boundary-smooth pooling weight of one view (model.py:752-759, mask == 1), un-normalised
+__device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
+    const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
+    float w3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
+        w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
+    }
+    return KMUL(KMUL(w3[0], w3[1]), w3[2]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row kernel.  x scratch layout: [(tile*V + v)*8 + q4][lane] float4, q4 = 4 consecutive registers of
 // the lane's 32-register result (block b = q4/4, regs 4*(q4%4)..+3) — lane-contiguous 1-KB stores.
@@ -187,22 +199,51 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
                 }
             }, a2);
         }
-        // ---- layers1.3 : softplus(120) -> 64, linear ----
+        // ---- layers1.3 : softplus(120) -> 64, linear.  The colour head's per-(point,view) gathers ride along
+        //      (query_color, model.py:806-832): this kernel already has the projection and VALU/memory slack,
+        //      k_fuse_color has neither.  They are produced inside this layer's operand callback so that their
+        //      loads and arithmetic interleave with its MFMAs. ----
         {
             kpn_f32x16 acc[2];
+            float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
             kpn_load_bias<2>(bias_s[3], h, acc);
             kpn_mfma_layer<64, 2, 4>(wp + kpn_seg_woff(SEG_G1_3), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a2[g / 4][(g % 4) * 4 + i]);
+                if constexpr (g == 2) {
+                    if (h == 0) {  // [r,g,b, pooling weight]
+                        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+                        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
+                        rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
+                    } else {       // texture channels (model.py:818)
+                        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+                        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+                        rec0 = kpn_tap4(tx, 8, 0, tt);
+                        rec1 = kpn_tap4(tx, 8, 4, tt);
+                    }
+                }
+                if constexpr (g == 6) {
+                    if (h == 0) {  // [ray_diff direction(3), dot]  (model.py:823-832)
+                        const float* cp = tb + KPN_TBL_CPOS;
+                        float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+                        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+                        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+                        const float r0 = KSUB(D[0], cr[0]), r1 = KSUB(D[1], cr[1]), r2 = KSUB(D[2], cr[2]);
+                        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
+                        rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
+                    }
+                }
             }, acc);
-            float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * 8) * 64 + lane;
+            float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd)
                     dst[(b * 4 + qd) * 64] =
                         make_float4(acc[b][4 * qd + 0], acc[b][4 * qd + 1], acc[b][4 * qd + 2], acc[b][4 * qd + 3]);
+            dst[8 * 64] = rec0;
+            dst[9 * 64] = rec1;
         }
     }
 }
@@ -222,43 +263,20 @@ struct kpn_ibr_view {
     float xb1[3];   // x' rows 32..34 (h == 0 lanes only)
 };
 
-// Boundary-smooth pooling weight of one view (model.py:752-759, mask == 1), un-normalised
-__device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
-    const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
-    float w3[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
-        w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
-    }
-    return KMUL(KMUL(w3[0], w3[1]), w3[2]);
-}
-
-__device__ __forceinline__ void kpn_gather_view(const kpn_scene_dev& sc, int v, int h, const float (&P)[3],
-                                                const float (&D)[3], kpn_view_gather& o) {
-    const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-    const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
-    o.pw = kpn_pix_weight(q);
-    const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
-    const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
-    o.rgb[0] = c.x; o.rgb[1] = c.y; o.rgb[2] = c.z;
-    const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
-    const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
-    const float4 t0 = kpn_tap4(tx, 8, 0, tt), t1 = kpn_tap4(tx, 8, 4, tt);       // model.py:818
+// the gather record of (tile t, view v) written by k_geo_rows: own half + partner half (lane ^ 32)
+__device__ __forceinline__ void kpn_gather_view(const float* __restrict__ xscr, int t, int V, int v, int lane, int h,
+                                                kpn_view_gather& o) {
+    const float4* rec = reinterpret_cast<const float4*>(xscr) + ((size_t)(t * V + v) * KPN_ROW_SLABS + 8) * 64;
+    const float4 own0 = rec[lane], own1 = rec[64 + lane], oth0 = rec[lane ^ 32], oth1 = rec[64 + (lane ^ 32)];
+    const float4 a0 = h ? oth0 : own0, a1 = h ? oth1 : own1;  // [r,g,b,pw] , [ray_diff(3), dot]
+    const float4 t0 = h ? own0 : oth0, t1 = h ? own1 : oth1;  // texture channels 0..3, 4..7
+    o.pw = a0.w;
+    o.rgb[0] = a0.x; o.rgb[1] = a0.y; o.rgb[2] = a0.z;
     // x' order is [lat24 | rgb3 | tex8]: rows 24..27 live in regs 12..15 of the h=0 lanes, rows 28..31 in
     // regs 12..15 of h=1, rows 32..34 in block 1 regs 0..2 of h=0
-    o.fadd[0] = h ? t0.y : c.x; o.fadd[1] = h ? t0.z : c.y; o.fadd[2] = h ? t0.w : c.z; o.fadd[3] = h ? t1.x : t0.x;
+    o.fadd[0] = h ? t0.y : a0.x; o.fadd[1] = h ? t0.z : a0.y; o.fadd[2] = h ? t0.w : a0.z; o.fadd[3] = h ? t1.x : t0.x;
     o.fadd[4] = h ? 0.0f : t1.y; o.fadd[5] = h ? 0.0f : t1.z; o.fadd[6] = h ? 0.0f : t1.w;
-    // ray-direction difference, model.py:823-832
-    const float* cp = tb + KPN_TBL_CPOS;
-    float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
-    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-    cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
-    const float r0 = KSUB(D[0], cr[0]), r1 = KSUB(D[1], cr[1]), r2 = KSUB(D[2], cr[2]);
-    const float rn = sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2));
-    const float rc = fmaxf(rn, 1e-6f);
-    o.rd[0] = r0 / rc; o.rd[1] = r1 / rc; o.rd[2] = r2 / rc;
-    o.rd[3] = kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]);
+    o.rd[0] = a1.x; o.rd[1] = a1.y; o.rd[2] = a1.z; o.rd[3] = a1.w;
 }
 
 // ray_encoder: Linear(4,16) ELU Linear(16,35) ELU (model.py:1246,1279), then x' = rgb_feat' + dir' (:1281-1284)
@@ -318,25 +336,22 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         const int ci_raw = t * KPN_TILE + p;
         const int ci = ci_raw < count ? ci_raw : count - 1;
         const int64_t n = list[ci];
-        float P[3], D[3];
-        kpn_get_point(ps, n, P, D);
 
-        // ---- pooling-weight normaliser (model.py:759; mask == 1 in every view for listed points) ----
+        // ---- pooled mean / var over views of the 64-vector (utils.py:731-748).  Pooling weights
+        //      (model.py:752-759; mask == 1 in every view for listed points) come with the gather records. ----
+        const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         float pwsum = 0.0f;
-        for (int v = 0; v < V; ++v)
-            pwsum = KADD(pwsum, kpn_pix_weight(kpn_project(sc.table + (size_t)v * KPN_TBL_STRIDE, P[0], P[1], P[2], sc)));
-        // ---- pooled mean / var over views of the 64-vector (utils.py:731-748), two passes ----
+        for (int v = 0; v < V; ++v) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
 #pragma unroll
         for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
-                const kpn_proj q = kpn_project(sc.table + (size_t)v * KPN_TBL_STRIDE, P[0], P[1], P[2], sc);
-                const float pw = kpn_pix_weight(q) / KADD(pwsum, 1e-6f);
-                const float4* src = reinterpret_cast<const float4*>(xscr) + ((size_t)(t * V + v) * 8) * 64 + lane;
+                const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
+                const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x = src[q4 * 64];
+                    const float4 x = src[q4 * 64 + lane];
                     const float xe[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
 #pragma unroll
             for (int v = 0; v < VC; ++v)
                 if (v < V) {
-                    kpn_gather_view(sc, v, h, P, D, gv[v]);
+                    kpn_gather_view(xscr, t, V, v, lane, h, gv[v]);
                     kpn_encode_view(wl, lane, h, gv[v], lat0, ivs[v]);
                     emin = fminf(emin, kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))));
                 }
@@ -395,10 +410,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         } else {
             for (int pass = 0; pass < 2; ++pass)
                 for (int v = 0; v < V; ++v) {
-                    const float* cp = sc.table + (size_t)v * KPN_TBL_STRIDE + KPN_TBL_CPOS;
-                    float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
-                    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-                    const float dot = kpn_dot3(cr[0] / nrm, cr[1] / nrm, cr[2] / nrm, D[0], D[1], D[2]);
+                    const float dot = rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w;
                     const float e = kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f)));
                     if (pass == 0) emin = fminf(emin, e); else esum = KADD(esum, KSUB(e, emin));
                 }
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                 for (int v = 0; v < VC; ++v) if (v < V) stats(pass, gv[v], ivs[v]);
             } else {
                 for (int v = 0; v < V; ++v) {
-                    kpn_gather_view(sc, v, h, P, D, gv[0]);
+                    kpn_gather_view(xscr, t, V, v, lane, h, gv[0]);
                     kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
                     stats(pass, gv[0], ivs[0]);
                 }
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             for (int v = 0; v < VC; ++v) if (v < V) head(gv[v], ivs[v]);
         } else {
             for (int v = 0; v < V; ++v) {
-                kpn_gather_view(sc, v, h, P, D, gv[0]);
+                kpn_gather_view(xscr, t, V, v, lane, h, gv[0]);
                 kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
                 head(gv[0], ivs[0]);
             }

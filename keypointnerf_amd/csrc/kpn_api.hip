@@ -287,7 +287,7 @@ QueryLayout query_layout(int64_t N, int V) {
     L.count = o; o += 256;
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
-    L.xscr = o; o += align_up(ntiles * (size_t)V * 8 * 64 * sizeof(float4), 256);
+    L.xscr = o; o += align_up(ntiles * (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4), 256);
     L.total = o;
     return L;
 }
@@ -463,7 +463,10 @@ extern "C" int kpn_render_rays(const kpn_scene_desc* d, const void* scene_ws, co
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
         if (a->alpha) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha);
         if (a->fine) {
-            KPN_LAUNCH(k_fine_samples, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), F(L.zf));
+            if (Sc <= 64 && Sf <= 64)
+                KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), F(L.zf));
+            else
+                KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), F(L.zf));
             kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull};
             if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;  // :1082
             if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;

@@ -109,5 +109,11 @@ constexpr int kpn_packed_floats() { return kpn_row_off(ROW_COUNT); }
 constexpr int kpn_k2_base() { return kpn_seg_woff(SEG_G2_0); }
 constexpr int kpn_k2_floats() { return kpn_packed_floats() - kpn_k2_base(); }
 
+// Row scratch written by k_geo_rows and read by k_fuse_color: per work item (tile, view) KPN_ROW_SLABS
+// slabs of [64 lanes] float4.  Slabs 0..7: the lane's 32 registers of the 64-vector (block b = slab/4);
+// slabs 8,9: the per-(point,view) gather record of the colour head — h=0 lanes hold
+// [r,g,b, pooling weight | ray_diff(3), dot], h=1 lanes hold the 8 texture channels.
+#define KPN_ROW_SLABS 10
+
 // row of the 32x32 D tile held by register r of a lane in half h
 #define KPN_ROWMAP(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

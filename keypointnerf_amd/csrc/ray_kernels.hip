@@ -285,10 +285,12 @@ __global__ __launch_bounds__(64) void k_importance(int64_t R, int Dm2, int n, co
 // z_mid (:1074) and contrib[...,1:-1] (:1075) followed by importance sampling and
 // z_fine = sort(cat[z, z_new]) (:1076).  One thread per ray; z_new is staged in LDS, insertion-sorted
 // (already ascending when u is the uniform linspace), then merged with the coarse z.
+// MAXD: LDS row length (odd: conflict-free column access); 65 serves Sc,Sf <= 64 at 4x the occupancy of 129
+template <int MAXD>
 __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, const float* __restrict__ zc,
                                                      const float* __restrict__ contrib, float* __restrict__ zf) {
-    __shared__ float cdf_s[64][KPN_IS_MAXD];
-    __shared__ float zn_s[64][KPN_IS_MAXD];
+    __shared__ float cdf_s[64][MAXD];
+    __shared__ float zn_s[64][MAXD];
     const int t = threadIdx.x;
     const int64_t r = (int64_t)blockIdx.x * 64 + t;
     if (r >= R) return;
