@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production); gloo + all ranks on cuda:0 only to exercise the N>1 flow on a 1-GPU box")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = size the CPU sample for ~15 s")
     return ap.parse_args()
 
@@ -83,8 +85,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -114,8 +120,13 @@ def main():
         L.check(L.kpn_scene_prepare(ctypes.byref(ps.desc), ctypes.c_void_p(ps.ws.data_ptr()),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         out = ops.render_rays(ps, w, cam_tar, scene["bounds"], plan=plan)
-        if world > 1:
-            dist.all_gather_into_tensor(gather_buf, out["tex_fg_fine"][0])
+        if world > 1:  # the job's only exchange: finished RGB frames (3 MB each)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(gather_buf, out["tex_fg_fine" if fine else "tex_fg"][0])
+            else:
+                host = out["tex_fg_fine" if fine else "tex_fg"][0].cpu()
+                bucket = [torch.empty_like(host) for _ in range(world)]
+                dist.all_gather(bucket, host)
         return out
 
     for i in range(args.warmup):
@@ -134,7 +145,7 @@ def main():
     ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
     L.check(L.kpn_profile_collect(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows)))
     L.check(L.kpn_profile_enable(0))
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -171,7 +182,7 @@ def main():
                          "algorithmic_flop_per_row": flops_row,
                          "kernel_time_share": (ms.value * 1e-3) / dt},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, scene_cpu, sd, fine=fine)
         print(json.dumps(line), flush=True)
     if world > 1:
