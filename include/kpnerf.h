@@ -141,6 +141,20 @@ int kpn_render_rays(const kpn_scene_desc* desc, const void* scene_ws, const floa
                     const kpn_render_args* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * SURVEY.md §8(f) "next" rows on the output side of the path (callers of the renderer).
+ *
+ * kpn_frame_to_rgb8: KeypointNeRFLightningModule._arrange_nerf_images (src/model.py:427-430: clamp to [0,1],
+ * CHW -> HWC) + the uint8 quantisation `(img*255.).astype(np.uint8)` of render_novel_views / save_test_image
+ * (src/model.py:496,504,281) + the channel flip handed to cv2.imwrite (`[:, :, ::-1]`, src/model.py:222,283).
+ * chw (3,H,W) fp32 -> hwc_out (H,W,3) uint8; bgr != 0 writes B,G,R.  Integer result is bit-exact.
+ *
+ * kpn_mse_psnr: ZJUEvaluator.compute_score's mse / _compute_psnr (src/zju_evaluator.py:16-19,63-64):
+ * mse = mean((pred-gt)^2) over all n elements, psnr = -10 ln(mse)/ln(10).  out2 (device, 2 doubles) = [mse, psnr];
+ * partial sums are accumulated in fp64.  scratch: 2048 doubles + 1 int (device, 16,392 bytes). */
+int kpn_frame_to_rgb8(const float* chw, int32_t height, int32_t width, int32_t bgr, uint8_t* hwc_out, void* stream);
+int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2, void* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py).  When enabled, every launch of the dominant kernel (k_geo_rows) is
  * bracketed by HIP events recorded on the caller's stream and the number of (point,view) rows it
  * processed is copied back asynchronously.  kpn_profile_collect synchronises the recorded events

@@ -343,11 +343,12 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     }
 #endif
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
+    static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
     if (sc.V <= 3)  // per-view IBR inputs cached in registers
-        KPN_LAUNCH(k_fuse_color<3>, dim3(fblocks), dim3(512), stream, sc, ps, wp, (const int*)list, (const int*)count,
+        KPN_LAUNCH(k_fuse_color<3>, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count,
                    count + 1, (const float*)xscr, mode, out);
     else
-        KPN_LAUNCH(k_fuse_color<0>, dim3(fblocks), dim3(512), stream, sc, ps, wp, (const int*)list, (const int*)count,
+        KPN_LAUNCH(k_fuse_color<0>, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count,
                    count + 1, (const float*)xscr, mode, out);
     return check_launch("field query");
 }
@@ -477,6 +478,24 @@ extern "C" int kpn_render_rays(const kpn_scene_desc* d, const void* scene_ws, co
         }
     }
     return check_launch("kpn_render_rays");
+}
+
+extern "C" int kpn_frame_to_rgb8(const float* chw, int32_t H, int32_t W, int32_t bgr, uint8_t* hwc_out, void* stream) {
+    KPN_REQUIRE(chw && hwc_out, "null pointer");
+    KPN_REQUIRE(H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "bad frame size");
+    KPN_LAUNCH(k_frame_to_rgb8, grid1d((int64_t)H * W, 256), dim3(256), stream, (int)(H * W), (int)bgr, chw, hwc_out);
+    return check_launch("kpn_frame_to_rgb8");
+}
+extern "C" int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2, void* scratch, void* stream) {
+    KPN_REQUIRE(pred && gt && out2 && scratch, "null pointer");
+    KPN_REQUIRE(n > 0, "empty image");
+    double* partial = static_cast<double*>(scratch);
+    int* ticket = reinterpret_cast<int*>(partial + 2048);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    (void)hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream);
+    KPN_LAUNCH(k_mse_psnr, dim3((unsigned)blocks), dim3(256), stream, n, pred, gt, partial, ticket, out2);
+    return check_launch("kpn_mse_psnr");
 }
 
 extern "C" int kpn_profile_enable(int32_t on) {

@@ -339,3 +339,48 @@ __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, 
         if (j != k) o[j] = v;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Output side: clamp + quantise + CHW->HWC (model.py:427-430,496), MSE/PSNR (zju_evaluator.py:16-19)
+__global__ void k_frame_to_rgb8(int HW, int bgr, const float* __restrict__ chw, uint8_t* __restrict__ hwc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = fminf(fmaxf(chw[(size_t)c * HW + i], 0.0f), 1.0f);
+        hwc[(size_t)i * 3 + (bgr ? 2 - c : c)] = (uint8_t)(int)KMUL(v, 255.0f);  // numpy astype(uint8): truncation
+    }
+}
+
+// grid-stride squared-error sum in fp64; the last workgroup to finish (ticket) folds the partials
+__global__ __launch_bounds__(256) void k_mse_psnr(int64_t n, const float* __restrict__ a, const float* __restrict__ b,
+                                                  double* __restrict__ partial, int* __restrict__ ticket,
+                                                  double* __restrict__ out2) {
+    __shared__ double red[256];
+    __shared__ int last;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = KSUB(a[i], b[i]);
+        acc += (double)KMUL(d, d);  // (pred-gt)**2 is an fp32 op in the reference
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0];
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double tot = 0.0;
+        for (unsigned k = 0; k < gridDim.x; ++k) tot += ((volatile double*)partial)[k];
+        const double mse = tot / (double)n;
+        out2[0] = mse;
+        out2[1] = -10.0 * log(mse) / log(10.0);
+    }
+}

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "kpn_query": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_sz, c_p]),
     "kpn_render_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),
     "kpn_render_rays": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs), c_p, c_sz, c_p]),
+    "kpn_frame_to_rgb8": (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p]),
+    "kpn_mse_psnr": (ctypes.c_int, [c_p, c_p, c_i64, c_p, c_p, c_p]),
     "kpn_flops_per_point": (ctypes.c_double, [c_i32]),
     "kpn_flops_per_row": (ctypes.c_double, []),
     "kpn_profile_enable": (ctypes.c_int, [c_i32]),

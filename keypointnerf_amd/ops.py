@@ -225,6 +225,31 @@ def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=
     return plan.out
 
 
+def frame_to_rgb8(img, bgr=False):
+    """(3,H,W) or (1,3,H,W) fp32 -> (H,W,3) uint8 on the device: clamp to [0,1] (_arrange_nerf_images, reference
+    src/model.py:427-430), x255 and truncate (`.astype(np.uint8)`, :496), optional B,G,R order for cv2.imwrite (:222)."""
+    L = kl.get_library()
+    x = _dev(img, "img")
+    x = x.reshape(3, *x.shape[-2:])
+    H, W = x.shape[-2:]
+    out = torch.empty(H, W, 3, dtype=torch.uint8, device=x.device)
+    L.check(L.kpn_frame_to_rgb8(_p(x), H, W, int(bool(bgr)), _p(out), _stream()))
+    return out
+
+
+def mse_psnr(pred, gt):
+    """ZJUEvaluator.compute_score's mse and psnr (reference src/zju_evaluator.py:16-19,63-64) without leaving the
+    device: returns a (2,) float64 tensor [mse, psnr]."""
+    L = kl.get_library()
+    a, b = _dev(pred, "pred"), _dev(gt, "gt")
+    if a.shape != b.shape:
+        raise ValueError("pred and gt must have the same shape")
+    out = torch.empty(2, dtype=torch.float64, device=a.device)
+    scratch = torch.empty(2048 * 8 + 8, dtype=torch.uint8, device=a.device)
+    L.check(L.kpn_mse_psnr(_p(a), _p(b), a.numel(), _p(out), _p(scratch), _stream()))
+    return out
+
+
 def selftest_mfma():
     """Checks on the device that v_mfma_f32_32x32x2_f32 has the operand/result lane maps the kernels assume."""
     L = kl.get_library()

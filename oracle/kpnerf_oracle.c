@@ -609,3 +609,23 @@ void kpo_render_rays(const kpo_scene* sc, const float* wflat, const float* K, co
     free(dirs); free(nearr); free(farr); free(z); free(pts); free(vw); free(rgba); free(contrib);
     free(sdf_tmp); free(col_tmp); free(dep_tmp); free(alp_tmp);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Output side.
+ * _arrange_nerf_images (model.py:427-430: clamp to [0,1], CHW -> HWC) + `(img*255.).astype(np.uint8)`
+ * (model.py:496,281) + optional `[:, :, ::-1]` for cv2.imwrite (model.py:222,283). */
+void kpo_frame_to_rgb8(const float* chw, int H, int W, int bgr, uint8_t* hwc) {
+    const size_t HW = (size_t)H * W;
+    for (size_t i = 0; i < HW; ++i)
+        for (int c = 0; c < 3; ++c) {
+            float v = fminf(fmaxf(chw[c * HW + i], 0.0f), 1.0f);
+            hwc[i * 3 + (bgr ? 2 - c : c)] = (uint8_t)(int)(v * 255.0f);
+        }
+}
+/* ZJUEvaluator.compute_score mse + _compute_psnr (zju_evaluator.py:16-19,63-64); fp64 accumulation */
+void kpo_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) { float d = pred[i] - gt[i]; acc += (double)(d * d); }
+    out2[0] = acc / (double)n;
+    out2[1] = -10.0 * log(out2[0]) / log(10.0);
+}

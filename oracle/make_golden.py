@@ -130,6 +130,25 @@ def run_tiled_case(net, name, n_views, src_hw, tar_hw, mask, level, Sc, Sf, seed
     print(f"{name}: frame {tuple(out['tex_fg_fine'].shape)} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_output_case(name, seed=9):
+    """Output side: the reference's own frame arrangement / quantisation / PSNR."""
+    rmodel = ref_shim.load_reference()
+    import src.zju_evaluator as rzju
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.rand(1, 3, 24, 20, generator=g) * 1.3 - 0.15          # values outside [0,1] exercise the clamp
+    gt = torch.rand(1, 3, 24, 20, generator=g)
+    hwc = rmodel.KeypointNeRFLightningModule._arrange_nerf_images({"tex_fg_fine": pred}, 2.0, 8.0)  # model.py:427-430
+    rgb8 = (hwc * 255.).astype(np.uint8)                                                              # model.py:496
+    a = pred.clamp(0, 1).squeeze(0).permute(1, 2, 0).numpy()
+    b = gt.squeeze(0).permute(1, 2, 0).numpy()
+    mse = float(np.mean((a - b) ** 2))                                                                # zju_evaluator.py:63
+    psnr = float(rzju.ZJUEvaluator._compute_psnr(a, b))                                               # :16-19
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, pred=_np(pred), gt=_np(gt), hwc=hwc, rgb8=rgb8, bgr8=rgb8[:, :, ::-1].copy(),
+                        mse=np.float64(mse), psnr=np.float64(psnr))
+    print(f"{name}: psnr={psnr:.4f} -> {path}")
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     net = ref_shim.build_reference_net(seed=0)
@@ -145,6 +164,7 @@ def main():
     run_case(net, "case_c_v3_offaxis", 3, (64, 64), (24, 24), "dense", 1, (0, 0), 8, 8, seed=3, tar_angle=95.0)
     # D: full-frame assembly through the reference tile loop + pixel_shuffle
     run_tiled_case(net, "case_d_v3_tiled_frame", 3, (64, 64), (16, 16), "ellipsoid", 3, 8, 8, seed=4)
+    run_output_case("case_e_output")
 
 
 if __name__ == "__main__":

@@ -163,3 +163,18 @@ def render_rays(oscene, wflat, cam_tar, bounds, pix, Sc=64, Sf=64, fine=True, st
                           g(st, "z_f"), g(st, "rgba_c"), g(st, "rgba_f"))
     o.update(st)
     return o
+
+
+def frame_to_rgb8(chw, bgr=False):
+    x = _f32(chw).reshape(3, *np.shape(chw)[-2:])
+    H, W = x.shape[-2:]
+    out = np.empty((H, W, 3), np.uint8)
+    lib().kpo_frame_to_rgb8(_ptr(x), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(int(bgr)), _ptr(out))
+    return out
+
+
+def mse_psnr(pred, gt):
+    a, b = _f32(pred).reshape(-1), _f32(gt).reshape(-1)
+    out = np.empty(2, np.float64)
+    lib().kpo_mse_psnr(_ptr(a), _ptr(b), ctypes.c_int64(a.size), _ptr(out))
+    return out

@@ -188,7 +188,8 @@ static inline kpn_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, k
 }
 
 // ---- atomics / math ----
-static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 // (fast-math intrinsics such as __expf are wrapped by kpn_common.h: glibc owns those names on the host)
 static inline float __fdividef(float a, float b) { return a / b; }

@@ -194,3 +194,23 @@ def test_full_size_properties(ops):
     ps0 = ops.PreparedScene(img0, scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"], scene["src_foreground_mask"])
     z = ops.render_rays(ps0, w, scene["cam_tar"], scene["bounds"], grid=(0, 0, 4, 128, 128))
     assert (z["tex_fg_fine"] == 0).all() and z["alpha_fine"].max() > 0.05
+
+
+def test_output_side(ops):
+    """§8(f) widening: on-device frame quantisation (bit-exact bytes) and MSE/PSNR vs the reference's values."""
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "case_e_output.npz"))
+    pred, gt = torch.from_numpy(g["pred"]).cuda(), torch.from_numpy(g["gt"]).cuda()
+    assert np.array_equal(ops.frame_to_rgb8(pred).cpu().numpy(), g["rgb8"])
+    assert np.array_equal(ops.frame_to_rgb8(pred, bgr=True).cpu().numpy(), g["bgr8"])
+    m = ops.mse_psnr(pred.clamp(0, 1), gt).cpu().numpy()
+    assert abs(m[0] - g["mse"]) < 1e-7 * g["mse"] and abs(m[1] - g["psnr"]) < 1e-5
+    # full-size: 512x512 frame, idempotence + checksum vs torch
+    big = torch.rand(3, 512, 512, device="cuda") * 1.2 - 0.1
+    q = ops.frame_to_rgb8(big)
+    ref = (big.clamp(0, 1) * 255.0).to(torch.uint8).permute(1, 2, 0)
+    assert torch.equal(q, ref)
+    big2 = torch.rand(3, 512, 512, device="cuda")
+    m = ops.mse_psnr(big, big2)
+    assert abs(float(m[0]) - float(((big - big2).double() ** 2).mean())) < 1e-9

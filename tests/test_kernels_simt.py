@@ -90,3 +90,22 @@ def test_render_pipeline_vs_golden(env):
         assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k
     for k in ("depth", "depth_fine", "sdf"):
         np.testing.assert_allclose(o[k], g["out." + k][0], rtol=2e-4, atol=2e-4)
+
+
+def test_output_kernels(env):
+    import ctypes
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    lib = env[0]
+    g = np.load(os.path.join(GOLDEN_DIR, "case_e_output.npz"))
+    pred, gt = sh.f32(g["pred"]), sh.f32(g["gt"])
+    H, W = pred.shape[-2:]
+    for bgr, key in ((0, "rgb8"), (1, "bgr8")):
+        out = np.zeros((H, W, 3), np.uint8)
+        lib.check(lib.kpn_frame_to_rgb8(sh.ptr(pred), H, W, bgr, sh.ptr(out), None))
+        assert np.array_equal(out, g[key])
+    a = np.ascontiguousarray(np.clip(pred, 0, 1))
+    out2, scratch = np.zeros(2, np.float64), np.zeros(2048 * 8 + 8, np.uint8)
+    lib.check(lib.kpn_mse_psnr(sh.ptr(a), sh.ptr(gt), a.size, sh.ptr(out2), sh.ptr(scratch), None))
+    assert abs(out2[0] - g["mse"]) < 1e-7 * g["mse"] and abs(out2[1] - g["psnr"]) < 1e-5
+    assert np.allclose(out2, oracle.mse_psnr(a, gt), rtol=1e-12)

@@ -111,3 +111,14 @@ def test_full_frame_equals_tiles(wflat):
     assert np.abs(o["tex_fg_fine"].reshape(H, W, 3).transpose(2, 0, 1) - g["out.tex_fg_fine"]).max() < 2e-5
     assert np.abs(o["alpha_fine"].reshape(1, H, W) - g["out.alpha_fine"]).max() < 2e-5
     assert np.abs(o["tex_fg"].reshape(H, W, 3).transpose(2, 0, 1) - g["out.tex_fg"]).max() < 2e-5
+
+
+def test_output_side_vs_golden():
+    """frame arrangement/quantisation and MSE/PSNR of the reference's driver/evaluator."""
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "case_e_output.npz"))
+    assert np.array_equal(oracle.frame_to_rgb8(g["pred"]), g["rgb8"])            # bit-exact bytes
+    assert np.array_equal(oracle.frame_to_rgb8(g["pred"], bgr=True), g["bgr8"])
+    m = oracle.mse_psnr(np.clip(g["pred"], 0, 1), g["gt"])
+    assert abs(m[0] - g["mse"]) < 1e-7 * g["mse"] + 1e-12 and abs(m[1] - g["psnr"]) < 1e-5
