@@ -162,6 +162,25 @@ int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2, vo
 int kpn_profile_enable(int32_t on);
 int kpn_profile_collect(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host);
 
+/* TRAIN branch of batch_render_pifu_nerf (forward only), every random draw supplied by the caller so that it can
+ * be the reference's own: src/model.py:1008-1017 (patch pixels), :1049-1053 (stratified jitter), :993-994 (density
+ * noise, coarse and fine eval), :742-748 (per-view dropout of the coarse and of the fine query), :1129 (random
+ * importance samples).  `args` as for kpn_render_rays with nx*ny = n rays (x0,y0,step unused); outputs are (C,ny,nx)
+ * planar in patch order.  Backward is not implemented yet. */
+typedef struct kpn_train_args {
+    const int32_t* pix;          /* (R,2) target pixels (x,y) */
+    const float* u_coarse;       /* (R,Sc)        th.rand_like(z) */
+    const float* noise_coarse;   /* (R*Sc)        th.randn_like(rad) of the coarse eval_func; NULL iff std == 0 */
+    const float* noise_fine;     /* (R*(Sc+Sf))   ... of the fine eval_func */
+    const float* u_fine;         /* (R,Sf)        th.rand of importance_sample */
+    uint32_t keep_coarse;        /* bit v = source view v kept by the coarse query's dropout */
+    uint32_t keep_fine;          /* ... by the fine query's dropout */
+    float rand_noise_std;        /* dr_kwargs.rand_noise_std (0.01) */
+} kpn_train_args;
+int kpn_render_rays_train(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
+                          const kpn_render_args* args, const kpn_train_args* train, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* FLOP / byte model of one field evaluation, for roofline reporting */
 double kpn_flops_per_point(int32_t n_views);
 /* algorithmic FLOPs of one k_geo_rows row = 2 * 70,080 MACs (MLPUNet layers1) */

@@ -24,6 +24,9 @@ struct kpn_points {
     const float* dirs;
     const float* z;
     int S;
+    // train-time density noise of eval_func (model.py:993-994): rad += noise[n] * noise_std; NULL in eval
+    const float* noise;
+    float noise_std;
 };
 __device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, float (&P)[3], float (&D)[3]) {
     if (ps.pts) {
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
             if (!sc.disable_fg_mask) all_fg &= (s.w > 0.1f);  // model.py:737-739
             acc[0] = KADD(acc[0], KMUL(s.x, pu)); acc[1] = KADD(acc[1], KMUL(s.y, pu)); acc[2] = KADD(acc[2], KMUL(s.z, pu));
         }
-        is_valid = all_in && all_fg;
+        // a_v = in_v * all(fg) * all(in) * dropout_v (model.py:739,748); valid = sum_v a_v > 0 (utils.py:643-646)
+        is_valid = all_in && all_fg && ((sc.keep & ((1u << sc.V) - 1u)) != 0u);
         if (valid) valid[n] = (uint8_t)is_valid;
         if (!is_valid) {
             // every view masked: pooled features are exactly 0 and the IBR softmax is uniform, so the
@@ -92,6 +96,30 @@ __device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
         w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
     }
     return KMUL(KMUL(w3[0], w3[1]), w3[2]);
+}
+
+// the colour head's per-(point,view) gather record (query_color, model.py:806-832): h=0 lanes [r,g,b, pooling
+// weight | ray_diff direction(3), dot], h=1 lanes the 8 texture channels (model.py:818)
+__device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, int h,
+                                               const kpn_proj& q, const float (&P)[3], const float (&D)[3], float4& rec0,
+                                               float4& rec1) {
+    if (h == 0) {
+        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
+        rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
+        const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
+        float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+        const float r0 = KSUB(D[0], cr[0]), r1 = KSUB(D[1], cr[1]), r2 = KSUB(D[2], cr[2]);
+        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
+        rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
+    } else {
+        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+        rec0 = kpn_tap4(tx, 8, 0, tt);
+        rec1 = kpn_tap4(tx, 8, 4, tt);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -136,6 +164,18 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         kpn_get_point(ps, n, P, D);
         const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
         const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+        if (!((sc.keep >> v) & 1u)) {
+            // view switched off by the train-time dropout: its pooling / blend weights are 0, only the record
+            // (the blend-weight minimum runs over ALL views, model.py:1288) is needed
+            float4 rec0, rec1;
+            kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
+            float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[8 * 64] = rec0;
+            dst[9 * 64] = rec1;
+            continue;
+        }
 
         // Activations are applied lazily: layer L+1 takes softplus(acc_L[...]) group by group as its B
         // operands, so the transcendental work interleaves with the MFMAs instead of forming a
@@ -211,29 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a2[g / 4][(g % 4) * 4 + i]);
-                if constexpr (g == 2) {
-                    if (h == 0) {  // [r,g,b, pooling weight]
-                        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
-                        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
-                        rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
-                    } else {       // texture channels (model.py:818)
-                        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
-                        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
-                        rec0 = kpn_tap4(tx, 8, 0, tt);
-                        rec1 = kpn_tap4(tx, 8, 4, tt);
-                    }
-                }
-                if constexpr (g == 6) {
-                    if (h == 0) {  // [ray_diff direction(3), dot]  (model.py:823-832)
-                        const float* cp = tb + KPN_TBL_CPOS;
-                        float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
-                        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-                        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
-                        const float r0 = KSUB(D[0], cr[0]), r1 = KSUB(D[1], cr[1]), r2 = KSUB(D[2], cr[2]);
-                        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
-                        rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
-                    }
-                }
+                if constexpr (g == 2) kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
             }, acc);
             float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
 #pragma unroll
@@ -340,13 +358,16 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         // ---- pooled mean / var over views of the 64-vector (utils.py:731-748).  Pooling weights
         //      (model.py:752-759; mask == 1 in every view for listed points) come with the gather records. ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
+        const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
         float pwsum = 0.0f;
-        for (int v = 0; v < V; ++v) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
+        for (int v = 0; v < V; ++v)
+            if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
 #pragma unroll
         for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
+                if (!((keep >> v) & 1u)) continue;
                 const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
                 const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
 #pragma unroll
@@ -401,18 +422,19 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             for (int v = 0; v < VC; ++v)
                 if (v < V) {
                     kpn_gather_view(xscr, t, V, v, lane, h, gv[v]);
-                    kpn_encode_view(wl, lane, h, gv[v], lat0, ivs[v]);
-                    emin = fminf(emin, kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))));
+                    if ((keep >> v) & 1u) kpn_encode_view(wl, lane, h, gv[v], lat0, ivs[v]);
+                    emin = fminf(emin, kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))));  // min over ALL views (:1288)
                 }
 #pragma unroll
             for (int v = 0; v < VC; ++v)
-                if (v < V) esum = KADD(esum, KSUB(kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))), emin));
+                if (v < V && ((keep >> v) & 1u)) esum = KADD(esum, KSUB(kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))), emin));
         } else {
             for (int pass = 0; pass < 2; ++pass)
                 for (int v = 0; v < V; ++v) {
                     const float dot = rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w;
                     const float e = kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f)));
-                    if (pass == 0) emin = fminf(emin, e); else esum = KADD(esum, KSUB(e, emin));
+                    if (pass == 0) emin = fminf(emin, e);
+                    else if ((keep >> v) & 1u) esum = KADD(esum, KSUB(e, emin));
                 }
         }
         // fused mean/var over views of x' (utils.py:91-95): K-steps mean' (16 + 3 + pad), var' (16 + 3 + pad)
@@ -431,9 +453,10 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         for (int pass = 0; pass < 2; ++pass) {
             if constexpr (VC > 0) {
 #pragma unroll
-                for (int v = 0; v < VC; ++v) if (v < V) stats(pass, gv[v], ivs[v]);
+                for (int v = 0; v < VC; ++v) if (v < V && ((keep >> v) & 1u)) stats(pass, gv[v], ivs[v]);
             } else {
                 for (int v = 0; v < V; ++v) {
+                    if (!((keep >> v) & 1u)) continue;
                     kpn_gather_view(xscr, t, V, v, lane, h, gv[0]);
                     kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
                     stats(pass, gv[0], ivs[0]);
@@ -507,9 +530,10 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         };
         if constexpr (VC > 0) {
 #pragma unroll
-            for (int v = 0; v < VC; ++v) if (v < V) head(gv[v], ivs[v]);
+            for (int v = 0; v < VC; ++v) if (v < V && ((keep >> v) & 1u)) head(gv[v], ivs[v]);
         } else {
             for (int v = 0; v < V; ++v) {
+                if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
                 kpn_gather_view(xscr, t, V, v, lane, h, gv[0]);
                 kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
                 head(gv[0], ivs[0]);
@@ -517,7 +541,10 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         }
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;
-            if (mode == 1) { o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw; }  // eval_func with mask = 1
+            if (mode == 1) {  // eval_func with mask = 1 (model.py:981-996)
+                if (ps.noise) rad = KADD(rad, KMUL(ps.noise[n], ps.noise_std));
+                o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw;
+            }
             else { o[0] = sdf_raw; o[1] = rad; }
             o[2] = c0 / lden; o[3] = c1 / lden; o[4] = c2 / lden;
         }

@@ -208,6 +208,7 @@ kpn_scene_dev scene_dev(const kpn_scene_desc* d, const void* ws) {
     s.disable_fg_mask = d->disable_fg_mask;
     s.znear = d->znear; s.zfar = d->zfar; s.nml_scale = d->nml_scale;
     s.two_sigma2 = (float)(2.0 * ((double)d->sigma * (double)d->sigma));  // spatial.py:114
+    s.keep = 0xFFFFFFFFu;
     s.table = base + L.table; s.rgbm = base + L.rgbm; s.geo0 = base + L.geo0; s.geo1 = base + L.geo1; s.tex = base + L.tex;
     return s;
 }
@@ -252,7 +253,7 @@ extern "C" int kpn_make_rays(const float* K, const float* RT, float znear, float
     KPN_REQUIRE(K && RT && bounds && dirs && cam_pos && near_o && far_o, "null pointer");
     KPN_REQUIRE(nx > 0 && ny > 0 && step > 0, "bad pixel grid");
     KPN_LAUNCH(k_make_rays, grid1d((int64_t)nx * ny, 256), dim3(256), stream, K, RT, znear, zfar, bounds, (int)x0, (int)y0,
-               (int)step, (int)nx, (int)ny, dirs, cam_pos, near_o, far_o);
+               (int)step, (int)nx, (int)ny, (const int*)nullptr, dirs, cam_pos, near_o, far_o);
     return check_launch("kpn_make_rays");
 }
 
@@ -438,37 +439,52 @@ extern "C" size_t kpn_render_workspace_bytes(const kpn_scene_desc* d, const kpn_
     return render_layout(d, a).total;
 }
 
-extern "C" int kpn_render_rays(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
-                               void* ws, size_t ws_bytes, void* stream) {
+// shared implementation: t == nullptr -> eval branch (model.py:1019-1022, uniform=True); otherwise the train
+// branch with explicit random draws
+static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
+                       const kpn_train_args* t, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
     if (int e = check_render(a)) return e;
     KPN_REQUIRE(scene_ws && wp && ws, "null pointer");
+    if (t) {
+        KPN_REQUIRE(t->pix && t->u_coarse, "train args: pix and u_coarse are required");
+        KPN_REQUIRE(!a->fine || t->u_fine, "train args: u_fine is required when fine");
+        KPN_REQUIRE(t->rand_noise_std == 0.0f || (t->noise_coarse && (!a->fine || t->noise_fine)), "train args: noise tensors missing");
+        KPN_REQUIRE((t->keep_coarse & ((1u << d->n_views) - 1u)) && (t->keep_fine & ((1u << d->n_views) - 1u)),
+                    "train args: view dropout must keep at least one view (reference src/model.py:744)");
+    }
     const RenderLayout L = render_layout(d, a);
     if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "render workspace too small");
     char* base = static_cast<char*>(ws);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
-    const kpn_scene_dev sc = scene_dev(d, scene_ws);
+    kpn_scene_dev sc = scene_dev(d, scene_ws);
     const int64_t R = (int64_t)a->nx * a->ny;
     const int Sc = a->n_coarse, Sf = a->fine ? a->n_fine : 0, Sfull = Sc + Sf;
     KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
-               (int)a->step, (int)a->nx, (int)a->ny, F(L.dirs), F(L.cam_pos), F(L.nearv), F(L.farv));
+               (int)a->step, (int)a->nx, (int)a->ny, t ? (const int*)t->pix : (const int*)nullptr, F(L.dirs), F(L.cam_pos),
+               F(L.nearv), F(L.farv));
     for (int64_t r0 = 0; r0 < R; r0 += L.chunk) {
         const int64_t n = (R - r0) < L.chunk ? (R - r0) : L.chunk;
         const float* dirs = F(L.dirs) + r0 * 3;
         KPN_LAUNCH(k_coarse_z, grid1d(n * Sc, 256), dim3(256), stream, n, Sc, (const float*)(F(L.nearv) + r0),
-                   (const float*)(F(L.farv) + r0), F(L.zc));
-        kpn_points ps{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc};
+                   (const float*)(F(L.farv) + r0), t ? t->u_coarse + r0 * Sc : (const float*)nullptr, F(L.zc));
+        kpn_points ps{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc,
+                      (t && t->rand_noise_std != 0.0f) ? t->noise_coarse + r0 * Sc : nullptr, t ? t->rand_noise_std : 0.0f};
+        sc.keep = t ? t->keep_coarse : 0xFFFFFFFFu;
         if (int e = run_field(sc, ps, wp, n * Sc, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;   // model.py:1062
         if (int e = kpn_rgba2out(F(L.rgba), F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
         if (a->alpha) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha);
         if (a->fine) {
+            const float* uf = t ? t->u_fine + r0 * Sf : (const float*)nullptr;
             if (Sc <= 64 && Sf <= 64)
-                KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), F(L.zf));
+                KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf));
             else
-                KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), F(L.zf));
-            kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull};
+                KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf));
+            kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
+                          (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
+            sc.keep = t ? t->keep_fine : 0xFFFFFFFFu;
             if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;  // :1082
             if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);
@@ -478,6 +494,16 @@ extern "C" int kpn_render_rays(const kpn_scene_desc* d, const void* scene_ws, co
         }
     }
     return check_launch("kpn_render_rays");
+}
+
+extern "C" int kpn_render_rays(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
+                               void* ws, size_t ws_bytes, void* stream) {
+    return render_impl(d, scene_ws, wp, a, nullptr, ws, ws_bytes, stream);
+}
+extern "C" int kpn_render_rays_train(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
+                                     const kpn_train_args* t, void* ws, size_t ws_bytes, void* stream) {
+    KPN_REQUIRE(t != nullptr, "train args null");
+    return render_impl(d, scene_ws, wp, a, t, ws, ws_bytes, stream);
 }
 
 extern "C" int kpn_frame_to_rgb8(const float* chw, int32_t H, int32_t W, int32_t bgr, uint8_t* hwc_out, void* stream) {

@@ -53,6 +53,7 @@ __device__ __forceinline__ float kpn_fast_exp(float x) { return kpn_exp2(x * 1.4
 struct kpn_scene_dev {
     int32_t V, H, W, g0h, g0w, g1h, g1w, th, tw, disable_fg_mask;
     float znear, zfar, nml_scale, two_sigma2;
+    uint32_t keep;  // bit v = 0: source view v switched off by train-time view dropout (model.py:742-748); eval: all ones
     const float* table;
     const float* rgbm;
     const float* geo0;

@@ -122,8 +122,8 @@ __global__ void k_ray_bbox(int64_t R, const float* __restrict__ bounds, const fl
 // model.py:1026-1043 for the pixel grid px = x0+ix*step, py = y0+iy*step
 __global__ void k_make_rays(const float* __restrict__ K, const float* __restrict__ RT, float znear, float zfar,
                             const float* __restrict__ bounds, int x0, int y0, int step, int nx, int ny,
-                            float* __restrict__ dirs, float* __restrict__ cam_pos, float* __restrict__ near_o,
-                            float* __restrict__ far_o) {
+                            const int* __restrict__ pix, float* __restrict__ dirs, float* __restrict__ cam_pos,
+                            float* __restrict__ near_o, float* __restrict__ far_o) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t R = (int64_t)nx * ny;
     // inverse of K[:3,:3] by cofactors in double (the reference calls th.inverse, model.py:1031)
@@ -140,7 +140,9 @@ __global__ void k_make_rays(const float* __restrict__ K, const float* __restrict
     if (r == 0) { cam_pos[0] = cp[0]; cam_pos[1] = cp[1]; cam_pos[2] = cp[2]; }
     if (r >= R) return;
     const int iy = (int)(r / nx), ix = (int)(r - (int64_t)iy * nx);
-    const float gx = (float)(x0 + ix * step), gy = (float)(y0 + iy * step), gz = 1.0f;
+    // eval: strided grid (model.py:1019-1022); train: explicit patch pixels (x,y) (model.py:1008-1017)
+    const float gx = pix ? (float)pix[r * 2 + 0] : (float)(x0 + ix * step);
+    const float gy = pix ? (float)pix[r * 2 + 1] : (float)(y0 + iy * step), gz = 1.0f;
     float cr[3], cn[3], cf[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -172,13 +174,21 @@ __device__ __forceinline__ float kpn_linspace01(int i, int steps) {
 }
 
 // z = near + (far-near)*linspace  (model.py:1045,1055)
+// u != NULL: stratified jitter of the train branch (model.py:1049-1053): t = lower + u*(upper-lower) with
+// lower = cat[t[:1], t_mid], upper = cat[t_mid, t[-1:]]
 __global__ void k_coarse_z(int64_t R, int S, const float* __restrict__ near_i, const float* __restrict__ far_i,
-                           float* __restrict__ z) {
+                           const float* __restrict__ u, float* __restrict__ z) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * S) return;
     const int64_t r = i / S;
     const int s = (int)(i - r * S);
-    z[i] = KADD(near_i[r], KMUL(KSUB(far_i[r], near_i[r]), kpn_linspace01(s, S)));
+    float t = kpn_linspace01(s, S);
+    if (u) {
+        const float lo = (s == 0) ? t : KMUL(0.5f, KADD(t, kpn_linspace01(s - 1, S)));
+        const float hi = (s == S - 1) ? t : KMUL(0.5f, KADD(kpn_linspace01(s + 1, S), t));
+        t = KADD(lo, KMUL(u[i], KSUB(hi, lo)));
+    }
+    z[i] = KADD(near_i[r], KMUL(KSUB(far_i[r], near_i[r]), t));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,7 +298,8 @@ __global__ __launch_bounds__(64) void k_importance(int64_t R, int Dm2, int n, co
 // MAXD: LDS row length (odd: conflict-free column access); 65 serves Sc,Sf <= 64 at 4x the occupancy of 129
 template <int MAXD>
 __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, const float* __restrict__ zc,
-                                                     const float* __restrict__ contrib, float* __restrict__ zf) {
+                                                     const float* __restrict__ contrib, const float* __restrict__ u,
+                                                     float* __restrict__ zf) {
     __shared__ float cdf_s[64][MAXD];
     __shared__ float zn_s[64][MAXD];
     const int t = threadIdx.x;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, 
         cdf_s[t][i + 1] = run;
     }
     for (int k = 0; k < Sf; ++k) {
-        const float s = kpn_linspace01(k, Sf);
+        const float s = u ? u[r * Sf + k] : kpn_linspace01(k, Sf);  // train: th.rand (:1129); eval: linspace (:1126)
         int lo = 0, hi = C;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;

@@ -41,6 +41,12 @@ class RenderArgs(ctypes.Structure):
                [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")]
 
 
+class TrainArgs(ctypes.Structure):
+    """struct kpn_train_args"""
+    _fields_ = [(n, c_p) for n in ("pix", "u_coarse", "noise_coarse", "noise_fine", "u_fine")] + \
+               [("keep_coarse", ctypes.c_uint32), ("keep_fine", ctypes.c_uint32), ("rand_noise_std", c_f)]
+
+
 # name -> (restype, argtypes); mirrors include/kpnerf.h one to one
 _SIGNATURES = {
     "kpn_abi_version": (ctypes.c_int, []),
@@ -59,6 +65,8 @@ _SIGNATURES = {
     "kpn_query": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_sz, c_p]),
     "kpn_render_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),
     "kpn_render_rays": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs), c_p, c_sz, c_p]),
+    "kpn_render_rays_train": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs),
+                                             ctypes.POINTER(TrainArgs), c_p, c_sz, c_p]),
     "kpn_frame_to_rgb8": (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_p, c_p]),
     "kpn_mse_psnr": (ctypes.c_int, [c_p, c_p, c_i64, c_p, c_p, c_p]),
     "kpn_flops_per_point": (ctypes.c_double, [c_i32]),

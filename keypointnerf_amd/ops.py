@@ -225,6 +225,37 @@ def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=
     return plan.out
 
 
+def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, keep_coarse, keep_fine, noise_coarse=None,
+                      noise_fine=None, rand_noise_std=0.0, n_coarse=64, n_fine=64, chunk_rays=0):
+    """TRAIN branch of batch_render_pifu_nerf, forward only, with the random draws passed in (reference
+    src/model.py:1008-1017,1049-1053,993-994,742-748,1129): pix (R,2) int32 patch pixels (x,y); u_coarse (R,Sc);
+    u_fine (R,Sf); keep_* = (V,) 0/1 view-dropout vectors (or bit masks) of the coarse / fine query; noise_* flat
+    density noise.  Returns the out dict with (1,3,R) / (1,R) tensors in patch order (reshape to (out_h,out_w))."""
+    L = kl.get_library()
+    px = pix.to(torch.int32).contiguous()
+    if not px.is_cuda:
+        raise RuntimeError("pix must live on the GPU")
+    R = px.shape[0]
+    plan = RenderPlan(scene, (0, 0, 1, R, 1), n_coarse, n_fine, fine=True, chunk_rays=chunk_rays)
+    K, RT, b = _dev(cam_tar["K"], "cam_tar['K']").reshape(4, 4), _dev(cam_tar["RT"], "cam_tar['RT']").reshape(4, 4), _dev(bounds, "bounds").reshape(2, 3)
+    a = plan.args
+    a.K, a.RT, a.bounds = K.data_ptr(), RT.data_ptr(), b.data_ptr()
+    a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    bits = lambda k: int(k) if isinstance(k, int) else int(sum(1 << i for i, x in enumerate(k.reshape(-1).tolist()) if x > 0.5))
+    uc, uf = _dev(u_coarse, "u_coarse").reshape(R, n_coarse), _dev(u_fine, "u_fine").reshape(R, n_fine)
+    nc = _dev(noise_coarse, "noise_coarse").reshape(-1) if noise_coarse is not None else None
+    nf = _dev(noise_fine, "noise_fine").reshape(-1) if noise_fine is not None else None
+    t = kl.TrainArgs()
+    t.pix, t.u_coarse, t.u_fine = px.data_ptr(), uc.data_ptr(), uf.data_ptr()
+    t.noise_coarse = nc.data_ptr() if nc is not None else None
+    t.noise_fine = nf.data_ptr() if nf is not None else None
+    t.keep_coarse, t.keep_fine, t.rand_noise_std = bits(keep_coarse), bits(keep_fine), float(rand_noise_std)
+    L.check(L.kpn_render_rays_train(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
+                                    _p(plan.ws), plan.nbytes, _stream()))
+    torch.cuda.current_stream().synchronize()  # the small argument tensors above must outlive the launches
+    return {k: v.reshape(1, *v.shape[1:-2], R) if v.dim() == 4 else v.reshape(1, R) for k, v in plan.out.items()}
+
+
 def frame_to_rgb8(img, bgr=False):
     """(3,H,W) or (1,3,H,W) fp32 -> (H,W,3) uint8 on the device: clamp to [0,1] (_arrange_nerf_images, reference
     src/model.py:427-430), x255 and truncate (`.astype(np.uint8)`, :496), optional B,G,R order for cv2.imwrite (:222)."""

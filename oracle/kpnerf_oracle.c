@@ -232,8 +232,11 @@ static void ibr_head(const kpo_weights* wt, int V, const float (*rgb_feat)[35], 
  * pts (N,3), view (N,3) -> out (N,5) = [sdf_raw, rad, r, g, b], valid (N) in {0,1}.
  * If apply_eval_func != 0 the eval_func closure (model.py:978-997, rand_noise_std = 0) is applied:
  * out = [mask*relu(rad), mask*sdf_raw + (1-mask)*(0.1/nml_scale), r, g, b]. */
-void kpo_query(const kpo_scene* sc, const float* wflat, int64_t N, const float* pts, const float* view,
-               int apply_eval_func, float* out, uint8_t* valid) {
+/* keep: bit v = 1 unless source view v is switched off by the train-time view dropout (model.py:742-748: a
+ * (B,V,1,1) 0/1 tensor multiplied into out_mask); eval = all ones.  noise (N) / noise_std: the density noise
+ * `rad += randn_like(rad) * rand_noise_std` of eval_func (model.py:993-994); NULL / 0 in eval. */
+void kpo_query_ex(const kpo_scene* sc, const float* wflat, int64_t N, const float* pts, const float* view,
+                  int apply_eval_func, uint32_t keep, const float* noise, float noise_std, float* out, uint8_t* valid) {
     kpo_weights wt;
     kpo_bind_weights(wflat, &wt);
     const int V = sc->V;
@@ -291,7 +294,7 @@ void kpo_query(const kpo_scene* sc, const float* wflat, int64_t N, const float* 
         }
         float asum = 0.0f, pwsum = 0.0f;
         for (int v = 0; v < V; ++v) {
-            a[v] = (float)(in_v[v] && all_in && all_fg);                         /* :735 / :739 */
+            a[v] = (float)(in_v[v] && all_in && all_fg) * (float)((keep >> v) & 1u); /* :735 / :739, dropout :748 */
             asum += a[v];
             /* boundary-smooth view weight :752-759 */
             float c3[3] = {0.5f * xn[v] + 0.5f, 0.5f * yn[v] + 0.5f, 0.5f * zn[v] + 0.5f};
@@ -391,6 +394,7 @@ void kpo_query(const kpo_scene* sc, const float* wflat, int64_t N, const float* 
         }
         if (apply_eval_func) { /* model.py:981-997 */
             float mask = (float)is_valid;
+            if (noise) rad += noise[n] * noise_std;                               /* :993-994 */
             o[0] = mask * fmaxf(rad, 0.0f);
             o[1] = mask * sdf_raw + (1.0f - mask) * (0.1f / sc->nml_scale);
         } else {
@@ -398,6 +402,11 @@ void kpo_query(const kpo_scene* sc, const float* wflat, int64_t N, const float* 
         }
         o[2] = rgb[0]; o[3] = rgb[1]; o[4] = rgb[2];
     }
+}
+
+void kpo_query(const kpo_scene* sc, const float* wflat, int64_t N, const float* pts, const float* view,
+               int apply_eval_func, float* out, uint8_t* valid) {
+    kpo_query_ex(sc, wflat, N, pts, view, apply_eval_func, 0xFFFFFFFFu, NULL, 0.0f, out, valid);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -608,6 +617,73 @@ void kpo_render_rays(const kpo_scene* sc, const float* wflat, const float* K, co
     }
     free(dirs); free(nearr); free(farr); free(z); free(pts); free(vw); free(rgba); free(contrib);
     free(sdf_tmp); free(col_tmp); free(dep_tmp); free(alp_tmp);
+}
+
+/* batch_render_pifu_nerf, TRAIN branch (model.py:1008-1017, 1049-1053, 993-994, 742-748, 1129) with every random
+ * draw supplied explicitly: pix (R,2) the patch pixels, u_c (R,Sc) stratified jitter, noise_c (R*Sc) / noise_f
+ * (R*(Sc+Sf)) density noise, u_f (R,Sf) importance samples, keep_c / keep_f view-dropout bit masks of the coarse
+ * and the fine query.  Outputs as kpo_render_rays. */
+void kpo_render_rays_train(const kpo_scene* sc, const float* wflat, const float* K, const float* RT, float znear,
+                           float zfar, const float* bounds, int64_t R, const int32_t* pix, int Sc, int Sf,
+                           const float* u_c, const float* noise_c, const float* noise_f, const float* u_f,
+                           uint32_t keep_c, uint32_t keep_f, float noise_std, float* tex_fg, float* depth, float* alpha,
+                           float* tex_fg_fine, float* depth_fine, float* alpha_fine, float* sdf_out, float* z_c_out,
+                           float* z_f_out) {
+    float* dirs = (float*)malloc(sizeof(float) * R * 3);
+    float* nearr = (float*)malloc(sizeof(float) * R);
+    float* farr = (float*)malloc(sizeof(float) * R);
+    float cam_pos[3];
+    kpo_make_rays(K, RT, znear, zfar, bounds, R, pix, dirs, cam_pos, nearr, farr);
+    const int Sfull = Sc + Sf;
+    float* z = (float*)malloc(sizeof(float) * R * Sc);
+    float* pts = (float*)malloc(sizeof(float) * R * Sfull * 3);
+    float* vw = (float*)malloc(sizeof(float) * R * Sfull * 3);
+    float* rgba = (float*)malloc(sizeof(float) * R * Sfull * 5);
+    float* contrib = (float*)malloc(sizeof(float) * R * Sfull);
+    for (int64_t r = 0; r < R; ++r)
+        for (int i = 0; i < Sc; ++i) {
+            /* z_lower = cat[z[:1], z_mid], z_upper = cat[z_mid, z[-1:]] on linspace(0,1,Sc)  :1045-1052 */
+            float t0 = linspace01(i, Sc);
+            float lo = (i == 0) ? t0 : 0.5f * (t0 + linspace01(i - 1, Sc));
+            float hi = (i == Sc - 1) ? t0 : 0.5f * (linspace01(i + 1, Sc) + t0);
+            float t = lo + u_c[r * Sc + i] * (hi - lo);
+            float zz = nearr[r] + (farr[r] - nearr[r]) * t;                       /* :1053 */
+            z[r * Sc + i] = zz;
+            for (int k = 0; k < 3; ++k) {
+                pts[(r * Sc + i) * 3 + k] = cam_pos[k] + dirs[r * 3 + k] * zz;
+                vw[(r * Sc + i) * 3 + k] = dirs[r * 3 + k];
+            }
+        }
+    kpo_query_ex(sc, wflat, R * Sc, pts, vw, 1, keep_c, noise_c, noise_std, rgba, NULL);
+    float* sdf_tmp = (float*)malloc(sizeof(float) * R);
+    kpo_rgba2out(rgba, z, R, Sc, tex_fg, depth, alpha, contrib, sdf_tmp);
+    if (z_c_out) memcpy(z_c_out, z, sizeof(float) * R * Sc);
+    {
+        float* zmid = (float*)malloc(sizeof(float) * R * (Sc - 1));
+        float* cin = (float*)malloc(sizeof(float) * R * (Sc - 2));
+        float* znew = (float*)malloc(sizeof(float) * R * Sf);
+        float* zf = (float*)malloc(sizeof(float) * R * Sfull);
+        for (int64_t r = 0; r < R; ++r) {
+            for (int i = 0; i < Sc - 1; ++i) zmid[r * (Sc - 1) + i] = 0.5f * (z[r * Sc + i + 1] + z[r * Sc + i]);
+            for (int i = 0; i < Sc - 2; ++i) cin[r * (Sc - 2) + i] = contrib[r * Sc + 1 + i];
+        }
+        kpo_importance_sample(cin, zmid, u_f, R, Sc - 2, Sf, znew);              /* :1075, uniform=False */
+        for (int64_t r = 0; r < R; ++r) {
+            memcpy(zf + r * Sfull, z + r * Sc, sizeof(float) * Sc);
+            memcpy(zf + r * Sfull + Sc, znew + r * Sf, sizeof(float) * Sf);
+            qsort(zf + r * Sfull, Sfull, sizeof(float), cmp_float);             /* :1076 */
+            for (int i = 0; i < Sfull; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    pts[(r * Sfull + i) * 3 + k] = cam_pos[k] + dirs[r * 3 + k] * zf[r * Sfull + i];
+                    vw[(r * Sfull + i) * 3 + k] = dirs[r * 3 + k];
+                }
+        }
+        kpo_query_ex(sc, wflat, R * Sfull, pts, vw, 1, keep_f, noise_f, noise_std, rgba, NULL);
+        kpo_rgba2out(rgba, zf, R, Sfull, tex_fg_fine, depth_fine, alpha_fine, contrib, sdf_out);
+        if (z_f_out) memcpy(z_f_out, zf, sizeof(float) * R * Sfull);
+        free(zmid); free(cin); free(znew); free(zf);
+    }
+    free(dirs); free(nearr); free(farr); free(z); free(pts); free(vw); free(rgba); free(contrib); free(sdf_tmp);
 }
 
 /* ------------------------------------------------------------------------------------------

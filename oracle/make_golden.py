@@ -130,6 +130,79 @@ def run_tiled_case(net, name, n_views, src_hw, tar_hw, mask, level, Sc, Sf, seed
     print(f"{name}: frame {tuple(out['tex_fg_fine'].shape)} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_train_case(net, name, n_views, src_hw, tar_hw, mask, Sc, Sf, seed, patch=12, noise_std=0.01):
+    """TRAIN branch of batch_render_pifu_nerf (reference src/model.py:1008-1017,1049-1053,993-994,742-748,1129)
+    with every random draw recorded: torch.rand_like / randn_like / rand are wrapped for the duration of the call,
+    np.random.randint is seeded.  The view-dropout keep vectors are rebuilt from the recorded draws with the
+    reference's own formula (:743-747)."""
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=tar_hw, mask=mask, seed=seed)
+    Ht, Wt = tar_hw
+    g = torch.Generator().manual_seed(seed)
+    # target-view foreground mask `msk` (decode_batch passes images_masks[:,0], src/model.py:312,391): a disc
+    yy, xx = torch.meshgrid(torch.arange(Ht), torch.arange(Wt), indexing="ij")
+    msk = (((yy - Ht / 2) ** 2 + (xx - Wt / 2) ** 2) < (0.3 * min(Ht, Wt)) ** 2)[None, None]
+    log = []
+    orig = {"rand_like": torch.rand_like, "randn_like": torch.randn_like, "rand": torch.rand}
+
+    def wrap(nm):
+        def f(*a, **k):
+            r = orig[nm](*a, **k)
+            log.append((nm, r.clone()))
+            return r
+        return f
+
+    net.train()
+    net.train_out_h = net.train_out_w = patch
+    rec = Recorder(net)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.rand_like, torch.randn_like, torch.rand = wrap("rand_like"), wrap("randn_like"), wrap("rand")
+    try:
+        cfg = dict(fine=True, uniform=False, sample_per_ray_c=Sc, sample_per_ray_f=Sf, rand_noise_std=noise_std,
+                   src_foreground_mask=scene["src_foreground_mask"], bounds=scene["bounds"], msk=msk)
+        with torch.no_grad():
+            out = net.batch_render_pifu_nerf(net, scene["img"], scene["cam"], n_views, scene["cam_tar"], 5, 0, None,
+                                             scene["feat_geo"], scene["feat_tex"], dict(scene["sp_data"]), None, **cfg)
+    finally:
+        torch.rand_like, torch.randn_like, torch.rand = orig["rand_like"], orig["randn_like"], orig["rand"]
+        rec.restore()
+        net.eval()
+    # draws in call order: rand_like(z) | query coarse: rand_like(dropout[:,1:]), rand_like(dropout) | randn_like(rad)
+    #                      | rand (importance u) | query fine: rand_like x2 | randn_like(rad)
+    names = [n for n, _ in log]
+    assert names == ["rand_like", "rand_like", "rand_like", "randn_like", "rand", "rand_like", "rand_like", "randn_like"], names
+    t = [x for _, x in log]
+
+    def keep_vec(r_mask, r_perm):                                  # src/model.py:743-747
+        d = torch.zeros(1, n_views, 1, 1)
+        d[:, :1] = 1.0
+        d[:, 1:] = (r_mask > 0.5).float()
+        return torch.gather(d, 1, r_perm.argsort(dim=1)).reshape(-1)
+
+    keep_c, keep_f = keep_vec(t[1], t[2]), keep_vec(t[5], t[6])
+    # the patch pixels (src/model.py:1010-1016), np.random.randint replayed with the same seed
+    np.random.seed(seed)
+    coords = torch.stack(torch.where(msk.squeeze())[::-1], -1)
+    center = coords[np.random.randint(0, coords.shape[0], 1)]
+    yg, xg = torch.meshgrid(torch.arange(0, patch), torch.arange(0, patch), indexing="ij")
+    grids = torch.stack([xg, yg], -1).view(-1, 2) + (center - patch // 2)
+    grids = grids.clamp(0, min(Wt - 1, Ht - 1))
+    d = scene_to_npz(scene)
+    d.update({"cfg": np.array([n_views, 5, 0, 0, Sc, Sf], np.int64), "pix": _np(grids).astype(np.int32),
+              "u_c": _np(t[0])[0], "noise_c": _np(t[3]).reshape(-1), "u_f": _np(t[4])[0], "noise_f": _np(t[7]).reshape(-1),
+              "keep_c": _np(keep_c), "keep_f": _np(keep_f), "noise_std": np.float32(noise_std), "msk": _np(msk)})
+    for k, v in out.items():
+        d["out." + k] = _np(v)
+    d["dirs"] = rec.calls["ray_bbox_intersection"][0]["direct"][0]
+    d["z_c"] = rec.calls["rgba2out"][0]["z"][0]
+    d["z_f"] = rec.calls["rgba2out"][1]["z"][0]
+    d["valid_c"] = rec.calls["query"][0]["valid"].reshape(-1)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: rays={grids.shape[0]} keep_c={keep_c.tolist()} keep_f={keep_f.tolist()} alpha_fine={float(out['alpha_fine'].mean()):.3f} "
+          f"valid_c={d['valid_c'].mean():.3f} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def run_output_case(name, seed=9):
     """Output side: the reference's own frame arrangement / quantisation / PSNR."""
     rmodel = ref_shim.load_reference()
@@ -165,6 +238,9 @@ def main():
     # D: full-frame assembly through the reference tile loop + pixel_shuffle
     run_tiled_case(net, "case_d_v3_tiled_frame", 3, (64, 64), (16, 16), "ellipsoid", 3, 8, 8, seed=4)
     run_output_case("case_e_output")
+    # F/G: train branch with recorded random draws (seeds chosen so that at least one view is dropped in one of them)
+    run_train_case(net, "case_f_v3_train", 3, (64, 64), (32, 32), "dense", 12, 12, seed=5)
+    run_train_case(net, "case_g_v4_train", 4, (48, 80), (32, 48), "ellipsoid", 16, 8, seed=8)
 
 
 if __name__ == "__main__":

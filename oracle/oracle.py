@@ -178,3 +178,35 @@ def mse_psnr(pred, gt):
     out = np.empty(2, np.float64)
     lib().kpo_mse_psnr(_ptr(a), _ptr(b), ctypes.c_int64(a.size), _ptr(out))
     return out
+
+
+def query_ex(oscene, wflat, pts, view, apply_eval_func=False, keep=0xFFFFFFFF, noise=None, noise_std=0.0):
+    pts, view = _f32(pts).reshape(-1, 3), _f32(view).reshape(-1, 3)
+    N = pts.shape[0]
+    out = np.empty((N, 5), np.float32)
+    valid = np.empty((N,), np.uint8)
+    nz = _f32(noise).reshape(-1) if noise is not None else None
+    lib().kpo_query_ex(ctypes.byref(oscene.struct), _ptr(wflat), ctypes.c_int64(N), _ptr(pts), _ptr(view),
+                       ctypes.c_int(int(apply_eval_func)), ctypes.c_uint32(keep), _ptr(nz) if nz is not None else None,
+                       ctypes.c_float(noise_std), _ptr(out), _ptr(valid))
+    return out, valid.astype(bool)
+
+
+def render_rays_train(oscene, wflat, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std):
+    """train-mode batch_render_pifu_nerf with explicit random draws (see kpo_render_rays_train)."""
+    K, RT = _f32(cam_tar["K"]).reshape(4, 4), _f32(cam_tar["RT"]).reshape(4, 4)
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    b = _f32(bounds).reshape(2, 3)
+    u_c, u_f = _f32(u_c).reshape(R, Sc), _f32(u_f).reshape(R, Sf)
+    noise_c, noise_f = _f32(noise_c).reshape(-1), _f32(noise_f).reshape(-1)
+    o = {k: np.empty((R, 3), np.float32) for k in ("tex_fg", "tex_fg_fine")}
+    o.update({k: np.empty(R, np.float32) for k in ("depth", "alpha", "depth_fine", "alpha_fine", "sdf")})
+    o["z_c"], o["z_f"] = np.empty((R, Sc), np.float32), np.empty((R, Sc + Sf), np.float32)
+    lib().kpo_render_rays_train(ctypes.byref(oscene.struct), _ptr(wflat), _ptr(K), _ptr(RT), ctypes.c_float(cam_tar["znear"]),
+                                ctypes.c_float(cam_tar["zfar"]), _ptr(b), ctypes.c_int64(R), _ptr(pix), ctypes.c_int(Sc),
+                                ctypes.c_int(Sf), _ptr(u_c), _ptr(noise_c), _ptr(noise_f), _ptr(u_f), ctypes.c_uint32(keep_c),
+                                ctypes.c_uint32(keep_f), ctypes.c_float(noise_std), _ptr(o["tex_fg"]), _ptr(o["depth"]),
+                                _ptr(o["alpha"]), _ptr(o["tex_fg_fine"]), _ptr(o["depth_fine"]), _ptr(o["alpha_fine"]),
+                                _ptr(o["sdf"]), _ptr(o["z_c"]), _ptr(o["z_f"]))
+    return o

@@ -42,3 +42,10 @@ def pixel_list(cfg, cam_tar):
     yy, xx = np.meshgrid(ys, xs, indexing="ij")
     pix = np.stack([xx.reshape(-1) + cfg["stride_j"], yy.reshape(-1) + cfg["stride_i"]], -1).astype(np.int32)
     return pix, (len(ys), len(xs))
+
+TRAIN_CASES = ["case_f_v3_train", "case_g_v4_train"]
+
+
+def keep_bits(vec):
+    """(V,) 0/1 view-dropout vector -> bit mask (bit v = view v kept)."""
+    return int(sum(1 << i for i, k in enumerate(vec) if k > 0.5))

@@ -126,3 +126,28 @@ def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays
     ws = np.zeros(nb, np.uint8)
     lib.check(lib.kpn_render_rays(ctypes.byref(hs.desc), ptr(hs.ws), ptr(packed), ctypes.byref(a), ptr(ws), nb, None))
     return o
+
+
+def render_train(lib, hs, packed, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std, chunk_rays=0):
+    """kpn_render_rays_train on host buffers; returns (C,R)-planar outputs reshaped to (R,...)."""
+    K, RT, b = f32(cam_tar["K"]).reshape(4, 4), f32(cam_tar["RT"]).reshape(4, 4), f32(bounds).reshape(2, 3)
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    o = {k: np.full((3, R), np.nan, np.float32) for k in ("tex_fg", "tex_fg_fine")}
+    o.update({k: np.full(R, np.nan, np.float32) for k in ("depth", "alpha", "depth_fine", "alpha_fine", "sdf")})
+    a = kl.RenderArgs()
+    a.K, a.RT, a.bounds = K.ctypes.data, RT.ctypes.data, b.ctypes.data
+    a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    a.x0, a.y0, a.step, a.nx, a.ny = 0, 0, 1, R, 1
+    a.n_coarse, a.n_fine, a.fine, a.chunk_rays = Sc, Sf, 1, chunk_rays
+    for k, v in o.items():
+        setattr(a, k, v.ctypes.data)
+    bufs = dict(u_c=f32(u_c).reshape(R, Sc), noise_c=f32(noise_c).reshape(-1), noise_f=f32(noise_f).reshape(-1), u_f=f32(u_f).reshape(R, Sf))
+    t = kl.TrainArgs()
+    t.pix, t.u_coarse, t.noise_coarse, t.noise_fine, t.u_fine = (pix.ctypes.data, bufs["u_c"].ctypes.data, bufs["noise_c"].ctypes.data,
+                                                                 bufs["noise_f"].ctypes.data, bufs["u_f"].ctypes.data)
+    t.keep_coarse, t.keep_fine, t.rand_noise_std = keep_c, keep_f, float(noise_std)
+    nb = lib.kpn_render_workspace_bytes(ctypes.byref(hs.desc), ctypes.byref(a))
+    ws = np.zeros(nb, np.uint8)
+    lib.check(lib.kpn_render_rays_train(ctypes.byref(hs.desc), ptr(hs.ws), ptr(packed), ctypes.byref(a), ctypes.byref(t), ptr(ws), nb, None))
+    return o

@@ -214,3 +214,19 @@ def test_output_side(ops):
     big2 = torch.rand(3, 512, 512, device="cuda")
     m = ops.mse_psnr(big, big2)
     assert abs(float(m[0]) - float(((big - big2).double() ** 2).mean())) < 1e-9
+
+
+@pytest.mark.parametrize("case", ["case_f_v3_train", "case_g_v4_train"])
+def test_train_branch_vs_golden(ops, golden_weights, case):
+    """Forward of the TRAIN branch with the reference's recorded random draws (view dropout drops a view in both cases)."""
+    from tests.golden_io import keep_bits
+    scene, cfg, g = load_case(case)
+    s, ps = _prep(ops, scene)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    out = ops.render_rays_train(ps, golden_weights[1], s["cam_tar"], s["bounds"], t("pix"), t("u_c"), t("u_f"), keep_bits(g["keep_c"]),
+                                keep_bits(g["keep_f"]), t("noise_c"), t("noise_f"), float(g["noise_std"]), n_coarse=cfg["Sc"],
+                                n_fine=cfg["Sf"], chunk_rays=100)
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(out[k].cpu().numpy()[0] - g["out." + k][0].reshape(3, -1)).max() <= RGBA_TOL, k
+    for k in ("alpha", "alpha_fine"):
+        assert np.abs(out[k].cpu().numpy().reshape(-1) - g["out." + k].reshape(-1)).max() <= RGBA_TOL, k

@@ -109,3 +109,24 @@ def test_output_kernels(env):
     lib.check(lib.kpn_mse_psnr(sh.ptr(a), sh.ptr(gt), a.size, sh.ptr(out2), sh.ptr(scratch), None))
     assert abs(out2[0] - g["mse"]) < 1e-7 * g["mse"] and abs(out2[1] - g["psnr"]) < 1e-5
     assert np.allclose(out2, oracle.mse_psnr(a, gt), rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["case_f_v3_train", "case_g_v4_train"])
+def test_train_branch_kernels(env, case):
+    """kpn_render_rays_train (patch pixels, stratified jitter, density noise, per-view dropout, random importance
+    samples) on the emulator vs the reference's recorded train-mode outputs and vs the oracle."""
+    from tests.golden_io import keep_bits
+    lib, packed, wflat = env
+    scene, cfg, g = load_case(case)
+    hs = sh.HostScene(lib, scene)
+    kc, kf = keep_bits(g["keep_c"]), keep_bits(g["keep_f"])
+    o = sh.render_train(lib, hs, packed, scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"], g["u_c"], g["noise_c"],
+                        g["noise_f"], g["u_f"], kc, kf, float(g["noise_std"]), chunk_rays=100)
+    ref = oracle.render_rays_train(oracle.OracleScene(scene), wflat, scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"],
+                                   g["u_c"], g["noise_c"], g["noise_f"], g["u_f"], kc, kf, float(g["noise_std"]))
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(o[k].T - ref[k]).max() < 1e-5, k
+        assert np.abs(o[k] - g["out." + k][0].reshape(3, -1)).max() < 1e-4, k
+    for k in ("alpha", "alpha_fine"):
+        assert np.abs(o[k] - ref[k]).max() < 1e-5, k
+        assert np.abs(o[k] - g["out." + k].reshape(-1)).max() < 1e-4, k

@@ -122,3 +122,25 @@ def test_output_side_vs_golden():
     assert np.array_equal(oracle.frame_to_rgb8(g["pred"], bgr=True), g["bgr8"])
     m = oracle.mse_psnr(np.clip(g["pred"], 0, 1), g["gt"])
     assert abs(m[0] - g["mse"]) < 1e-7 * g["mse"] + 1e-12 and abs(m[1] - g["psnr"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["case_f_v3_train", "case_g_v4_train"])
+def test_train_branch_vs_golden(case, wflat):
+    """TRAIN branch of batch_render_pifu_nerf with the reference's recorded random draws (patch pixels, stratified
+    jitter, density noise, per-view dropout, random importance samples)."""
+    from tests.golden_io import keep_bits
+    scene, cfg, g = load_case(case)
+    osc = oracle.OracleScene(scene)
+    o = oracle.render_rays_train(osc, wflat, scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"], g["u_c"],
+                                 g["noise_c"], g["noise_f"], g["u_f"], keep_bits(g["keep_c"]), keep_bits(g["keep_f"]),
+                                 float(g["noise_std"]))
+    dirs, _, _, _ = oracle.make_rays(scene["cam_tar"], scene["bounds"], g["pix"])
+    np.testing.assert_allclose(dirs, g["dirs"], atol=1e-6)          # the patch pixels are the reference's
+    np.testing.assert_allclose(o["z_c"], g["z_c"], atol=2e-6)
+    assert_samples_close(o["z_f"], g["z_f"], g["z_f"], atol=1e-5)
+    n = int(round(g["pix"].shape[0] ** 0.5))
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(o[k] - g["out." + k][0].transpose(1, 2, 0).reshape(-1, 3)).max() < 3e-5, k
+    for k in ("alpha", "alpha_fine"):
+        assert np.abs(o[k] - g["out." + k].reshape(-1)).max() < 3e-5, k
+    assert g["keep_c"].min() == 0 or g["keep_f"].min() == 0          # a view really is dropped in this case
