@@ -177,7 +177,7 @@ def main():
                        "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},
             "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": 256.0 * rows.value / max(1, launches.value),
+                         "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "algorithmic_flop_per_row": flops_row,
                          "kernel_time_share": (ms.value * 1e-3) / dt},
