@@ -106,6 +106,13 @@ int kpn_importance_sample(const float* contrib, const float* z, const float* u, 
 int kpn_rgba2out(const float* rgba, const float* z, int64_t n_rays, int32_t n_samples, float* color, float* depth,
                  float* alpha, float* contrib, float* sdf, void* stream);
 
+/* Backward of rgba2out (what torch autograd derives from src/model.py:1162-1174): given the forward inputs and the
+ * upstream gradients of color (R,3), depth (R), alpha (R), sdf (R) (any may be NULL = zero), writes d_rgba (R,S,5).
+ * z carries no gradient in the reference (sample positions are drawn under no_grad, :1038,1118).  First piece of the
+ * training backward; the field-evaluation backward is not built yet. */
+int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t n_rays, int32_t n_samples, const float* d_color,
+                          const float* d_depth, const float* d_alpha, const float* d_sdf, float* d_rgba, void* stream);
+
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).
  * mode 0: out = [sdf_raw, rad, r,g,b] exactly as query() returns;

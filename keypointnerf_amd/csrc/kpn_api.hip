@@ -278,6 +278,15 @@ extern "C" int kpn_rgba2out(const float* rgba, const float* z, int64_t R, int32_
     return check_launch("kpn_rgba2out");
 }
 
+extern "C" int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t R, int32_t S, const float* d_color,
+                                     const float* d_depth, const float* d_alpha, const float* d_sdf, float* d_rgba, void* stream) {
+    KPN_REQUIRE(rgba && z && d_rgba, "null pointer");
+    KPN_REQUIRE(S >= 1, "bad sample count");
+    if (R <= 0) return R == 0 ? KPN_OK : fail(KPN_EINVAL, "negative ray count");
+    KPN_LAUNCH(k_rgba2out_bwd, grid1d(R, 64), dim3(64), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
+    return check_launch("kpn_rgba2out_backward");
+}
+
 // ---------------------------------------------------------------------------------------------
 // field query
 namespace {

@@ -254,6 +254,45 @@ __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float*
     }
 }
 
+// Backward of rgba2out: one thread per ray.  Forward sweep: transmittance T_i (parked in the output row) and the
+// sums; reverse sweep with the division-free recurrence Q_{i-1} = g_i a_i + (1-a_i) Q_i, where g_i = dL/dc_i and
+// dL/da_i = T_i (g_i - Q_i)  (the cumprod's 1/(1-a_i) never appears, so a_i == 1 is harmless).
+__global__ void k_rgba2out_bwd(int64_t R, int S, const float* __restrict__ rgba, const float* __restrict__ z,
+                               const float* __restrict__ d_color, const float* __restrict__ d_depth,
+                               const float* __restrict__ d_alpha, const float* __restrict__ d_sdf, float* __restrict__ d_rgba) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* q = rgba + r * S * 5;
+    const float* zz = z + r * S;
+    float* dq = d_rgba + r * S * 5;
+    float T = 1.0f, A = 0.0f, Ssum = 0.0f, Dsum = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        const float dist = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;
+        const float a = 1.0f - expf(-q[i * 5 + 0] * dist);
+        const float c = a * T;
+        dq[i * 5 + 0] = T;
+        T *= (1.0f - a);
+        A += c; Ssum += q[i * 5 + 1] * c; Dsum += zz[i] * c;
+    }
+    const float dc0 = d_color ? d_color[r * 3 + 0] : 0.f, dc1 = d_color ? d_color[r * 3 + 1] : 0.f, dc2 = d_color ? d_color[r * 3 + 2] : 0.f;
+    const float dA = d_alpha ? d_alpha[r] : 0.f, dS = d_sdf ? d_sdf[r] : 0.f, dD = d_depth ? d_depth[r] : 0.f;
+    const float inv = 1.0f / (A + 1e-8f);
+    const float gA = dA - (dS * Ssum + dD * Dsum) * inv * inv;  // sdf and depth also depend on every c_i through alpha
+    float Q = 0.0f;
+    for (int i = S - 1; i >= 0; --i) {
+        const float dist = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;
+        const float e = expf(-q[i * 5 + 0] * dist);  // 1 - a_i
+        const float a = 1.0f - e;
+        const float Ti = dq[i * 5 + 0];
+        const float c = a * Ti;
+        const float g = dc0 * q[i * 5 + 2] + dc1 * q[i * 5 + 3] + dc2 * q[i * 5 + 4] + gA + dS * q[i * 5 + 1] * inv + dD * zz[i] * inv;
+        dq[i * 5 + 0] = Ti * (g - Q) * dist * e;     // d sigma_i = dL/da_i * da_i/dsigma_i
+        dq[i * 5 + 1] = c * dS * inv;                // d sdf_i
+        dq[i * 5 + 2] = c * dc0; dq[i * 5 + 3] = c * dc1; dq[i * 5 + 4] = c * dc2;
+        Q = g * a + e * Q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // importance_sample (model.py:1110-1148): one thread per ray, sequential cdf (torch.cumsum order),
 // searchsorted(right=True) by bisection in LDS.  contrib (R,Dm2), zin (R,Dm2+1), u (R,n)|NULL -> out (R,n)

@@ -147,8 +147,38 @@ def importance_sample(contrib, z, sample_per_ray, uniform=False, u=None):
     return out
 
 
+class _Rgba2Out(torch.autograd.Function):
+    """rgba2out with its hand-written backward (kpn_rgba2out_backward): d_rgba from the upstream gradients of
+    color/depth/alpha/sdf; contrib and z carry no gradient, as in the reference (:1038,1118 run under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, rgba, z):
+        out = _rgba2out_fwd(rgba, z)
+        ctx.save_for_backward(rgba.detach(), z.detach())
+        ctx.mark_non_differentiable(out[3])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_color, d_depth, d_alpha, d_contrib, d_sdf):
+        L = kl.get_library()
+        rgba, z = ctx.saved_tensors
+        q, zz = _dev(rgba, "rgba"), _dev(z, "z")
+        B, R, S = zz.shape
+        g = [None if x is None else _dev(x, "grad") for x in (d_color, d_depth, d_alpha, d_sdf)]
+        d_rgba = torch.empty_like(q)
+        L.check(L.kpn_rgba2out_backward(_p(q), _p(zz), B * R, S, _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(d_rgba), _stream()))
+        return d_rgba, None
+
+
 def rgba2out(rgba, z):
-    """rgba (B,R,S,5), z (B,R,S) -> color (B,R,3), depth (B,R), alpha (B,R), contrib (B,R,S), sdf (B,R)."""
+    """rgba (B,R,S,5), z (B,R,S) -> color (B,R,3), depth (B,R), alpha (B,R), contrib (B,R,S), sdf (B,R).
+    Differentiable w.r.t. rgba (hand-written backward kernel)."""
+    if torch.is_grad_enabled() and isinstance(rgba, torch.Tensor) and rgba.requires_grad:
+        return _Rgba2Out.apply(rgba, z)
+    return _rgba2out_fwd(rgba, z)
+
+
+def _rgba2out_fwd(rgba, z):
     L = kl.get_library()
     q, zz = _dev(rgba, "rgba"), _dev(z, "z")
     B, R, S = zz.shape

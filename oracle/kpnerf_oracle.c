@@ -705,3 +705,39 @@ void kpo_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2) {
     out2[0] = acc / (double)n;
     out2[1] = -10.0 * log(out2[0]) / log(10.0);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of rgba2out (model.py:1162-1174) as torch autograd derives it; fp64 restatement.  z has no gradient
+ * in the reference (drawn under no_grad).  d_* may be NULL (= zero upstream gradient). */
+void kpo_rgba2out_backward(const float* rgba, const float* z, int64_t R, int S, const float* d_color,
+                           const float* d_depth, const float* d_alpha, const float* d_sdf, float* d_rgba) {
+    double* T = (double*)malloc(sizeof(double) * S);
+    for (int64_t r = 0; r < R; ++r) {
+        const float* q = rgba + r * S * 5;
+        const float* zz = z + r * S;
+        float* dq = d_rgba + r * S * 5;
+        double t = 1.0, A = 0.0, Ss = 0.0, Ds = 0.0;
+        for (int i = 0; i < S; ++i) {
+            double dist = (i + 1 < S) ? (double)(zz[i + 1] - zz[i]) : 1e10;
+            double a = 1.0 - exp(-(double)q[i * 5] * dist);
+            T[i] = t;
+            A += a * t; Ss += q[i * 5 + 1] * a * t; Ds += zz[i] * a * t;
+            t *= (1.0 - a);
+        }
+        double dc[3] = {d_color ? d_color[r * 3] : 0.0, d_color ? d_color[r * 3 + 1] : 0.0, d_color ? d_color[r * 3 + 2] : 0.0};
+        double dA = d_alpha ? d_alpha[r] : 0.0, dS = d_sdf ? d_sdf[r] : 0.0, dD = d_depth ? d_depth[r] : 0.0;
+        double inv = 1.0 / (A + 1e-8);
+        double gA = dA - (dS * Ss + dD * Ds) * inv * inv;
+        double Q = 0.0;
+        for (int i = S - 1; i >= 0; --i) {
+            double dist = (i + 1 < S) ? (double)(zz[i + 1] - zz[i]) : 1e10;
+            double e = exp(-(double)q[i * 5] * dist), a = 1.0 - e, c = a * T[i];
+            double g = dc[0] * q[i * 5 + 2] + dc[1] * q[i * 5 + 3] + dc[2] * q[i * 5 + 4] + gA + dS * q[i * 5 + 1] * inv + dD * zz[i] * inv;
+            dq[i * 5 + 0] = (float)(T[i] * (g - Q) * dist * e);
+            dq[i * 5 + 1] = (float)(c * dS * inv);
+            dq[i * 5 + 2] = (float)(c * dc[0]); dq[i * 5 + 3] = (float)(c * dc[1]); dq[i * 5 + 4] = (float)(c * dc[2]);
+            Q = g * a + e * Q;
+        }
+    }
+    free(T);
+}

@@ -203,6 +203,27 @@ def run_train_case(net, name, n_views, src_hw, tar_hw, mask, Sc, Sf, seed, patch
           f"valid_c={d['valid_c'].mean():.3f} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_rgba2out_grad_case(name, seed=11, R=40, S=24):
+    """Gradients of the reference's rgba2out by torch autograd (first piece of the training backward)."""
+    rmodel = ref_shim.load_reference()
+    g = torch.Generator().manual_seed(seed)
+    rgba = torch.rand(1, R, S, 5, generator=g)
+    rgba[..., 0] = torch.relu(torch.randn(1, R, S, generator=g)) * 6.0          # sigma >= 0, many exact zeros
+    rgba[..., 1] = torch.randn(1, R, S, generator=g) * 0.01
+    rgba[0, :4, :, 0] = 0.0                                                    # rays with no density at all
+    z = (torch.rand(1, R, S, generator=g) * 0.2 + 0.01).cumsum(-1) + 2.0
+    rgba.requires_grad_(True)
+    color, depth, alpha, contrib, sdf = rmodel.KeypointNeRF.rgba2out(rgba, z)
+    d_color, d_depth = torch.randn(color.shape, generator=g), torch.randn(depth.shape, generator=g)
+    d_alpha, d_sdf = torch.randn(alpha.shape, generator=g), torch.randn(sdf.shape, generator=g)
+    (g_all,) = torch.autograd.grad([color, depth, alpha, sdf], [rgba], [d_color, d_depth, d_alpha, d_sdf], retain_graph=True)
+    (g_col,) = torch.autograd.grad([color], [rgba], [d_color])
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, rgba=_np(rgba), z=_np(z), d_color=_np(d_color), d_depth=_np(d_depth), d_alpha=_np(d_alpha),
+                        d_sdf=_np(d_sdf), g_all=_np(g_all), g_color_only=_np(g_col))
+    print(f"{name}: |g|max={float(g_all.abs().max()):.3g} -> {path}")
+
+
 def run_output_case(name, seed=9):
     """Output side: the reference's own frame arrangement / quantisation / PSNR."""
     rmodel = ref_shim.load_reference()
@@ -238,6 +259,7 @@ def main():
     # D: full-frame assembly through the reference tile loop + pixel_shuffle
     run_tiled_case(net, "case_d_v3_tiled_frame", 3, (64, 64), (16, 16), "ellipsoid", 3, 8, 8, seed=4)
     run_output_case("case_e_output")
+    run_rgba2out_grad_case("case_h_rgba2out_grad")
     # F/G: train branch with recorded random draws (seeds chosen so that at least one view is dropped in one of them)
     run_train_case(net, "case_f_v3_train", 3, (64, 64), (32, 32), "dense", 12, 12, seed=5)
     run_train_case(net, "case_g_v4_train", 4, (48, 80), (32, 48), "ellipsoid", 16, 8, seed=8)

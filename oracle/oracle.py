@@ -210,3 +210,13 @@ def render_rays_train(oscene, wflat, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c,
                                 _ptr(o["alpha"]), _ptr(o["tex_fg_fine"]), _ptr(o["depth_fine"]), _ptr(o["alpha_fine"]),
                                 _ptr(o["sdf"]), _ptr(o["z_c"]), _ptr(o["z_f"]))
     return o
+
+
+def rgba2out_backward(rgba, z, d_color=None, d_depth=None, d_alpha=None, d_sdf=None):
+    rgba, z = _f32(rgba), _f32(z)
+    S = z.shape[-1]
+    R = z.size // S
+    out = np.empty((R, S, 5), np.float32)
+    g = [None if x is None else _f32(x).reshape(-1) for x in (d_color, d_depth, d_alpha, d_sdf)]
+    lib().kpo_rgba2out_backward(_ptr(rgba), _ptr(z), ctypes.c_int64(R), ctypes.c_int(S), *[_ptr(x) if x is not None else None for x in g], _ptr(out))
+    return out

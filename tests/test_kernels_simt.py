@@ -130,3 +130,20 @@ def test_train_branch_kernels(env, case):
     for k in ("alpha", "alpha_fine"):
         assert np.abs(o[k] - ref[k]).max() < 1e-5, k
         assert np.abs(o[k] - g["out." + k].reshape(-1)).max() < 1e-4, k
+
+
+def test_rgba2out_backward_kernel(env):
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    from tests.test_oracle_vs_golden import assert_grad_close
+    lib = env[0]
+    g = np.load(os.path.join(GOLDEN_DIR, "case_h_rgba2out_grad.npz"))
+    rgba, z = sh.f32(g["rgba"][0]), sh.f32(g["z"][0])
+    R, S = z.shape
+    gs = [sh.f32(g[k]).reshape(-1) for k in ("d_color", "d_depth", "d_alpha", "d_sdf")]
+    out = np.zeros((R, S, 5), np.float32)
+    lib.check(lib.kpn_rgba2out_backward(sh.ptr(rgba), sh.ptr(z), R, S, sh.ptr(gs[0]), sh.ptr(gs[1]), sh.ptr(gs[2]), sh.ptr(gs[3]), sh.ptr(out), None))
+    assert_grad_close(out, g["g_all"][0])
+    out2 = np.zeros((R, S, 5), np.float32)
+    lib.check(lib.kpn_rgba2out_backward(sh.ptr(rgba), sh.ptr(z), R, S, sh.ptr(gs[0]), None, None, None, sh.ptr(out2), None))
+    assert_grad_close(out2, g["g_color_only"][0])

@@ -144,3 +144,18 @@ def test_train_branch_vs_golden(case, wflat):
     for k in ("alpha", "alpha_fine"):
         assert np.abs(o[k] - g["out." + k].reshape(-1)).max() < 3e-5, k
     assert g["keep_c"].min() == 0 or g["keep_f"].min() == 0          # a view really is dropped in this case
+
+
+def assert_grad_close(got, ref, rtol=2e-4):
+    """Per-ray relative comparison: the reference's last interval (1e10) makes some gradients ~1e18."""
+    scale = np.abs(ref).reshape(ref.shape[0], -1).max(-1)[:, None, None]
+    assert (np.abs(got - ref) <= rtol * scale + 1e-6).all(), float((np.abs(got - ref) / (scale + 1e-6)).max())
+
+
+def test_rgba2out_backward_vs_autograd_golden():
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "case_h_rgba2out_grad.npz"))
+    o = oracle.rgba2out_backward(g["rgba"][0], g["z"][0], g["d_color"], g["d_depth"], g["d_alpha"], g["d_sdf"])
+    assert_grad_close(o, g["g_all"][0])
+    assert_grad_close(oracle.rgba2out_backward(g["rgba"][0], g["z"][0], g["d_color"]), g["g_color_only"][0])
