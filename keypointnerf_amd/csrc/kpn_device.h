@@ -197,6 +197,7 @@ __device__ __forceinline__ void kpn_mfma_layer(const float* __restrict__ wseg, i
             for (int ob = 0; ob < NOB; ++ob)
                 acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][(i * NOB + ob) / 4][(i * NOB + ob) % 4], x[cur][i],
                                                                acc[ob], 0, 0, 0);
+
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) KPN_FENCE_RW(acc[ob]);
         if constexpr (g + 1 < NG) {
