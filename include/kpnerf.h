@@ -113,6 +113,24 @@ int kpn_rgba2out(const float* rgba, const float* z, int64_t n_rays, int32_t n_sa
 int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t n_rays, int32_t n_samples, const float* d_color,
                           const float* d_depth, const float* d_alpha, const float* d_sdf, float* d_rgba, void* stream);
 
+/* Backward of the per-(point, source view) geometry rows: MLPUNet.layers1 232->128->128->(+8)120->64
+ * (src/utils.py:691-716) and the bilinear gathers of feat_geo[0] / feat_geo[1] that feed it (src/model.py:763-765,
+ * src/utils.py:74-89) — what autograd does for ~70 % of the field's arithmetic in `training_step`
+ * (src/model.py:128-155).  The forward activations are recomputed (nothing is kept from the forward pass).
+ *   pts (N,3); keep_mask = the train-time view dropout bits (bit v = 0: view v off, as in kpn_train_args);
+ *   d_x (N, V, 64): d loss / d (layers1 output of point n in view v); rows of points that are masked
+ *        (query's validity, src/model.py:725-739) are ignored;
+ *   d_plain: += gradient w.r.t. the weight-norm-folded parameters, same flat layout as kpn_pack_weights' input
+ *        (kpn_plain_weight_floats() floats; only the four layers1 blocks are touched);
+ *   d_geo0 (V, geo0_h, geo0_w, 64), d_geo1 (V, geo1_h, geo1_w, 8): += gradient w.r.t. the feature maps,
+ *        CHANNELS-LAST (permute to NCHW to hand it to the encoder's backward).
+ * Accumulating: the caller zeroes the three outputs.  Float atomics: the summation order is not deterministic.
+ * The second piece of the training backward after kpn_rgba2out_backward; pooling / layers2 / colour head: next. */
+size_t kpn_geo_rows_backward_workspace_bytes(int64_t n_points, int32_t n_views);
+int kpn_geo_rows_backward(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights, int64_t n_points,
+                          const float* pts, uint32_t keep_mask, const float* d_x, float* d_plain, float* d_geo0,
+                          float* d_geo1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).
  * mode 0: out = [sdf_raw, rad, r,g,b] exactly as query() returns;

@@ -1,0 +1,314 @@
+// field_bwd_kernels.hip — reverse pass of the per-(point,view) geometry rows, i.e. of k_geo_rows:
+// MLPUNet.layers1 232->128->128->(+8)120->64 (reference src/utils.py:691-716) and the bilinear feature
+// gathers that feed it (feat_sample of feat_geo[0], feat_geo[1]; src/model.py:763-765, src/utils.py:74-89).
+// This is the dominant ~70 % of the field evaluation's arithmetic; the reference gets it from autograd.
+//
+//   k_geo_rows_bwd : per row tile (32 rows of one view) —
+//       F phase  recompute layers1.0 .. layers1.2 exactly as k_geo_rows does (activation checkpointing:
+//                nothing is kept from the forward pass), writing each layer's INPUT row-major
+//                (X0 [enc168|geo64], X1, X2 [128|hd8], X3) for the weight-gradient kernel;
+//       B phase  dX = W^T dY on the matrix cores with the transposed segments (kpn_common.h BSEG_*),
+//                chained through registers like the forward pass; softplus' = 1 - exp(-100 softplus) is
+//                taken from the X dumps; each dA (= dY of a Linear) is written row-major;
+//       scatter  d(geo0 64 ch) and d(geo1 8 ch) go back to the channels-last maps through the 4
+//                bilinear taps with hardware float atomics.
+//   k_weight_grad  : dW[o][f] += sum_rows dY[row][o] X[row][f], db[o] += sum_rows dY[row][o] — the
+//                reduction over rows is the K dimension of v_mfma_f32_32x32x2_f32; row-major dumps are
+//                exactly its A/B operand layout (lane = feature, k = row parity), no transposes.
+// The keypoint encoding has no upstream parameters (points and keypoints are inputs), so dX0's first
+// 168 entries are never formed.
+#include "kpn_device.h"
+
+struct kpn_bwd_bufs {
+    float* X0;  // [rows][232]: cols (12h+j)*7+t = PE block t of keypoint 12h+j; cols 168..231 geometry channels
+    float* X1;  // [rows][128]
+    float* X2;  // [rows][136]
+    float* X3;  // [rows][128]  (cols >= 120 unused)
+    float* D0;  // dA0 [rows][128]
+    float* D1;  // dA1 [rows][128]
+    float* D2;  // dA2 [rows][128] (cols >= 120 are 0)
+    float* D3;  // dY3 [rows][64]
+    float* dgeo0;  // V x g0h x g0w x 64, accumulated
+    float* dgeo1;  // V x g1h x g1w x 8, accumulated
+};
+#define KPN_LDX0 232
+#define KPN_LDX2 136
+
+// d softplus100(a) / da from the softplus value itself: sigmoid(100 a) = 1 - exp(-100 softplus(a)); above the
+// threshold (softplus == a, 100 a > 20) this is 1 to within 2e-9, the reference's exact 1
+__device__ __forceinline__ float kpn_softplus100_grad_from_value(float sp) { return 1.0f - kpn_exp2(sp * -144.269504088896341f); }
+
+__device__ __forceinline__ void kpn_scatter4(float* __restrict__ map, int C, int c0, const kpn_taps& t, float g0, float g1,
+                                             float g2, float g3) {
+    const int offs[4] = {t.o00, t.o01, t.o10, t.o11};
+    const float ws[4] = {t.w00, t.w01, t.w10, t.w11};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float* d = map + (size_t)offs[k] * C + c0;
+        kpn_atomic_add(d + 0, g0 * ws[k]); kpn_atomic_add(d + 1, g1 * ws[k]);
+        kpn_atomic_add(d + 2, g2 * ws[k]); kpn_atomic_add(d + 3, g3 * ws[k]);
+    }
+}
+
+// dx: upstream gradient d loss / d x_view, [N][V][64] row-major, indexed by the ORIGINAL point index
+__global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                         const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                         int* __restrict__ tickets, const float* __restrict__ dx,
+                                                         kpn_bwd_bufs bufs) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int count = *count_ptr;
+    const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
+    const int nwork = ntiles * sc.V;
+    const float pe_pi = 3.14159274101257324f;
+    __shared__ __attribute__((aligned(16))) float bias_s[3][128];
+    {
+        const int segs[3] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2};
+        for (int i = threadIdx.x; i < 3 * 128; i += blockDim.x) bias_s[i >> 7][i & 127] = wp[kpn_seg_boff(segs[i >> 7]) + (i & 127)];
+    }
+    __syncthreads();
+
+    for (;;) {
+        int wi = 0;
+        if (lane == 0) wi = atomicAdd(tickets, 1);
+        wi = __shfl(wi, 0);
+        if (wi >= nwork) break;
+        const int t = wi / sc.V, v = wi - t * sc.V;
+        int ci = t * KPN_TILE + p;
+        // pad lanes recompute the last point with a zero upstream gradient; so do views switched off by the
+        // train-time dropout (their pooling weight is 0, model.py:748)
+        const float live = (ci < count && ((sc.keep >> v) & 1u)) ? 1.0f : 0.0f;
+        if (ci >= count) ci = count - 1;
+        const int64_t n = list[ci];
+        const size_t row = (size_t)wi * KPN_TILE + p;
+        float P[3], D[3];
+        kpn_get_point(ps, n, P, D);
+        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+        const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+        const kpn_taps tp0 = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);
+        const kpn_taps tp1 = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
+        float* const x0row = bufs.X0 + row * KPN_LDX0;
+        float* const x1row = bufs.X1 + row * 128;
+        float* const x2row = bufs.X2 + row * KPN_LDX2;
+        float* const x3row = bufs.X3 + row * 128;
+
+        // ================= F phase (same arithmetic as k_geo_rows) =================
+        kpn_f32x16 a0[4];
+        {
+            const float* E = tb + KPN_TBL_EXT;
+            const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
+            const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
+            const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
+            const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
+            kpn_load_bias<4>(bias_s[0], h, a0);
+            kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
+                constexpr int j = decltype(gi)::value;
+                const float dx_ = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
+                const float d2 = KADD(KADD(KMUL(dx_, dx_), KMUL(dy, dy)), KMUL(dz, dz));
+                const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
+                float s1, c1;
+                kpn_sincos(KMUL(dz, pe_pi), s1, c1);
+                const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
+                const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
+                x[0] = dz * w;
+                x[1] = s1 * w; x[2] = c1 * w;
+                x[3] = s2 * w; x[4] = c2 * w;
+                x[5] = s4 * w; x[6] = c4 * w;
+                float* d = x0row + (12 * h + j) * 7;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) d[i] = x[i];
+            }, a0);
+            const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
+            kpn_mfma_layer<32, 4, 4>(wp + kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp0);
+                x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
+                *reinterpret_cast<float4*>(x0row + 168 + 32 * h + 4 * g) = f;
+            }, a0);
+        }
+        // chained group g of a 128-vector = features 32(g/4) + 8(g%4) + 4h .. +3 of this lane's row
+        kpn_f32x16 a1[4];
+        kpn_load_bias<4>(bias_s[1], h, a1);
+        kpn_mfma_layer<64, 4, 4>(wp + kpn_seg_woff(SEG_G1_1), lane, [&](auto gi, float (&x)[4]) {
+            constexpr int g = decltype(gi)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a0[g / 4][(g % 4) * 4 + i]);
+            *reinterpret_cast<float4*>(x1row + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
+        }, a1);
+        kpn_f32x16 a2[4];
+        {
+            const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1);
+            *reinterpret_cast<float4*>(x2row + 128 + 4 * h) = f;
+            kpn_load_bias<4>(bias_s[2], h, a2);
+            kpn_mfma_layer<68, 4, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                if constexpr (g < 16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a1[g / 4][(g % 4) * 4 + i]);
+                    *reinterpret_cast<float4*>(x2row + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
+                } else {
+                    x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
+                }
+            }, a2);
+        }
+        // X3 = softplus(a2), the input of layers1.3 (its forward product itself is not needed here)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float4 o;
+            o.x = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 0]); o.y = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 1]);
+            o.z = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 2]); o.w = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 3]);
+            *reinterpret_cast<float4*>(x3row + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = o;
+        }
+
+        // ================= B phase =================
+        // dX3 = W3^T dY3
+        kpn_f32x16 d3[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d3[ob][r] = 0.0f;
+        {
+            const float* grow = dx + ((size_t)n * sc.V + v) * 64;
+            float* d3row = bufs.D3 + row * 64;
+            kpn_mfma_layer<32, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
+                const float4 f = *reinterpret_cast<const float4*>(grow + col);
+                x[0] = f.x * live; x[1] = f.y * live; x[2] = f.z * live; x[3] = f.w * live;
+                *reinterpret_cast<float4*>(d3row + col) = make_float4(x[0], x[1], x[2], x[3]);
+            }, d3);
+        }
+        // dA2 = dX3 * softplus'(a2);  [dX2 | d hd] = W2^T dA2
+        kpn_f32x16 d2[5];
+#pragma unroll
+        for (int ob = 0; ob < 5; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[ob][r] = 0.0f;
+        {
+            float* drow = bufs.D2 + row * 128;
+            kpn_mfma_layer<64, 5, 4>(wp + kpn_bseg_woff(BSEG_G1_2T), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
+                const float4 s = *reinterpret_cast<const float4*>(x3row + col);
+                x[0] = d3[g / 4][(g % 4) * 4 + 0] * kpn_softplus100_grad_from_value(s.x);
+                x[1] = d3[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
+                x[2] = d3[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
+                x[3] = d3[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
+                *reinterpret_cast<float4*>(drow + col) = make_float4(x[0], x[1], x[2], x[3]);
+            }, d2);
+        }
+        // the 8 hd channels (rows 128..135 of dX2 = block 4 regs 0..3: channels 4h..4h+3) go back to feat_geo[1]
+        kpn_scatter4(bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1, d2[4][0], d2[4][1], d2[4][2], d2[4][3]);
+        // dA1 = dX2 * softplus'(a1);  dX1 = W1^T dA1
+        kpn_f32x16 d1[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[ob][r] = 0.0f;
+        {
+            float* drow = bufs.D1 + row * 128;
+            kpn_mfma_layer<64, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_1T), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
+                const float4 s = *reinterpret_cast<const float4*>(x2row + col);
+                x[0] = d2[g / 4][(g % 4) * 4 + 0] * kpn_softplus100_grad_from_value(s.x);
+                x[1] = d2[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
+                x[2] = d2[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
+                x[3] = d2[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
+                *reinterpret_cast<float4*>(drow + col) = make_float4(x[0], x[1], x[2], x[3]);
+            }, d1);
+        }
+        // dA0 = dX1 * softplus'(a0);  d geo0 = W0[:,168:232]^T dA0
+        kpn_f32x16 dg[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dg[ob][r] = 0.0f;
+        {
+            float* drow = bufs.D0 + row * 128;
+            kpn_mfma_layer<64, 2, 4>(wp + kpn_bseg_woff(BSEG_G1_0T), lane, [&](auto gi, float (&x)[4]) {
+                constexpr int g = decltype(gi)::value;
+                const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
+                const float4 s = *reinterpret_cast<const float4*>(x1row + col);
+                x[0] = d1[g / 4][(g % 4) * 4 + 0] * kpn_softplus100_grad_from_value(s.x);
+                x[1] = d1[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
+                x[2] = d1[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
+                x[3] = d1[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
+                *reinterpret_cast<float4*>(drow + col) = make_float4(x[0], x[1], x[2], x[3]);
+            }, dg);
+        }
+        // block b, regs 4q..4q+3 of this lane = geometry channels 32b + 8q + 4h .. +3
+        {
+            float* g0 = bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    kpn_scatter4(g0, 64, 32 * b + 8 * qd + 4 * h, tp0, dg[b][4 * qd + 0], dg[b][4 * qd + 1], dg[b][4 * qd + 2],
+                                 dg[b][4 * qd + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dW[o][colmap(c)] += sum_row dY[row][o] * X[row][c];  db[o] += sum_row dY[row][o].
+// grid (row splits, ceil(M/64), ceil(Kc/64)); a wave owns a 64x64 block of dW (2x2 MFMA tiles) and a slice of
+// the split's rows.  ENC: X is the X0 dump, whose first 168 columns are in (keypoint, PE block) order.
+template <int ENC>
+__global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ dY, int ldy, int M, const float* __restrict__ X,
+                                                     int ldx, int Kc, const int64_t* __restrict__ rows_ptr,
+                                                     float* __restrict__ dW, int in_dim, int f0, float* __restrict__ db) {
+    const int64_t rows = *rows_ptr;
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
+    // rows of this wave: pairs (2 rows per K-step), interleaved over splits x waves
+    const int64_t npairs = rows / 2;
+    const int64_t nworkers = (int64_t)gridDim.x * nwave;
+    const int64_t per = (npairs + nworkers - 1) / nworkers;
+    const int64_t pbeg = ((int64_t)blockIdx.x * nwave + wave) * per;
+    const int64_t pend = pbeg + per < npairs ? pbeg + per : npairs;
+    kpn_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const bool oa0 = o0 + i < M, oa1 = o0 + 32 + i < M;
+    const bool cb0 = c0 + i < Kc, cb1 = c0 + 32 + i < Kc;
+    float bs0 = 0.0f, bs1 = 0.0f;
+    for (int64_t pr = pbeg; pr < pend; ++pr) {
+        const int64_t r = 2 * pr + kk;
+        const float* yr = dY + r * ldy + o0 + i;
+        const float* xr = X + r * ldx + c0 + i;
+        const float ya = oa0 ? yr[0] : 0.0f, yb = oa1 ? yr[32] : 0.0f;
+        const float xa = cb0 ? xr[0] : 0.0f, xb = cb1 ? xr[32] : 0.0f;
+        bs0 += ya; bs1 += yb;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xa, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xb, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xa, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = c0 + 32 * b + i;
+            if (c >= Kc) continue;
+            const int f = f0 + ((ENC && c < 168) ? (c % 7) * 24 + c / 7 : c);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * a + KPN_ROWMAP(r, kk);
+                if (o < M) kpn_atomic_add(dW + (size_t)o * in_dim + f, acc[a][b][r]);
+            }
+        }
+    if (db != nullptr && blockIdx.z == 0) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (kk == 0) {
+            if (oa0) kpn_atomic_add(db + o0 + i, bs0);
+            if (oa1) kpn_atomic_add(db + o0 + 32 + i, bs1);
+        }
+    }
+}

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
         // a_v = in_v * all(fg) * all(in) * dropout_v (model.py:739,748); valid = sum_v a_v > 0 (utils.py:643-646)
         is_valid = all_in && all_fg && ((sc.keep & ((1u << sc.V) - 1u)) != 0u);
         if (valid) valid[n] = (uint8_t)is_valid;
-        if (!is_valid) {
+        if (!is_valid && out) {
             // every view masked: pooled features are exactly 0 and the IBR softmax is uniform, so the
             // reference's result is a constant + the plain average of the sampled source colours
             float* o = out + n * 5;

@@ -12,6 +12,7 @@
 // kernels (ray_kernels.hip / field_kernels.hip)
 #include "ray_kernels.hip"
 #include "field_kernels.hip"
+#include "field_bwd_kernels.hip"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -80,6 +81,24 @@ void pack_segment(float* packed, int seg, const float* W, const float* b, int ou
             for (int r = 0; r < 16; ++r) {
                 const int orow = omap(ob * 32 + KPN_ROWMAP(r, h));
                 bb[(ob * 2 + h) * 16 + r] = (with_bias && orow >= 0 && orow < out_dim) ? b[orow] : 0.0f;
+            }
+}
+// a transposed (backward) segment: out row R of the stream is forward INPUT feature in_of_row(R), K-step (s,h) is
+// forward OUTPUT feature chain_feature(s,h); value W[o][f]
+template <class RowMap>
+void pack_segment_t(float* packed, int bseg, const float* W, int out_dim, int in_dim, RowMap in_of_row) {
+    const int KS = kpn_bseg_shapes[bseg].ks, NOB = kpn_bseg_shapes[bseg].nob, G = kpn_bseg_shapes[bseg].g;
+    const int NF = G * NOB;
+    float* w = packed + kpn_bseg_woff(bseg);
+    for (int s = 0; s < KS; ++s)
+        for (int ob = 0; ob < NOB; ++ob)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                const int f = in_of_row(ob * 32 + i);
+                const int o = chain_feature(s, h);
+                float val = 0.0f;
+                if (f >= 0 && f < in_dim && o < out_dim) val = W[(size_t)o * in_dim + f];
+                w[((size_t)(s / G) * 64 + lane) * NF + (s % G) * NOB + ob] = val;
             }
 }
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
@@ -153,6 +172,11 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
     pack_row(ROW_V1_VIS, pl.w[P_V1_1] + 32 * 32, 32, pl.b[P_V1_1][32]);
     pack_row(ROW_V2_1, pl.w[P_V2_1], 32, pl.b[P_V2_1][0]);
     pack_row(ROW_O_2, pl.w[P_O_2], 8, pl.b[P_O_2][0]);
+    // backward of layers1 (kpn_geo_rows_backward): the transposed matrices
+    pack_segment_t(P, BSEG_G1_3T, pl.w[P_G1_3], 64, 120, ident);
+    pack_segment_t(P, BSEG_G1_2T, pl.w[P_G1_2], 120, 136, [](int R) { return R < 128 ? R : (R < 136 ? R : -1); });
+    pack_segment_t(P, BSEG_G1_1T, pl.w[P_G1_1], 128, 128, ident);
+    pack_segment_t(P, BSEG_G1_0T, pl.w[P_G1_0], 128, 232, [](int R) { return R < 64 ? 168 + R : -1; });
     // scalars: |ani_al| (model.py:1287) and layers2(0), the query() result of a fully masked point
     float* sc = P + kpn_scalar_off();
     sc[0] = fabsf(pl.ani_al);
@@ -380,6 +404,100 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
     if (ws_bytes < query_layout(N, d->n_views).total) return fail(KPN_EWORKSPACE, "query workspace too small");
     kpn_points ps{pts, view, nullptr, nullptr, nullptr, 1};
     return run_field(scene_dev(d, scene_ws), ps, wp, N, mode, out, valid, ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the geometry rows
+namespace {
+const int64_t kBwdChunk = 65536;  // points per pass: V=3 -> 196608 rows x 4.3 KB of dumps = 0.84 GB
+struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, total; int64_t chunk; };
+BwdLayout bwd_layout(int64_t N, int V) {
+    BwdLayout L;
+    L.chunk = N < kBwdChunk ? N : kBwdChunk;
+    const size_t rows = (size_t)((L.chunk + KPN_TILE - 1) / KPN_TILE) * KPN_TILE * V;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
+    L.count = take(256);
+    L.list = take((size_t)L.chunk * sizeof(int));
+    L.X0 = take(rows * KPN_LDX0 * 4); L.X1 = take(rows * 128 * 4); L.X2 = take(rows * KPN_LDX2 * 4); L.X3 = take(rows * 128 * 4);
+    L.D0 = take(rows * 128 * 4); L.D1 = take(rows * 128 * 4); L.D2 = take(rows * 128 * 4); L.D3 = take(rows * 64 * 4);
+    L.total = o;
+    return L;
+}
+size_t plain_w_off(int layer) {
+    size_t o = 0;
+    for (int l = 0; l < layer; ++l) o += (size_t)plain_dims[l][0] * plain_dims[l][1] + plain_dims[l][0];
+    return o;
+}
+}  // namespace
+
+// rows of the current pass, from the device-side valid count
+__global__ void k_bwd_rows(const int* __restrict__ count, int V, int64_t* __restrict__ rows) {
+    *rows = (int64_t)((*count + KPN_TILE - 1) / KPN_TILE) * KPN_TILE * V;
+}
+
+extern "C" size_t kpn_geo_rows_backward_workspace_bytes(int64_t N, int32_t V) {
+    if (N <= 0 || V <= 0) return 0;
+    return bwd_layout(N, V).total;
+}
+
+extern "C" int kpn_geo_rows_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N,
+                                     const float* pts, uint32_t keep_mask, const float* d_x, float* d_plain, float* d_geo0,
+                                     float* d_geo1, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
+    if (N == 0) return KPN_OK;
+    KPN_REQUIRE(scene_ws && wp && pts && d_x && d_plain && d_geo0 && d_geo1 && ws, "null pointer");
+    const int V = d->n_views;
+    const BwdLayout L = bwd_layout(N, V);
+    if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "geo-rows backward workspace too small");
+    kpn_scene_dev sc = scene_dev(d, scene_ws);
+    sc.keep = keep_mask;
+    char* base = static_cast<char*>(ws);
+    int* count = reinterpret_cast<int*>(base + L.count);
+    int64_t* rows_dev = reinterpret_cast<int64_t*>(base + L.count + 64);
+    int* list = reinterpret_cast<int*>(base + L.list);
+    kpn_bwd_bufs B;
+    B.X0 = reinterpret_cast<float*>(base + L.X0); B.X1 = reinterpret_cast<float*>(base + L.X1);
+    B.X2 = reinterpret_cast<float*>(base + L.X2); B.X3 = reinterpret_cast<float*>(base + L.X3);
+    B.D0 = reinterpret_cast<float*>(base + L.D0); B.D1 = reinterpret_cast<float*>(base + L.D1);
+    B.D2 = reinterpret_cast<float*>(base + L.D2); B.D3 = reinterpret_cast<float*>(base + L.D3);
+    B.dgeo0 = d_geo0; B.dgeo1 = d_geo1;
+    float* dW[4]; float* dB[4];
+    for (int l = 0; l < 4; ++l) {
+        dW[l] = d_plain + plain_w_off(P_G1_0 + l);
+        dB[l] = dW[l] + (size_t)plain_dims[P_G1_0 + l][0] * plain_dims[P_G1_0 + l][1];
+    }
+    const int blocks = field_grid_blocks();
+    for (int64_t c0 = 0; c0 < N; c0 += L.chunk) {
+        const int64_t n = (N - c0 < L.chunk) ? (N - c0) : L.chunk;
+        kpn_points ps{pts + c0 * 3, pts + c0 * 3, nullptr, nullptr, nullptr, 1, nullptr, 0.0f};
+        hipMemsetAsync(count, 0, 4 * sizeof(int), (hipStream_t)stream);
+        KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
+                   (uint8_t*)nullptr, list, count);
+        KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, (const int*)count, V, rows_dev);
+        KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1,
+                   d_x + c0 * V * 64, B);
+        const int64_t max_rows = (n + KPN_TILE - 1) / KPN_TILE * KPN_TILE * V;
+        auto wgrad = [&](auto enc, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
+            const int gy = (M + 63) / 64, gz = (Kc + 63) / 64;
+#ifdef KPN_SIMT_EMU
+            int splits = 1;
+#else
+            int splits = (int)(max_rows / 512);
+            const int cap = 1024 / (gy * gz);
+            if (splits > cap) splits = cap;
+            if (splits < 1) splits = 1;
+#endif
+            KPN_LAUNCH(k_weight_grad<decltype(enc)::value>, dim3(splits, gy, gz), dim3(256), stream, dY, ldy, M, X, ldx, Kc,
+                       (const int64_t*)rows_dev, dW[layer], plain_dims[P_G1_0 + layer][1], 0, dB[layer]);
+        };
+        wgrad(kpn_ic<1>{}, B.D0, 128, 128, B.X0, KPN_LDX0, 232, 0);
+        wgrad(kpn_ic<0>{}, B.D1, 128, 128, B.X1, 128, 128, 1);
+        wgrad(kpn_ic<0>{}, B.D2, 128, 120, B.X2, KPN_LDX2, 136, 2);
+        wgrad(kpn_ic<0>{}, B.D3, 64, 64, B.X3, 128, 120, 3);
+    }
+    return check_launch("geo rows backward");
 }
 
 // ---------------------------------------------------------------------------------------------

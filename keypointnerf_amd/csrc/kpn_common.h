@@ -30,6 +30,17 @@ typedef const kpn_f32x4* kpn_lptr4;
 #define KPN_GLOBAL4(p) ((kpn_gptr4)(p))
 #define KPN_LDS4(p) ((kpn_lptr4)(p))
 #endif
+#ifndef KPN_SIMT_EMU
+// hardware global_atomic_add_f32 (no CAS loop); the sum order is not deterministic
+__device__ __forceinline__ void kpn_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+#else
+static inline void kpn_atomic_add(float* p, float v) {
+    uint32_t* u = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
+    do { float f; memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); }
+    while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+#endif
 __device__ __forceinline__ float kpn_fast_exp(float x) { return kpn_exp2(x * 1.44269504088896341f); }
 
 #define KPN_NKPT 24
@@ -104,11 +115,27 @@ constexpr int kpn_scalar_off() { return kpn_seg_woff(SEG_COUNT); }
 // row vector layout [2 halves][16 regs] weights, then [bias, 0, 0, 0]
 enum { ROW_V1_VIS, ROW_V2_1, ROW_O_2, ROW_COUNT };  // vis_layer1.2 row 32, vis_layer2.2, out_layer.4
 constexpr int kpn_row_off(int row) { return kpn_scalar_off() + 4 + row * 36; }
-constexpr int kpn_packed_floats() { return kpn_row_off(ROW_COUNT); }
+constexpr int kpn_fwd_floats() { return kpn_row_off(ROW_COUNT); }
 // everything k_fuse_color reads (segments SEG_G2_0.., scalars, row vectors) is one contiguous region
 // of 136.8 KB: it is copied into LDS once per (persistent) workgroup
 constexpr int kpn_k2_base() { return kpn_seg_woff(SEG_G2_0); }
-constexpr int kpn_k2_floats() { return kpn_packed_floats() - kpn_k2_base(); }
+constexpr int kpn_k2_floats() { return kpn_fwd_floats() - kpn_k2_base(); }
+
+// Backward segments (appended after the forward region): the TRANSPOSED layers1 matrices, streamed exactly
+// like forward segments (dX^T = W^T * dY^T is one more chained layer: the lane-register layout of an
+// accumulator is the B operand layout of the next MFMA layer in either direction).  No bias part is used.
+//   BSEG_G1_3T : dY3(64)  -> dX3(120 of 128)          BSEG_G1_2T : dA2(120 of 128) -> [dX2 chained 128 | hd 8 (block 4)]
+//   BSEG_G1_1T : dA1(128) -> dX1(128)                 BSEG_G1_0T : dA0(128) -> d(geometry channels 64)
+enum { BSEG_G1_3T, BSEG_G1_2T, BSEG_G1_1T, BSEG_G1_0T, BSEG_COUNT };
+#define KPN_BSEG_SHAPES {32, 4, 4}, {64, 5, 4}, {64, 4, 4}, {64, 2, 4}
+static constexpr kpn_seg_shape kpn_bseg_shapes[BSEG_COUNT] = {KPN_BSEG_SHAPES};
+constexpr int kpn_bseg_wfloats(int seg) { return kpn_bseg_shapes[seg].ks * kpn_bseg_shapes[seg].nob * 64; }
+constexpr int kpn_bseg_woff(int seg) {
+    int o = kpn_fwd_floats();
+    for (int i = 0; i < seg; ++i) o += kpn_bseg_wfloats(i);
+    return o;
+}
+constexpr int kpn_packed_floats() { return kpn_bseg_woff(BSEG_COUNT); }
 
 // Row scratch written by k_geo_rows and read by k_fuse_color: per work item (tile, view) KPN_ROW_SLABS
 // slabs of [64 lanes] float4.  Slabs 0..7: the lane's 32 registers of the 64-vector (block b = slab/4);

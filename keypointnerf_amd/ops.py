@@ -211,6 +211,30 @@ def query(scene, weights, pts, view, mode=0):
     return out.view(1, N, 5), valid.view(1, N, 1).bool()
 
 
+def geo_rows_backward(scene, weights, pts, d_x, keep_mask=0xFFFFFFFF):
+    """Reverse pass of the per-(point,view) geometry rows (kpn_geo_rows_backward): MLPUNet.layers1 and the
+    feat_geo gathers (reference src/utils.py:691-716, src/model.py:763-765).
+    pts (1,N,3) or (N,3); d_x (N,V,64) = d loss / d layers1-output.  Returns (d_plain, d_geo0, d_geo1):
+    d_plain flat like weights.flatten_plain (feed it to weights.plain_grads_to_state_dict), d_geo* shaped
+    like feat_geo[*] (NCHW views of the channels-last accumulators)."""
+    L = kl.get_library()
+    p = _dev(pts, "pts").reshape(-1, 3)
+    N, V = p.shape[0], scene.n_views
+    g = _dev(d_x, "d_x")
+    if tuple(g.shape) != (N, V, 64):
+        raise ValueError(f"d_x must be (N, V, 64) = {(N, V, 64)}, got {tuple(g.shape)}")
+    d = scene.desc
+    d_plain = torch.zeros(L.kpn_plain_weight_floats(), dtype=_f32, device=p.device)
+    d_g0 = torch.zeros(V, d.geo0_h, d.geo0_w, 64, dtype=_f32, device=p.device)
+    d_g1 = torch.zeros(V, d.geo1_h, d.geo1_w, 8, dtype=_f32, device=p.device)
+    if N > 0:
+        nb = L.kpn_geo_rows_backward_workspace_bytes(N, V)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=p.device)
+        L.check(L.kpn_geo_rows_backward(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), N, _p(p), int(keep_mask) & 0xFFFFFFFF,
+                                        _p(g), _p(d_plain), _p(d_g0), _p(d_g1), _p(ws), nb, _stream()))
+    return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2)
+
+
 class RenderPlan:
     """Pre-allocated outputs + workspace for repeated renders of one pixel grid (no per-call allocation)."""
 

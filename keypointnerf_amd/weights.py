@@ -59,3 +59,32 @@ def flatten_plain(eff):
         parts.append(b.reshape(-1))
     parts.append(np.array([eff["ani_al"]], dtype=np.float32))
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+def plain_grads_to_state_dict(state_dict, d_plain):
+    """Gradient w.r.t. the flat effective parameters (the layout of ``flatten_plain``; what
+    ``kpn_geo_rows_backward`` accumulates) -> gradient w.r.t. the reference's own parameters
+    (``weight_g`` / ``weight_v`` / ``bias`` / ``weight``), by differentiating the weight-norm fold
+    ``torch._weight_norm(v, g, 0)`` (reference src/utils.py:542-543).  Returns {state-dict key: grad tensor}."""
+    sd = _strip_prefix(state_dict)
+    d_plain = torch.as_tensor(d_plain).detach().float().cpu()
+    grads, off = {}, 0
+    for name, prefix, shape, wn in HOTPATH_LAYERS:
+        n = shape[0] * shape[1]
+        dW = d_plain[off:off + n].reshape(shape); off += n
+        db = d_plain[off:off + shape[0]]; off += shape[0]
+        grads[prefix + ".bias"] = db.clone()
+        if wn and (prefix + ".weight_g") in sd:
+            g = sd[prefix + ".weight_g"].detach().float().cpu().requires_grad_(True)
+            v = sd[prefix + ".weight_v"].detach().float().cpu().requires_grad_(True)
+            dg, dv = torch.autograd.grad(torch._weight_norm(v, g, 0), [g, v], dW)
+            grads[prefix + ".weight_g"], grads[prefix + ".weight_v"] = dg, dv
+        elif (prefix + ".parametrizations.weight.original0") in sd:
+            g = sd[prefix + ".parametrizations.weight.original0"].detach().float().cpu().requires_grad_(True)
+            v = sd[prefix + ".parametrizations.weight.original1"].detach().float().cpu().requires_grad_(True)
+            dg, dv = torch.autograd.grad(torch._weight_norm(v, g, 0), [g, v], dW)
+            grads[prefix + ".parametrizations.weight.original0"], grads[prefix + ".parametrizations.weight.original1"] = dg, dv
+        else:
+            grads[prefix + ".weight"] = dW.clone()
+    grads["mlp_tex.ani_al"] = d_plain[off:off + 1].clone()
+    return grads

@@ -741,3 +741,165 @@ void kpo_rgba2out_backward(const float* rgba, const float* z, int64_t R, int S, 
     }
     free(T);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Reverse pass of the per-(point, view) geometry rows — what autograd computes for
+ * MLPUNet.layers1 (utils.py:691-716: Linear/Softplus(beta=100) x3 + Linear, skip of feat_geo[1] at layer 2)
+ * and for the two feat_sample calls that feed it (model.py:763-765; grid_sample bilinear/border/align_corners
+ * backward w.r.t. the INPUT map = scatter of the 4 tap weights; the sample positions carry no gradient to
+ * any parameter).  Scalar reverse mode, fp32 activations, fp64 accumulation of the parameter / map sums.
+ *   d_x (N,V,64): upstream gradient of x_view = layers1 output; ignored for masked points and dropped views
+ *   d_w: += into a flat vector laid out like wflat (only layers1 entries are touched)
+ *   d_geo0 (V,64,g0h,g0w), d_geo1 (V,8,g1h,g1w): += , NCHW like the inputs. */
+static void scatter_bilinear(double* dmap, int C, int h, int w, float xn, float yn, const float* g) {
+    float ix = ((xn + 1.0f) / 2.0f) * (float)(w - 1);
+    float iy = ((yn + 1.0f) / 2.0f) * (float)(h - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(w - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(h - 1));
+    float fx = floorf(ix), fy = floorf(iy);
+    int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
+    float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
+    int x1ok = x1 <= w - 1, y1ok = y1 <= h - 1;
+    size_t plane = (size_t)h * w;
+    for (int c = 0; c < C; ++c) {
+        double* m = dmap + (size_t)c * plane;
+        double gc = g[c];
+#pragma omp atomic
+        m[(size_t)y0 * w + x0] += gc * wnw;
+        if (x1ok) {
+#pragma omp atomic
+            m[(size_t)y0 * w + x1] += gc * wne;
+        }
+        if (y1ok) {
+#pragma omp atomic
+            m[(size_t)y1 * w + x0] += gc * wsw;
+        }
+        if (x1ok && y1ok) {
+#pragma omp atomic
+            m[(size_t)y1 * w + x1] += gc * wse;
+        }
+    }
+}
+static inline float softplus100_grad(float x) { /* ATen softplus_backward: z = exp(x*beta); x*beta > threshold ? 1 : z/(z+1) */
+    float t = x * 100.0f;
+    if (t > 20.0f) return 1.0f;
+    float z = expf(t);
+    return z / (z + 1.0f);
+}
+
+void kpo_geo_rows_backward(const kpo_scene* sc, const float* wflat, int64_t N, const float* pts, uint32_t keep,
+                           const float* d_x, float* d_w, float* d_geo0, float* d_geo1) {
+    kpo_weights wt;
+    kpo_bind_weights(wflat, &wt);
+    const int V = sc->V;
+    float kcam[KPO_MAXV][KPO_NKPT][3];
+    for (int v = 0; v < V; ++v) {
+        const float* E = sc->extrin + v * 16;
+        for (int k = 0; k < KPO_NKPT; ++k)
+            for (int i = 0; i < 3; ++i)
+                kcam[v][k][i] = ((sc->kpt3d[k * 3 + 0] * E[i * 4 + 0] + sc->kpt3d[k * 3 + 1] * E[i * 4 + 1]) +
+                                 sc->kpt3d[k * 3 + 2] * E[i * 4 + 2]) + E[i * 4 + 3];
+    }
+    const float pe_vec[KPO_PE_LEVELS] = {(float)(M_PI * 1.0), (float)(M_PI * 2.0), (float)(M_PI * 4.0)};
+    const float two_sigma2 = (float)(2.0 * ((double)sc->sigma * (double)sc->sigma));
+    const size_t HW = (size_t)sc->H * sc->W;
+    const int dims[4][2] = {{128, 232}, {128, 128}, {120, 136}, {64, 120}};
+    size_t woff[4], boff[4], nparam = 0;
+    for (int l = 0; l < 4; ++l) { woff[l] = nparam; nparam += (size_t)dims[l][0] * dims[l][1]; boff[l] = nparam; nparam += dims[l][0]; }
+    const size_t n_g0 = (size_t)V * 64 * sc->g0h * sc->g0w, n_g1 = (size_t)V * 8 * sc->g1h * sc->g1w;
+    double* g0acc = (double*)calloc(n_g0, sizeof(double));
+    double* g1acc = (double*)calloc(n_g1, sizeof(double));
+    double* wacc = (double*)calloc(nparam, sizeof(double));
+
+#pragma omp parallel
+    {
+        double* wloc = (double*)calloc(nparam, sizeof(double));
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t n = 0; n < N; ++n) {
+            const float* p = pts + n * 3;
+            float xn[KPO_MAXV], yn[KPO_MAXV];
+            int all_in = 1, all_fg = 1;
+            for (int v = 0; v < V; ++v) { /* model.py:713-739, as in kpo_query_ex */
+                const float* M = sc->KRT + v * 16;
+                float vh[3];
+                for (int i = 0; i < 3; ++i)
+                    vh[i] = ((p[0] * M[i * 4 + 0] + p[1] * M[i * 4 + 1]) + p[2] * M[i * 4 + 2]) + M[i * 4 + 3];
+                float z = vh[2], x = vh[0] / z, y = vh[1] / z;
+                xn[v] = 2.0f * (x / ((float)sc->W - 1.0f)) - 1.0f;
+                yn[v] = 2.0f * (y / ((float)sc->H - 1.0f)) - 1.0f;
+                float zn = 2.0f * (z - sc->znear) / (sc->zfar - sc->znear) - 1.0f;
+                const float eps = 1e-2f;
+                all_in &= (xn[v] >= -1.0f - eps) && (xn[v] <= 1.0f + eps) && (yn[v] >= -1.0f - eps) && (yn[v] <= 1.0f + eps) &&
+                          (zn >= -1.0f);
+                if (!sc->disable_fg_mask) {
+                    float m;
+                    sample_bilinear(sc->fgmask + (size_t)v * HW, 1, sc->H, sc->W, xn[v], yn[v], &m);
+                    all_fg &= (m > 0.1f);
+                }
+            }
+            if (!(all_in && all_fg) || (keep & ((1u << V) - 1u)) == 0u) continue;
+            for (int v = 0; v < V; ++v) {
+                if (!((keep >> v) & 1u)) continue;
+                float x0[232], a0[128], x1[128], a1[128], x2[136], a2[120], x3[120], y3[64];
+                const float* E = sc->extrin + v * 16;
+                float c[3];
+                for (int i = 0; i < 3; ++i)
+                    c[i] = ((p[0] * E[i * 4 + 0] + p[1] * E[i * 4 + 1]) + p[2] * E[i * 4 + 2]) + E[i * 4 + 3];
+                for (int k = 0; k < KPO_NKPT; ++k) { /* spatial.py:110-118 */
+                    float dx = c[0] - kcam[v][k][0], dy = c[1] - kcam[v][k][1], dz = c[2] - kcam[v][k][2];
+                    float d2 = (dx * dx + dy * dy) + dz * dz;
+                    float w = expf(-d2 / two_sigma2);
+                    x0[k] = dz * w;
+                    for (int l = 0; l < KPO_PE_LEVELS; ++l) {
+                        float y = dz * pe_vec[l];
+                        x0[(1 + 2 * l) * KPO_NKPT + k] = sinf(y) * w;
+                        x0[(2 + 2 * l) * KPO_NKPT + k] = cosf(y) * w;
+                    }
+                }
+                sample_bilinear(sc->geo0 + (size_t)v * 64 * sc->g0h * sc->g0w, 64, sc->g0h, sc->g0w, xn[v], yn[v], x0 + KPO_PE_DIM);
+                linear(wt.w[L_G1_0], wt.b[L_G1_0], 128, 232, x0, a0);
+                for (int i = 0; i < 128; ++i) x1[i] = softplus100(a0[i]);
+                linear(wt.w[L_G1_1], wt.b[L_G1_1], 128, 128, x1, a1);
+                for (int i = 0; i < 128; ++i) x2[i] = softplus100(a1[i]);
+                sample_bilinear(sc->geo1 + (size_t)v * 8 * sc->g1h * sc->g1w, 8, sc->g1h, sc->g1w, xn[v], yn[v], x2 + 128);
+                linear(wt.w[L_G1_2], wt.b[L_G1_2], 120, 136, x2, a2);
+                for (int i = 0; i < 120; ++i) x3[i] = softplus100(a2[i]);
+                (void)y3;
+                /* reverse */
+                const float* dy3 = d_x + ((size_t)n * V + v) * 64;
+                float dx3[120], da2[120], dx2[136], da1[128], dx1[128], da0[128], dx0g[64];
+                const float* xs[4] = {x0, x1, x2, x3};
+                const float* dys[4];
+                /* layer 3: dX3 = W3^T dY3 */
+                for (int i = 0; i < 120; ++i) { float s = 0.0f; for (int o = 0; o < 64; ++o) s += wt.w[L_G1_3][o * 120 + i] * dy3[o]; dx3[i] = s; }
+                for (int i = 0; i < 120; ++i) da2[i] = dx3[i] * softplus100_grad(a2[i]);
+                for (int i = 0; i < 136; ++i) { float s = 0.0f; for (int o = 0; o < 120; ++o) s += wt.w[L_G1_2][o * 136 + i] * da2[o]; dx2[i] = s; }
+                for (int i = 0; i < 128; ++i) da1[i] = dx2[i] * softplus100_grad(a1[i]);
+                for (int i = 0; i < 128; ++i) { float s = 0.0f; for (int o = 0; o < 128; ++o) s += wt.w[L_G1_1][o * 128 + i] * da1[o]; dx1[i] = s; }
+                for (int i = 0; i < 128; ++i) da0[i] = dx1[i] * softplus100_grad(a0[i]);
+                for (int i = 0; i < 64; ++i) { float s = 0.0f; for (int o = 0; o < 128; ++o) s += wt.w[L_G1_0][o * 232 + 168 + i] * da0[o]; dx0g[i] = s; }
+                dys[0] = da0; dys[1] = da1; dys[2] = da2; dys[3] = dy3;
+                for (int l = 0; l < 4; ++l) {
+                    const int od = dims[l][0], id = dims[l][1];
+                    for (int o = 0; o < od; ++o) {
+                        const double g = dys[l][o];
+                        double* wr = wloc + woff[l] + (size_t)o * id;
+                        for (int i = 0; i < id; ++i) wr[i] += g * (double)xs[l][i];
+                        wloc[boff[l] + o] += g;
+                    }
+                }
+                scatter_bilinear(g0acc + (size_t)v * 64 * sc->g0h * sc->g0w, 64, sc->g0h, sc->g0w, xn[v], yn[v], dx0g);
+                scatter_bilinear(g1acc + (size_t)v * 8 * sc->g1h * sc->g1w, 8, sc->g1h, sc->g1w, xn[v], yn[v], dx2 + 128);
+            }
+        }
+#pragma omp critical
+        for (size_t i = 0; i < nparam; ++i) wacc[i] += wloc[i];
+        free(wloc);
+    }
+    /* layers1 are the first four layers of the flat layout, so offsets coincide */
+    for (size_t i = 0; i < nparam; ++i) d_w[i] += (float)wacc[i];
+    for (size_t i = 0; i < n_g0; ++i) d_geo0[i] += (float)g0acc[i];
+    for (size_t i = 0; i < n_g1; ++i) d_geo1[i] += (float)g1acc[i];
+    free(g0acc); free(g1acc); free(wacc);
+}

@@ -224,6 +224,54 @@ def run_rgba2out_grad_case(name, seed=11, R=40, S=24):
     print(f"{name}: |g|max={float(g_all.abs().max()):.3g} -> {path}")
 
 
+def run_geo_rows_grad_case(net, name, n_views, src_hw, mask, n_pts, seed, S=8):
+    """Gradients of the per-(point,view) geometry rows by the reference's own autograd: a forward hook on
+    net.mlp_geo.layers1 (MLPUNet, src/utils.py:691-720) captures x_view inside an unmodified net.query() call;
+    loss = sum(x_view * G) with G zeroed on masked points (their pooling weights are 0, so no gradient reaches
+    them in training).  Recorded: d loss / d (effective weight, bias, weight_g, weight_v) of layers1 and
+    d loss / d feat_geo[0], feat_geo[1]."""
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=(16, 16), mask=mask, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = scene["bounds"].reshape(2, 3)[0], scene["bounds"].reshape(2, 3)[1]
+    pts = (lo + (hi - lo) * torch.rand(n_pts, 3, generator=g))[None]
+    view = torch.nn.functional.normalize(torch.randn(n_pts, 3, generator=g), dim=-1)[None]
+    feat_geo = [f.clone().requires_grad_(True) for f in scene["feat_geo"]]
+    captured, eff = {}, {}
+    l1 = net.mlp_geo.layers1
+    hooks = [l1.register_forward_hook(lambda m, i, o: captured.__setitem__("x_view", o))]
+    for li, layer in enumerate(l1.layers):
+        def fh(m, i, o, li=li):
+            m.weight.retain_grad()
+            eff[li] = m.weight
+        hooks.append(layer.linear.register_forward_hook(fh))
+    net.eval()
+    out, valid = net.query(pts, scene["cam"], feat_geo, scene["feat_tex"], n_views=n_views, view=view, nerf=True,
+                           sp_data=dict(scene["sp_data"]), tx_data={"img": scene["img"]}, bbox_center=None, n_pts_samples=S,
+                           src_foreground_mask=scene["src_foreground_mask"])
+    for h in hooks:
+        h.remove()
+    x_view = captured["x_view"]                                           # (B, V, N, 64)
+    assert x_view.shape == (1, n_views, n_pts, 64), x_view.shape
+    G = torch.randn(x_view.shape, generator=g) * valid.reshape(1, 1, n_pts, 1).float()
+    params = dict(l1.named_parameters())
+    net.zero_grad()
+    (x_view * G).sum().backward()
+    d = scene_to_npz(scene)
+    d.update({"cfg": np.array([n_views, 0, 0, 0, 0, 0], np.int64), "pts": _np(pts[0]), "view": _np(view[0]), "valid": _np(valid).reshape(-1), "x_view": _np(x_view[0]),
+              "G": _np(G[0].permute(1, 0, 2)),                             # (N, V, 64), the C-ABI layout
+              "d_geo0": _np(feat_geo[0].grad), "d_geo1": _np(feat_geo[1].grad)})
+    for li in range(4):
+        d[f"dW{li}"] = _np(eff[li].grad)
+        d[f"db{li}"] = _np(params[f"layers.{li}.linear.bias"].grad)
+    for k, v in params.items():
+        d["param_grad." + k] = _np(v.grad)
+    net.zero_grad()
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: N={n_pts} valid={float(valid.float().mean()):.3f} |dW0|max={float(eff[0].grad.abs().max()):.3g} "
+          f"|d_geo0|max={float(feat_geo[0].grad.abs().max()):.3g} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def run_output_case(name, seed=9):
     """Output side: the reference's own frame arrangement / quantisation / PSNR."""
     rmodel = ref_shim.load_reference()
@@ -263,6 +311,7 @@ def main():
     # F/G: train branch with recorded random draws (seeds chosen so that at least one view is dropped in one of them)
     run_train_case(net, "case_f_v3_train", 3, (64, 64), (32, 32), "dense", 12, 12, seed=5)
     run_train_case(net, "case_g_v4_train", 4, (48, 80), (32, 48), "ellipsoid", 16, 8, seed=8)
+    run_geo_rows_grad_case(net, "case_i_v3_geo_rows_grad", 3, (64, 64), "ellipsoid", 600, seed=12)
 
 
 if __name__ == "__main__":

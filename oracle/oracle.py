@@ -220,3 +220,17 @@ def rgba2out_backward(rgba, z, d_color=None, d_depth=None, d_alpha=None, d_sdf=N
     g = [None if x is None else _f32(x).reshape(-1) for x in (d_color, d_depth, d_alpha, d_sdf)]
     lib().kpo_rgba2out_backward(_ptr(rgba), _ptr(z), ctypes.c_int64(R), ctypes.c_int(S), *[_ptr(x) if x is not None else None for x in g], _ptr(out))
     return out
+
+
+def geo_rows_backward(oscene, wflat, pts, d_x, keep=0xFFFFFFFF):
+    """Reverse pass of layers1 + the feat_geo gathers (kpo_geo_rows_backward).
+    Returns (d_w flat like wflat, d_geo0 (V,64,h,w), d_geo1 (V,8,h,w))."""
+    pts = _f32(pts).reshape(-1, 3)
+    N = pts.shape[0]
+    d_x = _f32(d_x).reshape(N, oscene.V, 64)
+    d_w = np.zeros_like(wflat)
+    d_g0 = np.zeros_like(oscene.bufs["geo0"])
+    d_g1 = np.zeros_like(oscene.bufs["geo1"])
+    lib().kpo_geo_rows_backward(ctypes.byref(oscene.struct), _ptr(wflat), ctypes.c_int64(N), _ptr(pts), ctypes.c_uint32(keep),
+                                _ptr(d_x), _ptr(d_w), _ptr(d_g0), _ptr(d_g1))
+    return d_w, d_g0, d_g1

@@ -266,3 +266,47 @@ def test_rgba2out_autograd(ops):
     scale = g2[ok].abs().amax((-1, -2), keepdim=True)
     assert ((g1[ok] - g2[ok]).abs() <= 2e-4 * scale + 1e-6).all()
     assert torch.isfinite(g1).all()  # the hand-written backward has no 1/(1-a) and stays finite everywhere
+
+
+def test_geo_rows_backward(ops, golden_weights):
+    """kpn_geo_rows_backward on the MI355X: (a) the reference's own autograd numbers (golden case i); (b) with a
+    dropped view against the oracle; (c) the weight-norm parameter gradients (weight_g / weight_v / bias) the
+    reference's optimizer would see; (d) linearity in the upstream gradient at a training-batch size."""
+    from oracle import oracle
+    from keypointnerf_amd.weights import plain_grads_to_state_dict
+    from tests.test_kernels_simt import assert_geo_grads_close, golden_geo_grads
+    sd, w = golden_weights
+    scene, cfg, g = load_case("case_i_v3_geo_rows_grad")
+    s, ps = _prep(ops, scene)
+    pts, G = torch.from_numpy(g["pts"]).cuda(), torch.from_numpy(g["G"]).cuda()
+    npy = lambda r: (r[0].cpu().numpy(), r[1].cpu().numpy(), r[2].cpu().numpy())
+    got = npy(ops.geo_rows_backward(ps, w, pts, G))
+    assert_geo_grads_close(got, golden_geo_grads(g), 3e-5)
+    osc, wflat = oracle.OracleScene(scene), oracle.flat_weights(sd)
+    got = npy(ops.geo_rows_backward(ps, w, pts, G, keep_mask=0b110))
+    assert_geo_grads_close(got, oracle.geo_rows_backward(osc, wflat, g["pts"], g["G"], keep=0b110), 1e-5)
+    # (c)
+    got = ops.geo_rows_backward(ps, w, pts, G)
+    pg = plain_grads_to_state_dict(sd, got[0])
+    for k in g:
+        if k.startswith("param_grad."):
+            name = "mlp_geo.layers1." + k[len("param_grad."):]
+            ref = g[k]
+            assert np.abs(pg[name].numpy() - ref).max() <= 3e-5 * np.abs(ref).max() + 1e-7, name
+    # (d) 1024 rays x 192 samples of a training batch (SURVEY section 8 config 4 shape): grad(G1 + 2 G2) = grad(G1) + 2 grad(G2)
+    from keypointnerf_amd.synthetic import make_scene
+    big = make_scene(n_views=3, src_hw=(256, 256), tar_hw=(64, 64), mask="ellipsoid", seed=21)
+    sb, pb = _prep(ops, big)
+    N = 1024 * 192
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    lo, hi = sb["bounds"].reshape(2, 3)[0], sb["bounds"].reshape(2, 3)[1]
+    P = lo + (hi - lo) * torch.rand(N, 3, device="cuda", generator=gen)
+    G1 = torch.randn(N, 3, 64, device="cuda", generator=gen)
+    G2 = torch.randn(N, 3, 64, device="cuda", generator=gen)
+    wr = ops.PackedWeights(sd)
+    a, b, c = (ops.geo_rows_backward(pb, wr, P, x) for x in (G1, G2, G1 + 2 * G2))
+    for i in range(3):
+        ref = a[i] + 2 * b[i]
+        assert torch.isfinite(c[i]).all()
+        assert (c[i] - ref).abs().max() <= 2e-4 * ref.abs().max(), i
+    assert a[0].abs().max() > 0 and a[1].abs().max() > 0

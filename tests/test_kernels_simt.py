@@ -147,3 +147,53 @@ def test_rgba2out_backward_kernel(env):
     out2 = np.zeros((R, S, 5), np.float32)
     lib.check(lib.kpn_rgba2out_backward(sh.ptr(rgba), sh.ptr(z), R, S, sh.ptr(gs[0]), None, None, None, sh.ptr(out2), None))
     assert_grad_close(out2, g["g_color_only"][0])
+
+
+GEO_LAYERS = [(128, 232), (128, 128), (120, 136), (64, 120)]
+
+
+def split_layers1(d_plain):
+    """flat plain gradient -> [(dW, db)] of layers1.0..3 and the untouched remainder."""
+    off, out = 0, []
+    for o, i in GEO_LAYERS:
+        out.append((d_plain[off:off + o * i].reshape(o, i), d_plain[off + o * i:off + o * i + o]))
+        off += o * i + o
+    return out, d_plain[off:]
+
+
+def assert_geo_grads_close(got, ref, rtol):
+    """got/ref = (d_plain, d_geo0, d_geo1); per-tensor max-norm relative tolerance."""
+    (gl, grest), (rl, _) = split_layers1(got[0]), split_layers1(ref[0])
+    for li, ((gw, gb), (rw, rb)) in enumerate(zip(gl, rl)):
+        assert np.abs(gw - rw).max() <= rtol * np.abs(rw).max(), (li, "W", np.abs(gw - rw).max(), np.abs(rw).max())
+        assert np.abs(gb - rb).max() <= rtol * np.abs(rb).max(), (li, "b", np.abs(gb - rb).max(), np.abs(rb).max())
+    assert np.all(grest == 0)
+    for k in (1, 2):
+        assert np.abs(got[k] - ref[k]).max() <= rtol * np.abs(ref[k]).max(), (k, np.abs(got[k] - ref[k]).max())
+
+
+def golden_geo_grads(g):
+    d_plain = np.concatenate([np.concatenate([g[f"dW{li}"].reshape(-1), g[f"db{li}"].reshape(-1)]) for li in range(4)])
+    return d_plain, g["d_geo0"], g["d_geo1"]
+
+
+def test_geo_rows_backward_kernels(env):
+    """k_geo_rows_bwd + k_weight_grad (emulated) against the reference's autograd (golden case i, 256 points) and,
+    with a view switched off by the train-time dropout, against the oracle."""
+    lib, packed, wflat = env
+    scene, cfg, g = load_case("case_i_v3_geo_rows_grad")
+    hs = sh.HostScene(lib, scene)
+    osc = oracle.OracleScene(scene)
+    N = 256
+    pts, G = g["pts"][:N], g["G"][:N]
+    got = sh.geo_rows_backward(lib, hs, packed, pts, G)
+    ref = oracle.geo_rows_backward(osc, wflat, pts, G)
+    assert_geo_grads_close(got, ref, 1e-5)
+    # all 600 points: the reference autograd's own numbers
+    got_all = sh.geo_rows_backward(lib, hs, packed, g["pts"], g["G"])
+    assert_geo_grads_close(got_all, golden_geo_grads(g), 3e-5)
+    # view 1 dropped
+    got = sh.geo_rows_backward(lib, hs, packed, pts, G, keep=0b101)
+    ref = oracle.geo_rows_backward(osc, wflat, pts, G, keep=0b101)
+    assert_geo_grads_close(got, ref, 1e-5)
+    assert np.all(got[1][1] == 0) and np.all(got[2][1] == 0)

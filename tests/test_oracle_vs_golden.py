@@ -159,3 +159,23 @@ def test_rgba2out_backward_vs_autograd_golden():
     o = oracle.rgba2out_backward(g["rgba"][0], g["z"][0], g["d_color"], g["d_depth"], g["d_alpha"], g["d_sdf"])
     assert_grad_close(o, g["g_all"][0])
     assert_grad_close(oracle.rgba2out_backward(g["rgba"][0], g["z"][0], g["d_color"]), g["g_color_only"][0])
+
+
+def test_geo_rows_backward_vs_reference_autograd():
+    """kpo_geo_rows_backward against the reference's own autograd through MLPUNet.layers1 + feat_sample
+    (golden case i: forward hook on net.mlp_geo.layers1 inside an unmodified net.query call)."""
+    scene, cfg, g = load_case("case_i_v3_geo_rows_grad")
+    sd = load_weights()
+    osc = oracle.OracleScene(scene)
+    wflat = oracle.flat_weights(sd)
+    d_w, d_g0, d_g1 = oracle.geo_rows_backward(osc, wflat, g["pts"], g["G"])
+    off = 0
+    for li, (o, i) in enumerate([(128, 232), (128, 128), (120, 136), (64, 120)]):
+        dW = d_w[off:off + o * i].reshape(o, i); off += o * i
+        db = d_w[off:off + o]; off += o
+        sW, sb = np.abs(g[f"dW{li}"]).max(), np.abs(g[f"db{li}"]).max()
+        assert np.abs(dW - g[f"dW{li}"]).max() <= 2e-5 * sW, (li, np.abs(dW - g[f"dW{li}"]).max(), sW)
+        assert np.abs(db - g[f"db{li}"]).max() <= 2e-5 * sb, (li, np.abs(db - g[f"db{li}"]).max(), sb)
+    assert np.all(d_w[off:] == 0)
+    for got, ref in ((d_g0, g["d_geo0"]), (d_g1, g["d_geo1"])):
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
