@@ -31,24 +31,20 @@ struct kpn_bwd_bufs {
     float* dgeo0;  // V x g0h x g0w x 64, accumulated
     float* dgeo1;  // V x g1h x g1w x 8, accumulated
 };
+#ifdef KPN_ABLATE_DUMP  // timing experiment only (wrong results): no activation / gradient dumps
+#define KPN_ST4(p, v) ((void)0)
+#define KPN_ST1(p, v) ((void)0)
+#else
+#define KPN_ST4(p, v) (*reinterpret_cast<float4*>(p) = (v))
+#define KPN_ST1(p, v) (*(p) = (v))
+#endif
+#define KPN_SCAT_LD 76  // 72 floats + pad: rows start on different banks, float4-aligned
 #define KPN_LDX0 232
 #define KPN_LDX2 136
 
 // d softplus100(a) / da from the softplus value itself: sigmoid(100 a) = 1 - exp(-100 softplus(a)); above the
 // threshold (softplus == a, 100 a > 20) this is 1 to within 2e-9, the reference's exact 1
 __device__ __forceinline__ float kpn_softplus100_grad_from_value(float sp) { return 1.0f - kpn_exp2(sp * -144.269504088896341f); }
-
-__device__ __forceinline__ void kpn_scatter4(float* __restrict__ map, int C, int c0, const kpn_taps& t, float g0, float g1,
-                                             float g2, float g3) {
-    const int offs[4] = {t.o00, t.o01, t.o10, t.o11};
-    const float ws[4] = {t.w00, t.w01, t.w10, t.w11};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float* d = map + (size_t)offs[k] * C + c0;
-        kpn_atomic_add(d + 0, g0 * ws[k]); kpn_atomic_add(d + 1, g1 * ws[k]);
-        kpn_atomic_add(d + 2, g2 * ws[k]); kpn_atomic_add(d + 3, g3 * ws[k]);
-    }
-}
 
 // dx: upstream gradient d loss / d x_view, [N][V][64] row-major, indexed by the ORIGINAL point index
 __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
@@ -62,6 +58,9 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
     const int nwork = ntiles * sc.V;
     const float pe_pi = 3.14159274101257324f;
     __shared__ __attribute__((aligned(16))) float bias_s[3][128];
+    __shared__ __attribute__((aligned(16))) float scat_s[4][KPN_TILE][KPN_SCAT_LD];  // per wave: 32 rows x (64 + 8 channels)
+    __shared__ __attribute__((aligned(16))) int4 tap_o[4][2][KPN_TILE];
+    __shared__ __attribute__((aligned(16))) float4 tap_w[4][2][KPN_TILE];
     {
         const int segs[3] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2};
         for (int i = threadIdx.x; i < 3 * 128; i += blockDim.x) bias_s[i >> 7][i & 127] = wp[kpn_seg_boff(segs[i >> 7]) + (i & 127)];
@@ -116,14 +115,14 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
                 x[5] = s4 * w; x[6] = c4 * w;
                 float* d = x0row + (12 * h + j) * 7;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) d[i] = x[i];
+                for (int i = 0; i < 7; ++i) KPN_ST1(d + i, x[i]);
             }, a0);
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
             kpn_mfma_layer<32, 4, 4>(wp + kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp0);
                 x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
-                *reinterpret_cast<float4*>(x0row + 168 + 32 * h + 4 * g) = f;
+                KPN_ST4(x0row + 168 + 32 * h + 4 * g, f);
             }, a0);
         }
         // chained group g of a 128-vector = features 32(g/4) + 8(g%4) + 4h .. +3 of this lane's row
@@ -133,19 +132,19 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
             constexpr int g = decltype(gi)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a0[g / 4][(g % 4) * 4 + i]);
-            *reinterpret_cast<float4*>(x1row + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
+            KPN_ST4(x1row + 32 * (g / 4) + 8 * (g % 4) + 4 * h, make_float4(x[0], x[1], x[2], x[3]));
         }, a1);
         kpn_f32x16 a2[4];
         {
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1);
-            *reinterpret_cast<float4*>(x2row + 128 + 4 * h) = f;
+            KPN_ST4(x2row + 128 + 4 * h, f);
             kpn_load_bias<4>(bias_s[2], h, a2);
             kpn_mfma_layer<68, 4, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 if constexpr (g < 16) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a1[g / 4][(g % 4) * 4 + i]);
-                    *reinterpret_cast<float4*>(x2row + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
+                    KPN_ST4(x2row + 32 * (g / 4) + 8 * (g % 4) + 4 * h, make_float4(x[0], x[1], x[2], x[3]));
                 } else {
                     x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
                 }
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
             float4 o;
             o.x = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 0]); o.y = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 1]);
             o.z = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 2]); o.w = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 3]);
-            *reinterpret_cast<float4*>(x3row + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = o;
+            KPN_ST4(x3row + 32 * (g / 4) + 8 * (g % 4) + 4 * h, o);
         }
 
         // ================= B phase =================
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
                 const float4 f = *reinterpret_cast<const float4*>(grow + col);
                 x[0] = f.x * live; x[1] = f.y * live; x[2] = f.z * live; x[3] = f.w * live;
-                *reinterpret_cast<float4*>(d3row + col) = make_float4(x[0], x[1], x[2], x[3]);
+                KPN_ST4(d3row + col, make_float4(x[0], x[1], x[2], x[3]));
             }, d3);
         }
         // dA2 = dX3 * softplus'(a2);  [dX2 | d hd] = W2^T dA2
@@ -194,11 +193,11 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
                 x[1] = d3[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d3[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
                 x[3] = d3[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
-                *reinterpret_cast<float4*>(drow + col) = make_float4(x[0], x[1], x[2], x[3]);
+                KPN_ST4(drow + col, make_float4(x[0], x[1], x[2], x[3]));
             }, d2);
         }
         // the 8 hd channels (rows 128..135 of dX2 = block 4 regs 0..3: channels 4h..4h+3) go back to feat_geo[1]
-        kpn_scatter4(bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1, d2[4][0], d2[4][1], d2[4][2], d2[4][3]);
+        const float4 dhd = make_float4(d2[4][0], d2[4][1], d2[4][2], d2[4][3]);
         // dA1 = dX2 * softplus'(a1);  dX1 = W1^T dA1
         kpn_f32x16 d1[4];
 #pragma unroll
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
                 x[1] = d2[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d2[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
                 x[3] = d2[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
-                *reinterpret_cast<float4*>(drow + col) = make_float4(x[0], x[1], x[2], x[3]);
+                KPN_ST4(drow + col, make_float4(x[0], x[1], x[2], x[3]));
             }, d1);
         }
         // dA0 = dX1 * softplus'(a0);  d geo0 = W0[:,168:232]^T dA0
@@ -234,81 +233,182 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
                 x[1] = d1[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d1[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
                 x[3] = d1[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
-                *reinterpret_cast<float4*>(drow + col) = make_float4(x[0], x[1], x[2], x[3]);
+                KPN_ST4(drow + col, make_float4(x[0], x[1], x[2], x[3]));
             }, dg);
         }
-        // block b, regs 4q..4q+3 of this lane = geometry channels 32b + 8q + 4h .. +3
+        // Scatter through the bilinear taps.  A lane holds 32 channels of ONE row; issued from this layout an atomic
+        // instruction would touch 32 different texels (cache lines).  The tile is transposed through LDS instead:
+        // lane = channel, so that one instruction adds 64 consecutive floats (two lines) of one texel.
         {
-            float* g0 = bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64;
+            const int w4 = threadIdx.x >> 6;
+            float* sg = scat_s[w4][0];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd)
-                    kpn_scatter4(g0, 64, 32 * b + 8 * qd + 4 * h, tp0, dg[b][4 * qd + 0], dg[b][4 * qd + 1], dg[b][4 * qd + 2],
-                                 dg[b][4 * qd + 3]);
+                    *reinterpret_cast<float4*>(sg + p * KPN_SCAT_LD + 32 * b + 8 * qd + 4 * h) =
+                        make_float4(dg[b][4 * qd + 0], dg[b][4 * qd + 1], dg[b][4 * qd + 2], dg[b][4 * qd + 3]);
+            *reinterpret_cast<float4*>(sg + p * KPN_SCAT_LD + 64 + 4 * h) = dhd;
+            if (h == 0) {
+                tap_o[w4][0][p] = make_int4(tp0.o00, tp0.o01, tp0.o10, tp0.o11);
+                tap_w[w4][0][p] = make_float4(tp0.w00 * live, tp0.w01 * live, tp0.w10 * live, tp0.w11 * live);
+            } else {
+                tap_o[w4][1][p] = make_int4(tp1.o00, tp1.o01, tp1.o10, tp1.o11);
+                tap_w[w4][1][p] = make_float4(tp1.w00 * live, tp1.w01 * live, tp1.w10 * live, tp1.w11 * live);
+            }
+            KPN_WAVE_SYNC();
+            float* g0 = bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64 + lane;
+            const int npt = min(KPN_TILE, count - t * KPN_TILE);
+            for (int pt = 0; pt < npt; ++pt) {
+                const float val = sg[pt * KPN_SCAT_LD + lane];
+                const int4 o = tap_o[w4][0][pt];
+                const float4 ww = tap_w[w4][0][pt];
+                kpn_atomic_add(g0 + (size_t)o.x * 64, val * ww.x); kpn_atomic_add(g0 + (size_t)o.y * 64, val * ww.y);
+                kpn_atomic_add(g0 + (size_t)o.z * 64, val * ww.z); kpn_atomic_add(g0 + (size_t)o.w * 64, val * ww.w);
+            }
+            // 8 hd channels: lane = (point pt8, channel c), 8 points per instruction
+            float* g1 = bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8 + (lane & 7);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int pt = grp * 8 + (lane >> 3);
+                if (pt < npt) {
+                    const float val = sg[pt * KPN_SCAT_LD + 64 + (lane & 7)];
+                    const int4 o = tap_o[w4][1][pt];
+                    const float4 ww = tap_w[w4][1][pt];
+                    kpn_atomic_add(g1 + (size_t)o.x * 8, val * ww.x); kpn_atomic_add(g1 + (size_t)o.y * 8, val * ww.y);
+                    kpn_atomic_add(g1 + (size_t)o.z * 8, val * ww.z); kpn_atomic_add(g1 + (size_t)o.w * 8, val * ww.w);
+                }
+            }
+            KPN_WAVE_SYNC();  // the next tile overwrites the exchange buffers
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dW[o][colmap(c)] += sum_row dY[row][o] * X[row][c];  db[o] += sum_row dY[row][o].
-// grid (row splits, ceil(M/64), ceil(Kc/64)); a wave owns a 64x64 block of dW (2x2 MFMA tiles) and a slice of
-// the split's rows.  ENC: X is the X0 dump, whose first 168 columns are in (keypoint, PE block) order.
-template <int ENC>
-__global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ dY, int ldy, int M, const float* __restrict__ X,
+// Weight gradient  dW[o][colmap(c)] = sum_row dY[row][o] * X[row][c],  db[o] = sum_row dY[row][o].
+// The sum over rows is the K dimension of the MFMA: lane l supplies row 2s + (l>>5) of K-step s.  A lane
+// loads MV consecutive features of dY (16 B for MV = 4) and 2 consecutive columns of X per K-step and feeds
+// MV x 2 tiles: tile (a, b) holds output feature MV*i + a (A lane i) x column c0 + 2*j + b (B lane j) — the
+// strided labelling makes the vector loads the operands of several MFMAs at once (8 MFMAs per 24 bytes).
+// grid (row workers / 4, 1, ceil(Kc/64)); every wave writes its partial tile block to `partial` in raw
+// register order; k_weight_grad_reduce sums the workers in a fixed order (deterministic, no atomics).
+//   partial: [gridDim.z][workers][MV*2*16][64 lanes];  dbp: [workers][MV][64 lanes]
+template <int MV>
+__global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                      int ldx, int Kc, const int64_t* __restrict__ rows_ptr,
-                                                     float* __restrict__ dW, int in_dim, int f0, float* __restrict__ db) {
+                                                     float* __restrict__ partial, float* __restrict__ dbp) {
+    // block = one row worker; its waves are the column groups (wave z -> columns 64z..64z+63), so the dY rows
+    // of the slice are fetched from HBM once and hit in cache for the sibling waves
     const int64_t rows = *rows_ptr;
     const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
-    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int o0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
-    // rows of this wave: pairs (2 rows per K-step), interleaved over splits x waves
+    const int z = threadIdx.x >> 6;
+    const int worker = blockIdx.x, nworkers = gridDim.x;
+    const int c0 = z * 64;
     const int64_t npairs = rows / 2;
-    const int64_t nworkers = (int64_t)gridDim.x * nwave;
-    const int64_t per = (npairs + nworkers - 1) / nworkers;
-    const int64_t pbeg = ((int64_t)blockIdx.x * nwave + wave) * per;
+    int64_t per = (npairs + nworkers - 1) / nworkers;
+    per = (per + 3) / 4 * 4;  // whole groups of 4 K-steps
+    const int64_t pbeg = (int64_t)worker * per;
     const int64_t pend = pbeg + per < npairs ? pbeg + per : npairs;
-    kpn_f32x16 acc[2][2];
+    kpn_f32x16 acc[MV][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MV; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    const bool oa0 = o0 + i < M, oa1 = o0 + 32 + i < M;
-    const bool cb0 = c0 + i < Kc, cb1 = c0 + 32 + i < Kc;
-    float bs0 = 0.0f, bs1 = 0.0f;
-    for (int64_t pr = pbeg; pr < pend; ++pr) {
-        const int64_t r = 2 * pr + kk;
-        const float* yr = dY + r * ldy + o0 + i;
-        const float* xr = X + r * ldx + c0 + i;
-        const float ya = oa0 ? yr[0] : 0.0f, yb = oa1 ? yr[32] : 0.0f;
-        const float xa = cb0 ? xr[0] : 0.0f, xb = cb1 ? xr[32] : 0.0f;
-        bs0 += ya; bs1 += yb;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xa, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya, xb, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xa, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb, xb, acc[1][1], 0, 0, 0);
-    }
+    float bs[MV];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MV; ++a) bs[a] = 0.0f;
+    const bool cok = c0 + 2 * i < Kc;  // Kc is even: both columns of the pair are in or out
+    constexpr int U = 4;               // K-steps per software-pipeline stage
+    float ya[2][U][MV];
+    float2 xb[2][U];
+    auto fetch = [&](int64_t pr, float (&y)[U][MV], float2 (&x)[U]) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int c = c0 + 32 * b + i;
-            if (c >= Kc) continue;
-            const int f = f0 + ((ENC && c < 168) ? (c % 7) * 24 + c / 7 : c);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + 32 * a + KPN_ROWMAP(r, kk);
-                if (o < M) kpn_atomic_add(dW + (size_t)o * in_dim + f, acc[a][b][r]);
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = 2 * (pr + u) + kk;
+            const bool in = pr + u < pend;
+            if constexpr (MV == 4) {
+                float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) y4 = *reinterpret_cast<const float4*>(dY + r * ldy + 4 * i);
+                y[u][0] = y4.x; y[u][1] = y4.y; y[u][2] = y4.z; y[u][3] = y4.w;
+            } else {
+                float2 y2 = make_float2(0.f, 0.f);
+                if (in) y2 = *reinterpret_cast<const float2*>(dY + r * ldy + 2 * i);
+                y[u][0] = y2.x; y[u][1] = y2.y;
             }
+            x[u] = make_float2(0.f, 0.f);
+            if (in && cok) x[u] = *reinterpret_cast<const float2*>(X + r * ldx + c0 + 2 * i);
         }
-    if (db != nullptr && blockIdx.z == 0) {
-        bs0 += __shfl_xor(bs0, 32);
-        bs1 += __shfl_xor(bs1, 32);
-        if (kk == 0) {
-            if (oa0) kpn_atomic_add(db + o0 + i, bs0);
-            if (oa1) kpn_atomic_add(db + o0 + 32 + i, bs1);
+    };
+    auto consume = [&](const float (&y)[U][MV], const float2 (&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < MV; ++a) {
+                bs[a] += y[u][a];
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[u][a], x[u].x, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y[u][a], x[u].y, acc[a][1], 0, 0, 0);
+            }
+    };
+    if (pbeg < pend) {
+        fetch(pbeg, ya[0], xb[0]);
+        for (int64_t pr = pbeg; pr < pend; pr += 2 * U) {
+            fetch(pr + U, ya[1], xb[1]);   // (reads nothing past pend)
+            consume(ya[0], xb[0]);
+            fetch(pr + 2 * U, ya[0], xb[0]);
+            consume(ya[1], xb[1]);
         }
+    }
+    float* dst = partial + ((size_t)z * nworkers + worker) * (MV * 2 * 16 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < MV; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
+    if (z == 0) {
+#pragma unroll
+        for (int a = 0; a < MV; ++a) dbp[((size_t)worker * MV + a) * 64 + lane] = bs[a];
+    }
+}
+
+// Fixed-order sum of the workers' partial blocks, added to the plain-layout gradient (no atomics: the weight
+// gradient is deterministic).  A workgroup owns 32 consecutive elements; its 8 waves-quarters stride over the
+// workers and combine through LDS.  ENC: the first 168 columns of X0 are in (keypoint, PE block) order.
+template <int MV, int ENC>
+__global__ __launch_bounds__(256) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ dbp,
+                                                            int nworkers, int M, int Kc, float* __restrict__ dW, int in_dim,
+                                                            float* __restrict__ db) {
+    constexpr int TILE_E = MV * 2 * 16 * 64;
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, wl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const int z = blockIdx.y;
+    float s = 0.0f;
+    if (e < TILE_E) {
+        const float* src = partial + (size_t)z * nworkers * TILE_E + e;
+        for (int w = wl; w < nworkers; w += 8) s += src[(size_t)w * TILE_E];
+    } else if (z == 0 && e < TILE_E + MV * 32) {
+        const int q = e - TILE_E, a = q / 32, i = q % 32;
+        for (int w = wl; w < nworkers; w += 8) s += dbp[((size_t)w * MV + a) * 64 + i] + dbp[((size_t)w * MV + a) * 64 + 32 + i];
+    }
+    red[wl][el] = s;
+    __syncthreads();
+    if (wl != 0) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][el];
+    if (e < TILE_E) {
+        const int lane = e & 63, r = (e >> 6) & 15, ab = e >> 10, a = ab >> 1, b = ab & 1;
+        const int o = MV * KPN_ROWMAP(r, lane >> 5) + a;
+        const int c = z * 64 + 2 * (lane & 31) + b;
+        if (o < M && c < Kc) {
+            const int f = (ENC && c < 168) ? (c % 7) * 24 + c / 7 : c;
+            dW[(size_t)o * in_dim + f] += s;
+        }
+    } else if (z == 0 && e < TILE_E + MV * 32) {
+        const int q = e - TILE_E, a = q / 32, i = q % 32;
+        const int o = MV * i + a;
+        if (o < M) db[o] += s;
     }
 }

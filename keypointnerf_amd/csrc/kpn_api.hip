@@ -409,8 +409,13 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
 // ---------------------------------------------------------------------------------------------
 // backward of the geometry rows
 namespace {
-const int64_t kBwdChunk = 65536;  // points per pass: V=3 -> 196608 rows x 4.3 KB of dumps = 0.84 GB
-struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, total; int64_t chunk; };
+const int64_t kBwdChunk = 262144;  // points per pass: V=3 -> 786432 rows x 4.3 KB of dumps = 3.4 GB
+#ifdef KPN_SIMT_EMU
+const int kGradWorkers = 3;     // row workers (one workgroup each; its waves are the column groups)
+#else
+const int kGradWorkers = 512;   // 2 workgroups per CU
+#endif
+struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, partial, dbp, total; int64_t chunk; };
 BwdLayout bwd_layout(int64_t N, int V) {
     BwdLayout L;
     L.chunk = N < kBwdChunk ? N : kBwdChunk;
@@ -421,6 +426,8 @@ BwdLayout bwd_layout(int64_t N, int V) {
     L.list = take((size_t)L.chunk * sizeof(int));
     L.X0 = take(rows * KPN_LDX0 * 4); L.X1 = take(rows * 128 * 4); L.X2 = take(rows * KPN_LDX2 * 4); L.X3 = take(rows * 128 * 4);
     L.D0 = take(rows * 128 * 4); L.D1 = take(rows * 128 * 4); L.D2 = take(rows * 128 * 4); L.D3 = take(rows * 64 * 4);
+    L.partial = take((size_t)4 * kGradWorkers * (4 * 2 * 16 * 64) * 4);  // [column groups <= 4][workers][128 x 64 tile block]
+    L.dbp = take((size_t)kGradWorkers * 4 * 64 * 4);
     L.total = o;
     return L;
 }
@@ -478,24 +485,22 @@ extern "C" int kpn_geo_rows_backward(const kpn_scene_desc* d, const void* scene_
         KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, (const int*)count, V, rows_dev);
         KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1,
                    d_x + c0 * V * 64, B);
-        const int64_t max_rows = (n + KPN_TILE - 1) / KPN_TILE * KPN_TILE * V;
-        auto wgrad = [&](auto enc, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
-            const int gy = (M + 63) / 64, gz = (Kc + 63) / 64;
-#ifdef KPN_SIMT_EMU
-            int splits = 1;
-#else
-            int splits = (int)(max_rows / 512);
-            const int cap = 1024 / (gy * gz);
-            if (splits > cap) splits = cap;
-            if (splits < 1) splits = 1;
-#endif
-            KPN_LAUNCH(k_weight_grad<decltype(enc)::value>, dim3(splits, gy, gz), dim3(256), stream, dY, ldy, M, X, ldx, Kc,
-                       (const int64_t*)rows_dev, dW[layer], plain_dims[P_G1_0 + layer][1], 0, dB[layer]);
+        float* partial = reinterpret_cast<float*>(base + L.partial);
+        float* dbp = reinterpret_cast<float*>(base + L.dbp);
+        auto wgrad = [&](auto mv, auto enc, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
+            constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value;
+            const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
+            KPN_LAUNCH(k_weight_grad<MV>, dim3(nworkers), dim3(64 * gz), stream, dY, ldy, X, ldx, Kc,
+                       (const int64_t*)rows_dev, partial, dbp);
+            constexpr int nelem = MV * 2 * 16 * 64 + MV * 32;
+            KPN_LAUNCH((k_weight_grad_reduce<MV, ENC>), dim3((nelem + 31) / 32, gz), dim3(256), stream,
+                       (const float*)partial, (const float*)dbp, nworkers, M, Kc, dW[layer], plain_dims[P_G1_0 + layer][1],
+                       dB[layer]);
         };
-        wgrad(kpn_ic<1>{}, B.D0, 128, 128, B.X0, KPN_LDX0, 232, 0);
-        wgrad(kpn_ic<0>{}, B.D1, 128, 128, B.X1, 128, 128, 1);
-        wgrad(kpn_ic<0>{}, B.D2, 128, 120, B.X2, KPN_LDX2, 136, 2);
-        wgrad(kpn_ic<0>{}, B.D3, 64, 64, B.X3, 128, 120, 3);
+        wgrad(kpn_ic<4>{}, kpn_ic<1>{}, B.D0, 128, 128, B.X0, KPN_LDX0, 232, 0);
+        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, B.D1, 128, 128, B.X1, 128, 128, 1);
+        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, B.D2, 128, 120, B.X2, KPN_LDX2, 136, 2);
+        wgrad(kpn_ic<2>{}, kpn_ic<0>{}, B.D3, 64, 64, B.X3, 128, 120, 3);
     }
     return check_launch("geo rows backward");
 }

@@ -30,9 +30,23 @@ typedef const kpn_f32x4* kpn_lptr4;
 #define KPN_GLOBAL4(p) ((kpn_gptr4)(p))
 #define KPN_LDS4(p) ((kpn_lptr4)(p))
 #endif
+// lanes of one wavefront exchanging data through LDS: LDS operations of a wave execute in order, so only the
+// compiler must be kept from moving accesses across the exchange point
+#ifndef KPN_SIMT_EMU
+#define KPN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define KPN_WAVE_SYNC() simt::wave_sync()
+#endif
 #ifndef KPN_SIMT_EMU
 // hardware global_atomic_add_f32 (no CAS loop); the sum order is not deterministic
-__device__ __forceinline__ void kpn_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void kpn_atomic_add(float* p, float v) {
+#ifdef KPN_ABLATE_ATOMIC  // timing experiment only (wrong results)
+    if (v == 1234.5f) *p = v;
+    return;
+#endif
+    unsafeAtomicAdd(p, v);
+}
 #else
 static inline void kpn_atomic_add(float* p, float v) {
     uint32_t* u = reinterpret_cast<uint32_t*>(p);

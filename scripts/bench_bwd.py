@@ -13,6 +13,9 @@ from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to
 
 
 def main():
+    if os.environ.get("KPN_EXPERIMENT_LIB"):  # timing experiments with ablated builds (never the product path)
+        from keypointnerf_amd import lib as kl
+        kl._default = kl.KpnLibrary(os.environ["KPN_EXPERIMENT_LIB"])
     rays = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     dev = torch.device("cuda", 0)
     sc = to_device(make_scene(n_views=3, src_hw=(512, 512), tar_hw=(64, 64), mask="dense", seed=1), dev)

@@ -248,6 +248,7 @@ def test_rgba2out_autograd(ops):
     assert_grad_close(gr.cpu().numpy()[0], g["g_all"][0])
     # full size: 65536 rays x 128 samples, loss on colour only (what compute_error uses), vs eager torch autograd
     R, S = 65536, 128
+    torch.manual_seed(17)
     q = torch.rand(1, R, S, 5, device="cuda")
     q[..., 0] = torch.relu(torch.randn(1, R, S, device="cuda")) * 4
     zz = (torch.rand(1, R, S, device="cuda") * 0.05 + 0.005).cumsum(-1) + 2.0
@@ -261,7 +262,9 @@ def test_rgba2out_autograd(ops):
     cw = a * torch.cumprod(torch.cat([torch.ones_like(a[..., :1]), 1 - a[..., :-1]], -1), -1)
     c2 = (q2[..., 2:] * cw[..., None]).sum(-2)
     (g2,) = torch.autograd.grad(c2, q2, w)
-    ok = torch.isfinite(g2).all(-1).all(-1)  # torch's cumprod backward yields NaN where some a_i == 1 exactly
+    # torch's cumprod backward divides by (1 - a_i): NaN where some a_i == 1 exactly, inaccurate where it is close;
+    # those rays are checked for finiteness only
+    ok = torch.isfinite(g2).all(-1).all(-1) & ((1 - a[..., :-1]).detach().amin(-1) > 1e-3)
     assert ok.float().mean() > 0.5
     scale = g2[ok].abs().amax((-1, -2), keepdim=True)
     assert ((g1[ok] - g2[ok]).abs() <= 2e-4 * scale + 1e-6).all()
