@@ -903,3 +903,369 @@ void kpo_geo_rows_backward(const kpo_scene* sc, const float* wflat, int64_t N, c
     for (size_t i = 0; i < n_g1; ++i) d_geo1[i] += (float)g1acc[i];
     free(g0acc); free(g1acc); free(wacc);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Reverse pass of the WHOLE field evaluation KeypointNeRF.query (+ eval_func): what loss.backward() computes
+ * for it in training_step (model.py:128-155).  Hand-written scalar reverse mode of kpo_query_ex, fp32
+ * activations, fp64 accumulation of parameter / map sums.  Gradients flow to: every hot-path parameter
+ * (flat layout of wflat, incl. the raw ani_al last), feat_geo[0], feat_geo[1], feat_tex.  Sample positions,
+ * cameras, keypoints, source images and masks are inputs without gradient (positions are drawn under
+ * no_grad, model.py:1038,1118; pix_weight / validity depend on geometry only).
+ *   d_out (N,5): gradient of [sdf_raw, rad, r,g,b] (apply_eval_func = 0) or of eval_func's
+ *                [mask*relu(rad+noise), mask*sdf_raw+..., r,g,b] (apply_eval_func = 1, the training path).
+ * Outputs are accumulated (+=), maps NCHW like the inputs. */
+static inline float elu_grad_from_out(float y) { return y > 0.0f ? 1.0f : y + 1.0f; } /* ELU alpha=1: d/dx = x>0 ? 1 : e^x = y+1 */
+
+/* y = W x + b backward: dx (+=, may be NULL), dW/db (+=, fp64, layout W row-major then b) */
+static void lin_bwd(const float* W, int out, int in, const float* x, const float* dy, float* dx, double* dWb) {
+    for (int o = 0; o < out; ++o) {
+        const double g = dy[o];
+        if (g == 0.0) continue;
+        double* wr = dWb + (size_t)o * in;
+        for (int i = 0; i < in; ++i) wr[i] += g * (double)x[i];
+        dWb[(size_t)out * in + o] += g;
+    }
+    if (dx)
+        for (int i = 0; i < in; ++i) {
+            float s = 0.0f;
+            for (int o = 0; o < out; ++o) s += W[(size_t)o * in + i] * dy[o];
+            dx[i] += s;
+        }
+}
+
+void kpo_query_backward(const kpo_scene* sc, const float* wflat, int64_t N, const float* pts, const float* view,
+                        int apply_eval_func, uint32_t keep, const float* noise, float noise_std, const float* d_out,
+                        float* d_w, float* d_geo0, float* d_geo1, float* d_tex) {
+    kpo_weights wt;
+    kpo_bind_weights(wflat, &wt);
+    const int V = sc->V;
+    float kcam[KPO_MAXV][KPO_NKPT][3], cpos[KPO_MAXV][3];
+    for (int v = 0; v < V; ++v) {
+        const float* E = sc->extrin + v * 16;
+        for (int k = 0; k < KPO_NKPT; ++k)
+            for (int i = 0; i < 3; ++i)
+                kcam[v][k][i] = ((sc->kpt3d[k * 3 + 0] * E[i * 4 + 0] + sc->kpt3d[k * 3 + 1] * E[i * 4 + 1]) +
+                                 sc->kpt3d[k * 3 + 2] * E[i * 4 + 2]) + E[i * 4 + 3];
+        double inv[16];
+        inverse4(sc->KRT + v * 16, inv);
+        for (int i = 0; i < 3; ++i) cpos[v][i] = (float)inv[i * 4 + 3];
+    }
+    const float pe_vec[KPO_PE_LEVELS] = {(float)(M_PI * 1.0), (float)(M_PI * 2.0), (float)(M_PI * 4.0)};
+    const float two_sigma2 = (float)(2.0 * ((double)sc->sigma * (double)sc->sigma));
+    const size_t HW = (size_t)sc->H * sc->W;
+    size_t loff[L_COUNT], nparam = 0;
+    for (int l = 0; l < L_COUNT; ++l) { loff[l] = nparam; nparam += (size_t)kpo_dims[l][0] * kpo_dims[l][1] + kpo_dims[l][0]; }
+    const size_t ani_off = nparam;
+    nparam += 1;
+    const size_t n_g0 = (size_t)V * 64 * sc->g0h * sc->g0w, n_g1 = (size_t)V * 8 * sc->g1h * sc->g1w,
+                 n_tx = (size_t)V * 8 * sc->th * sc->tw;
+    double* g0acc = (double*)calloc(n_g0, sizeof(double));
+    double* g1acc = (double*)calloc(n_g1, sizeof(double));
+    double* txacc = (double*)calloc(n_tx, sizeof(double));
+    double* wacc = (double*)calloc(nparam, sizeof(double));
+
+#pragma omp parallel
+    {
+        double* wl = (double*)calloc(nparam, sizeof(double));
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t n = 0; n < N; ++n) {
+            const float* p = pts + n * 3;
+            const float* vd = view + n * 3;
+            const float* go = d_out + n * 5;
+            float xn[KPO_MAXV], yn[KPO_MAXV], zn[KPO_MAXV], a[KPO_MAXV], pw[KPO_MAXV];
+            int all_in = 1, all_fg = 1, in_v[KPO_MAXV];
+            for (int v = 0; v < V; ++v) {
+                const float* M = sc->KRT + v * 16;
+                float vh[3];
+                for (int i = 0; i < 3; ++i)
+                    vh[i] = ((p[0] * M[i * 4 + 0] + p[1] * M[i * 4 + 1]) + p[2] * M[i * 4 + 2]) + M[i * 4 + 3];
+                float z = vh[2], x = vh[0] / z, y = vh[1] / z;
+                xn[v] = 2.0f * (x / ((float)sc->W - 1.0f)) - 1.0f;
+                yn[v] = 2.0f * (y / ((float)sc->H - 1.0f)) - 1.0f;
+                zn[v] = 2.0f * (z - sc->znear) / (sc->zfar - sc->znear) - 1.0f;
+                const float eps = 1e-2f;
+                in_v[v] = (xn[v] >= -1.0f - eps) && (xn[v] <= 1.0f + eps) && (yn[v] >= -1.0f - eps) &&
+                          (yn[v] <= 1.0f + eps) && (zn[v] >= -1.0f);
+                all_in &= in_v[v];
+                if (!sc->disable_fg_mask) {
+                    float m;
+                    sample_bilinear(sc->fgmask + (size_t)v * HW, 1, sc->H, sc->W, xn[v], yn[v], &m);
+                    all_fg &= (m > 0.1f);
+                }
+            }
+            float asum = 0.0f, pwsum = 0.0f;
+            for (int v = 0; v < V; ++v) {
+                a[v] = (float)(in_v[v] && all_in && all_fg) * (float)((keep >> v) & 1u);
+                asum += a[v];
+                float c3[3] = {0.5f * xn[v] + 0.5f, 0.5f * yn[v] + 0.5f, 0.5f * zn[v] + 0.5f};
+                float w3[3];
+                for (int i = 0; i < 3; ++i) {
+                    float d = fminf(c3[i], 1.0f - c3[i]);
+                    w3[i] = sigmoidf(5.0f * (d / 0.1f - 1.0f));
+                }
+                pw[v] = (w3[0] * w3[1] * w3[2]) * a[v];
+                pwsum += pw[v];
+            }
+            for (int v = 0; v < V; ++v) pw[v] = pw[v] / (pwsum + 1e-6f);
+            const int is_valid = asum > 0.0f;
+
+            /* ---------------- forward, everything kept ---------------- */
+            float pooled[128], a64[64], h0[64], b64[64], h1[64], o2[2];
+            float X0[KPO_MAXV][232], A0[KPO_MAXV][128], X1[KPO_MAXV][128], A1[KPO_MAXV][128], X2[KPO_MAXV][136],
+                A2[KPO_MAXV][120], X3[KPO_MAXV][120], XV[KPO_MAXV][64];
+            if (!is_valid) {
+                if (apply_eval_func) continue; /* mask = 0: sigma = 0*relu(rad), sdf = const; colour = plain average of inputs */
+                for (int i = 0; i < 128; ++i) pooled[i] = 0.0f;
+            } else {
+                for (int v = 0; v < V; ++v) {
+                    const float* E = sc->extrin + v * 16;
+                    float c[3];
+                    for (int i = 0; i < 3; ++i)
+                        c[i] = ((p[0] * E[i * 4 + 0] + p[1] * E[i * 4 + 1]) + p[2] * E[i * 4 + 2]) + E[i * 4 + 3];
+                    for (int k = 0; k < KPO_NKPT; ++k) {
+                        float dx = c[0] - kcam[v][k][0], dy = c[1] - kcam[v][k][1], dz = c[2] - kcam[v][k][2];
+                        float d2 = (dx * dx + dy * dy) + dz * dz;
+                        float w = expf(-d2 / two_sigma2);
+                        X0[v][k] = dz * w;
+                        for (int l = 0; l < KPO_PE_LEVELS; ++l) {
+                            float y = dz * pe_vec[l];
+                            X0[v][(1 + 2 * l) * KPO_NKPT + k] = sinf(y) * w;
+                            X0[v][(2 + 2 * l) * KPO_NKPT + k] = cosf(y) * w;
+                        }
+                    }
+                    sample_bilinear(sc->geo0 + (size_t)v * 64 * sc->g0h * sc->g0w, 64, sc->g0h, sc->g0w, xn[v], yn[v], X0[v] + KPO_PE_DIM);
+                    linear(wt.w[L_G1_0], wt.b[L_G1_0], 128, 232, X0[v], A0[v]);
+                    for (int i = 0; i < 128; ++i) X1[v][i] = softplus100(A0[v][i]);
+                    linear(wt.w[L_G1_1], wt.b[L_G1_1], 128, 128, X1[v], A1[v]);
+                    for (int i = 0; i < 128; ++i) X2[v][i] = softplus100(A1[v][i]);
+                    sample_bilinear(sc->geo1 + (size_t)v * 8 * sc->g1h * sc->g1w, 8, sc->g1h, sc->g1w, xn[v], yn[v], X2[v] + 128);
+                    linear(wt.w[L_G1_2], wt.b[L_G1_2], 120, 136, X2[v], A2[v]);
+                    for (int i = 0; i < 120; ++i) X3[v][i] = softplus100(A2[v][i]);
+                    linear(wt.w[L_G1_3], wt.b[L_G1_3], 64, 120, X3[v], XV[v]);
+                }
+                for (int i = 0; i < 64; ++i) {
+                    float m = 0.0f;
+                    for (int v = 0; v < V; ++v) m += pw[v] * XV[v][i];
+                    float var = 0.0f;
+                    for (int v = 0; v < V; ++v) { float d = XV[v][i] - m; var += pw[v] * (d * d); }
+                    pooled[i] = m; pooled[64 + i] = var;
+                }
+            }
+            linear(wt.w[L_G2_0], wt.b[L_G2_0], 64, 128, pooled, a64);
+            for (int i = 0; i < 64; ++i) h0[i] = softplus100(a64[i]);
+            linear(wt.w[L_G2_1], wt.b[L_G2_1], 64, 64, h0, b64);
+            for (int i = 0; i < 64; ++i) h1[i] = softplus100(b64[i]);
+            linear(wt.w[L_G2_2], wt.b[L_G2_2], 2, 64, h1, o2);
+
+            /* ---------------- reverse ---------------- */
+            float d_o2[2], d_rgb[3] = {go[2], go[3], go[4]};
+            if (apply_eval_func) {
+                float radn = o2[1] + (noise ? noise[n] * noise_std : 0.0f);
+                d_o2[1] = radn > 0.0f ? go[0] : 0.0f; /* relu */
+                d_o2[0] = go[1];
+            } else { d_o2[0] = go[0]; d_o2[1] = go[1]; }
+            float d_pooled[128];
+            for (int i = 0; i < 128; ++i) d_pooled[i] = 0.0f;
+
+            if (is_valid) {
+                /* ---- colour head forward (kept) ---- */
+                float lat[24], rgb_feat[KPO_MAXV][35], ray_diff[KPO_MAXV][4];
+                linear(wt.w[L_CMP], wt.b[L_CMP], 24, 128, pooled, lat);
+                for (int v = 0; v < V; ++v) {
+                    sample_bilinear(sc->img + (size_t)v * 3 * HW, 3, sc->H, sc->W, xn[v], yn[v], rgb_feat[v]);
+                    sample_bilinear(sc->tex + (size_t)v * 8 * sc->th * sc->tw, 8, sc->th, sc->tw, xn[v], yn[v], rgb_feat[v] + 3);
+                    memcpy(rgb_feat[v] + 11, lat, 24 * sizeof(float));
+                    float cr[3] = {p[0] - cpos[v][0], p[1] - cpos[v][1], p[2] - cpos[v][2]};
+                    float nrm = fmaxf(sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]), 1e-12f);
+                    for (int i = 0; i < 3; ++i) cr[i] /= nrm;
+                    float rd[3] = {vd[0] - cr[0], vd[1] - cr[1], vd[2] - cr[2]};
+                    float rn = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+                    float rc = fmaxf(rn, 1e-6f);
+                    ray_diff[v][0] = rd[0] / rc; ray_diff[v][1] = rd[1] / rc; ray_diff[v][2] = rd[2] / rc;
+                    ray_diff[v][3] = (cr[0] * vd[0] + cr[1] * vd[1]) + cr[2] * vd[2];
+                }
+                const float* mask = a;
+                float H16[KPO_MAXV][16], DIRF[KPO_MAXV][35], x35[KPO_MAXV][35], e[KPO_MAXV], u[KPO_MAXV], weight[KPO_MAXV];
+                const float aabs = fabsf(wt.ani_al);
+                for (int v = 0; v < V; ++v) {
+                    linear(wt.w[L_RE_0], wt.b[L_RE_0], 16, 4, ray_diff[v], H16[v]);
+                    for (int i = 0; i < 16; ++i) H16[v][i] = eluf(H16[v][i]);
+                    linear(wt.w[L_RE_1], wt.b[L_RE_1], 35, 16, H16[v], DIRF[v]);
+                    for (int i = 0; i < 35; ++i) { DIRF[v][i] = eluf(DIRF[v][i]); x35[v][i] = rgb_feat[v][i] + DIRF[v][i]; }
+                    e[v] = expf(aabs * (ray_diff[v][3] - 1.0f));
+                }
+                int imin = 0;
+                for (int v = 1; v < V; ++v) if (e[v] < e[imin]) imin = v;
+                float wsum = 0.0f;
+                for (int v = 0; v < V; ++v) { u[v] = (e[v] - e[imin]) * mask[v]; wsum += u[v]; }
+                for (int v = 0; v < V; ++v) weight[v] = u[v] / (wsum + 1e-8f);
+                float in105[KPO_MAXV][105];
+                float mean[35], var[35];
+                for (int i = 0; i < 35; ++i) {
+                    float m = 0.0f;
+                    for (int v = 0; v < V; ++v) m += x35[v][i] * weight[v];
+                    float vr = 0.0f;
+                    for (int v = 0; v < V; ++v) { float d = x35[v][i] - m; vr += weight[v] * (d * d); }
+                    mean[i] = m; var[i] = vr;
+                }
+                float H64[KPO_MAXV][64], Xa[KPO_MAXV][32], XIN1[KPO_MAXV][32], T32[KPO_MAXV][32], T33[KPO_MAXV][33],
+                    Xb[KPO_MAXV][32], SV[KPO_MAXV], XIN2[KPO_MAXV][32], T32b[KPO_MAXV][32], VIS0[KPO_MAXV], IN37[KPO_MAXV][37],
+                    O16[KPO_MAXV][16], O8[KPO_MAXV][8], logit[KPO_MAXV];
+                for (int v = 0; v < V; ++v) {
+                    memcpy(in105[v], mean, 35 * sizeof(float));
+                    memcpy(in105[v] + 35, var, 35 * sizeof(float));
+                    memcpy(in105[v] + 70, x35[v], 35 * sizeof(float));
+                    linear(wt.w[L_BL_0], wt.b[L_BL_0], 64, 105, in105[v], H64[v]);
+                    for (int i = 0; i < 64; ++i) H64[v][i] = eluf(H64[v][i]);
+                    linear(wt.w[L_BL_1], wt.b[L_BL_1], 32, 64, H64[v], Xa[v]);
+                    for (int i = 0; i < 32; ++i) { Xa[v][i] = eluf(Xa[v][i]); XIN1[v][i] = Xa[v][i] * weight[v]; }
+                    linear(wt.w[L_V1_0], wt.b[L_V1_0], 32, 32, XIN1[v], T32[v]);
+                    for (int i = 0; i < 32; ++i) T32[v][i] = eluf(T32[v][i]);
+                    linear(wt.w[L_V1_1], wt.b[L_V1_1], 33, 32, T32[v], T33[v]);
+                    for (int i = 0; i < 33; ++i) T33[v][i] = eluf(T33[v][i]);
+                    for (int i = 0; i < 32; ++i) Xb[v][i] = Xa[v][i] + T33[v][i];
+                    SV[v] = sigmoidf(T33[v][32]);
+                    for (int i = 0; i < 32; ++i) XIN2[v][i] = Xb[v][i] * SV[v] * mask[v];
+                    linear(wt.w[L_V2_0], wt.b[L_V2_0], 32, 32, XIN2[v], T32b[v]);
+                    for (int i = 0; i < 32; ++i) T32b[v][i] = eluf(T32b[v][i]);
+                    float s1;
+                    linear(wt.w[L_V2_1], wt.b[L_V2_1], 1, 32, T32b[v], &s1);
+                    VIS0[v] = sigmoidf(s1);
+                    memcpy(IN37[v], Xb[v], 32 * sizeof(float));
+                    IN37[v][32] = VIS0[v] * mask[v];
+                    memcpy(IN37[v] + 33, ray_diff[v], 4 * sizeof(float));
+                    linear(wt.w[L_O_0], wt.b[L_O_0], 16, 37, IN37[v], O16[v]);
+                    for (int i = 0; i < 16; ++i) O16[v][i] = eluf(O16[v][i]);
+                    linear(wt.w[L_O_1], wt.b[L_O_1], 8, 16, O16[v], O8[v]);
+                    for (int i = 0; i < 8; ++i) O8[v][i] = eluf(O8[v][i]);
+                    linear(wt.w[L_O_2], wt.b[L_O_2], 1, 8, O8[v], &logit[v]);
+                    if (mask[v] == 0.0f) logit[v] = -1e9f;
+                }
+                float lmax = logit[0];
+                for (int v = 1; v < V; ++v) lmax = fmaxf(lmax, logit[v]);
+                float den = 0.0f, sm[KPO_MAXV];
+                for (int v = 0; v < V; ++v) { sm[v] = expf(logit[v] - lmax); den += sm[v]; }
+                for (int v = 0; v < V; ++v) sm[v] /= den;
+                /* ---- colour head reverse ---- */
+                float rgbdot[KPO_MAXV], rgbtot = 0.0f;
+                for (int v = 0; v < V; ++v) {
+                    rgbdot[v] = (rgb_feat[v][0] * d_rgb[0] + rgb_feat[v][1] * d_rgb[1]) + rgb_feat[v][2] * d_rgb[2];
+                    rgbtot += sm[v] * rgbdot[v];
+                }
+                float d_x35[KPO_MAXV][35], d_weight[KPO_MAXV], d_mean[35], d_var[35];
+                for (int i = 0; i < 35; ++i) d_mean[i] = d_var[i] = 0.0f;
+                for (int v = 0; v < V; ++v) {
+                    d_weight[v] = 0.0f;
+                    for (int i = 0; i < 35; ++i) d_x35[v][i] = 0.0f;
+                    if (mask[v] == 0.0f) continue; /* masked_fill / * proj_mask: no gradient through a masked view */
+                    float dl = sm[v] * (rgbdot[v] - rgbtot);
+                    float d_o8[8] = {0}, d_o16[16] = {0}, d_in37[37] = {0};
+                    lin_bwd(wt.w[L_O_2], 1, 8, O8[v], &dl, d_o8, wl + loff[L_O_2]);
+                    for (int i = 0; i < 8; ++i) d_o8[i] *= elu_grad_from_out(O8[v][i]);
+                    lin_bwd(wt.w[L_O_1], 8, 16, O16[v], d_o8, d_o16, wl + loff[L_O_1]);
+                    for (int i = 0; i < 16; ++i) d_o16[i] *= elu_grad_from_out(O16[v][i]);
+                    lin_bwd(wt.w[L_O_0], 16, 37, IN37[v], d_o16, d_in37, wl + loff[L_O_0]);
+                    float d_xb[32];
+                    for (int i = 0; i < 32; ++i) d_xb[i] = d_in37[i];
+                    /* vis = sigmoid(s1) * mask */
+                    float d_s1 = d_in37[32] * mask[v] * VIS0[v] * (1.0f - VIS0[v]);
+                    float d_t32b[32] = {0}, d_xin2[32] = {0};
+                    lin_bwd(wt.w[L_V2_1], 1, 32, T32b[v], &d_s1, d_t32b, wl + loff[L_V2_1]);
+                    for (int i = 0; i < 32; ++i) d_t32b[i] *= elu_grad_from_out(T32b[v][i]);
+                    lin_bwd(wt.w[L_V2_0], 32, 32, XIN2[v], d_t32b, d_xin2, wl + loff[L_V2_0]);
+                    float d_sv = 0.0f;
+                    for (int i = 0; i < 32; ++i) { d_xb[i] += d_xin2[i] * SV[v] * mask[v]; d_sv += d_xin2[i] * Xb[v][i] * mask[v]; }
+                    float d_t33[33], d_t32[32] = {0}, d_xin1[32] = {0};
+                    for (int i = 0; i < 32; ++i) d_t33[i] = d_xb[i] * elu_grad_from_out(T33[v][i]);
+                    d_t33[32] = d_sv * SV[v] * (1.0f - SV[v]) * elu_grad_from_out(T33[v][32]);
+                    lin_bwd(wt.w[L_V1_1], 33, 32, T32[v], d_t33, d_t32, wl + loff[L_V1_1]);
+                    for (int i = 0; i < 32; ++i) d_t32[i] *= elu_grad_from_out(T32[v][i]);
+                    lin_bwd(wt.w[L_V1_0], 32, 32, XIN1[v], d_t32, d_xin1, wl + loff[L_V1_0]);
+                    float d_xa[32], d_h64[64] = {0}, d_in105[105] = {0};
+                    for (int i = 0; i < 32; ++i) {
+                        d_xa[i] = (d_xb[i] + d_xin1[i] * weight[v]) * elu_grad_from_out(Xa[v][i]);
+                        d_weight[v] += d_xin1[i] * Xa[v][i];
+                    }
+                    lin_bwd(wt.w[L_BL_1], 32, 64, H64[v], d_xa, d_h64, wl + loff[L_BL_1]);
+                    for (int i = 0; i < 64; ++i) d_h64[i] *= elu_grad_from_out(H64[v][i]);
+                    lin_bwd(wt.w[L_BL_0], 64, 105, in105[v], d_h64, d_in105, wl + loff[L_BL_0]);
+                    for (int i = 0; i < 35; ++i) { d_mean[i] += d_in105[i]; d_var[i] += d_in105[35 + i]; d_x35[v][i] += d_in105[70 + i]; }
+                }
+                /* fused_mean_variance reverse (utils.py:91-95) */
+                for (int i = 0; i < 35; ++i) {
+                    float s = 0.0f; /* d var / d mean = -2 sum_v w_v (x_v - m) */
+                    for (int v = 0; v < V; ++v) s += weight[v] * (x35[v][i] - mean[i]);
+                    float dm = d_mean[i] - 2.0f * d_var[i] * s;
+                    for (int v = 0; v < V; ++v) {
+                        float d = x35[v][i] - mean[i];
+                        d_x35[v][i] += weight[v] * (dm + 2.0f * d * d_var[i]);
+                        d_weight[v] += x35[v][i] * dm + d * d * d_var[i];
+                    }
+                }
+                /* blend weights reverse -> ani_al (model.py:1287-1289) */
+                {
+                    float S = wsum + 1e-8f, dot_du = 0.0f, d_u[KPO_MAXV], d_e[KPO_MAXV], d_emin = 0.0f;
+                    for (int v = 0; v < V; ++v) dot_du += d_weight[v] * u[v];
+                    for (int v = 0; v < V; ++v) { d_u[v] = d_weight[v] / S - dot_du / (S * S); d_e[v] = d_u[v] * mask[v]; d_emin -= d_u[v] * mask[v]; }
+                    d_e[imin] += d_emin;
+                    double d_aabs = 0.0;
+                    for (int v = 0; v < V; ++v) d_aabs += (double)d_e[v] * e[v] * (ray_diff[v][3] - 1.0f);
+                    wl[ani_off] += d_aabs * (wt.ani_al > 0.0f ? 1.0 : (wt.ani_al < 0.0f ? -1.0 : 0.0));
+                }
+                /* x35 = rgb_feat + elu(ray_encoder(ray_diff)) */
+                float d_lat[24];
+                for (int i = 0; i < 24; ++i) d_lat[i] = 0.0f;
+                for (int v = 0; v < V; ++v) {
+                    if (mask[v] == 0.0f) continue;
+                    float d_dir[35], d_h16[16] = {0};
+                    for (int i = 0; i < 35; ++i) d_dir[i] = d_x35[v][i] * elu_grad_from_out(DIRF[v][i]);
+                    lin_bwd(wt.w[L_RE_1], 35, 16, H16[v], d_dir, d_h16, wl + loff[L_RE_1]);
+                    for (int i = 0; i < 16; ++i) d_h16[i] *= elu_grad_from_out(H16[v][i]);
+                    lin_bwd(wt.w[L_RE_0], 16, 4, ray_diff[v], d_h16, NULL, wl + loff[L_RE_0]);
+                    for (int i = 0; i < 24; ++i) d_lat[i] += d_x35[v][11 + i];
+                    scatter_bilinear(txacc + (size_t)v * 8 * sc->th * sc->tw, 8, sc->th, sc->tw, xn[v], yn[v], d_x35[v] + 3);
+                }
+                lin_bwd(wt.w[L_CMP], 24, 128, pooled, d_lat, d_pooled, wl + loff[L_CMP]);
+            }
+            /* ---- layers2 reverse ---- */
+            {
+                float d_h1[64] = {0}, d_h0[64] = {0};
+                lin_bwd(wt.w[L_G2_2], 2, 64, h1, d_o2, d_h1, wl + loff[L_G2_2]);
+                for (int i = 0; i < 64; ++i) d_h1[i] *= softplus100_grad(b64[i]);
+                lin_bwd(wt.w[L_G2_1], 64, 64, h0, d_h1, d_h0, wl + loff[L_G2_1]);
+                for (int i = 0; i < 64; ++i) d_h0[i] *= softplus100_grad(a64[i]);
+                lin_bwd(wt.w[L_G2_0], 64, 128, pooled, d_h0, is_valid ? d_pooled : NULL, wl + loff[L_G2_0]);
+            }
+            if (!is_valid) continue;
+            /* ---- pooling reverse (pool_ops utils.py:733-746, w given) and layers1 + gathers ---- */
+            for (int v = 0; v < V; ++v) {
+                if (a[v] == 0.0f) continue; /* pw[v] == 0: no gradient reaches this view's row */
+                float dxv[64];
+                for (int i = 0; i < 64; ++i) {
+                    float s = 0.0f;
+                    for (int k = 0; k < V; ++k) s += pw[k] * (XV[k][i] - pooled[i]);
+                    float dm = d_pooled[i] - 2.0f * d_pooled[64 + i] * s;
+                    dxv[i] = pw[v] * (dm + 2.0f * (XV[v][i] - pooled[i]) * d_pooled[64 + i]);
+                }
+                float dx3[120] = {0}, dx2[136] = {0}, dx1[128] = {0}, dx0[232] = {0};
+                lin_bwd(wt.w[L_G1_3], 64, 120, X3[v], dxv, dx3, wl + loff[L_G1_3]);
+                for (int i = 0; i < 120; ++i) dx3[i] *= softplus100_grad(A2[v][i]);
+                lin_bwd(wt.w[L_G1_2], 120, 136, X2[v], dx3, dx2, wl + loff[L_G1_2]);
+                for (int i = 0; i < 128; ++i) dx2[i] *= softplus100_grad(A1[v][i]);
+                lin_bwd(wt.w[L_G1_1], 128, 128, X1[v], dx2, dx1, wl + loff[L_G1_1]);
+                for (int i = 0; i < 128; ++i) dx1[i] *= softplus100_grad(A0[v][i]);
+                lin_bwd(wt.w[L_G1_0], 128, 232, X0[v], dx1, dx0, wl + loff[L_G1_0]);
+                scatter_bilinear(g0acc + (size_t)v * 64 * sc->g0h * sc->g0w, 64, sc->g0h, sc->g0w, xn[v], yn[v], dx0 + KPO_PE_DIM);
+                scatter_bilinear(g1acc + (size_t)v * 8 * sc->g1h * sc->g1w, 8, sc->g1h, sc->g1w, xn[v], yn[v], dx2 + 128);
+            }
+        }
+#pragma omp critical
+        for (size_t i = 0; i < nparam; ++i) wacc[i] += wl[i];
+        free(wl);
+    }
+    for (size_t i = 0; i < nparam; ++i) d_w[i] += (float)wacc[i];
+    for (size_t i = 0; i < n_g0; ++i) d_geo0[i] += (float)g0acc[i];
+    for (size_t i = 0; i < n_g1; ++i) d_geo1[i] += (float)g1acc[i];
+    for (size_t i = 0; i < n_tx; ++i) d_tex[i] += (float)txacc[i];
+    free(g0acc); free(g1acc); free(txacc); free(wacc);
+}

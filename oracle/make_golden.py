@@ -272,6 +272,67 @@ def run_geo_rows_grad_case(net, name, n_views, src_hw, mask, n_pts, seed, S=8):
           f"|d_geo0|max={float(feat_geo[0].grad.abs().max()):.3g} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_query_grad_case(net, name, n_views, src_hw, mask, n_pts, seed, S=8, keep=None):
+    """Gradients of the WHOLE field evaluation by the reference's own autograd: an unmodified net.query() call in
+    eval mode (no random dropout), loss = sum(out * G) with (a) out = query's raw [sdf_raw, rad, rgb] and
+    (b) out = eval_func(query) restated from src/model.py:981-996 (mask*relu(rad), mask*sdf + (1-mask)*0.1/nml_scale).
+    Recorded per variant: d loss / d every hot-path parameter (effective weights via retain_grad on the
+    weight-normed tensors, plus the raw weight_g / weight_v / bias / ani_al grads) and d loss / d feat_geo[0],
+    feat_geo[1], feat_tex."""
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=(16, 16), mask=mask, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = scene["bounds"].reshape(2, 3)[0], scene["bounds"].reshape(2, 3)[1]
+    pts = (lo + (hi - lo) * torch.rand(n_pts, 3, generator=g))[None]
+    view = torch.nn.functional.normalize(torch.randn(n_pts, 3, generator=g), dim=-1)[None]
+    G = torch.randn(1, n_pts, 5, generator=g)
+    d = scene_to_npz(scene)
+    d.update({"cfg": np.array([n_views, 0, 0, 0, 0, 0], np.int64), "pts": _np(pts[0]), "view": _np(view[0]), "G": _np(G[0])})
+    net.eval()
+    for variant in ("raw", "evalfunc"):
+        feat_geo = [f.clone().requires_grad_(True) for f in scene["feat_geo"]]
+        feat_tex = scene["feat_tex"].clone().requires_grad_(True)
+        eff, hooks = {}, []
+        for lname, prefix, shape, wn in HOTPATH_LAYERS:
+            mod = net.get_submodule(prefix)
+            def fh(m, i, o, lname=lname):
+                if not m.weight.is_leaf:
+                    m.weight.retain_grad()
+                eff[lname] = m.weight
+            hooks.append(mod.register_forward_hook(fh))
+        net.zero_grad()
+        out, valid = net.query(pts, scene["cam"], feat_geo, feat_tex, n_views=n_views, view=view, nerf=True,
+                               sp_data=dict(scene["sp_data"]), tx_data={"img": scene["img"]}, bbox_center=None, n_pts_samples=S,
+                               src_foreground_mask=scene["src_foreground_mask"])
+        for h in hooks:
+            h.remove()
+        if variant == "evalfunc":                                           # src/model.py:981-996, rand_noise_std = 0
+            m = valid.float()
+            sdf = m * out[..., :1] + (1.0 - m) * (0.1 / scene["cam"]["nml_scale"])
+            sigma = m * torch.relu(out[..., 1:2])
+            res = torch.cat([sigma, sdf, out[..., 2:]], -1)
+        else:
+            res = out
+        (res * G).sum().backward()
+        pre = variant + "."
+        d[pre + "out"], d[pre + "valid"] = _np(res[0]), _np(valid).reshape(-1)
+        d[pre + "d_geo0"], d[pre + "d_geo1"], d[pre + "d_tex"] = _np(feat_geo[0].grad), _np(feat_geo[1].grad), _np(feat_tex.grad)
+        for lname, prefix, shape, wn in HOTPATH_LAYERS:
+            mod = net.get_submodule(prefix)
+            d[pre + "dW." + lname] = _np(eff[lname].grad)
+            d[pre + "db." + lname] = _np(mod.bias.grad)
+        d[pre + "d_ani_al"] = _np(net.mlp_tex.ani_al.grad).reshape(1)
+        for k, v in net.named_parameters():
+            if k.startswith(HOT_PREFIXES) and v.grad is not None:
+                d[pre + "param_grad." + k] = _np(v.grad)
+        print(f"{name}/{variant}: N={n_pts} valid={float(valid.float().mean()):.3f} |d_tex|max={float(feat_tex.grad.abs().max()):.3g} "
+              f"d_ani={float(net.mlp_tex.ani_al.grad):.4g}")
+    net.zero_grad()
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def run_output_case(name, seed=9):
     """Output side: the reference's own frame arrangement / quantisation / PSNR."""
     rmodel = ref_shim.load_reference()
@@ -312,6 +373,7 @@ def main():
     run_train_case(net, "case_f_v3_train", 3, (64, 64), (32, 32), "dense", 12, 12, seed=5)
     run_train_case(net, "case_g_v4_train", 4, (48, 80), (32, 48), "ellipsoid", 16, 8, seed=8)
     run_geo_rows_grad_case(net, "case_i_v3_geo_rows_grad", 3, (64, 64), "ellipsoid", 600, seed=12)
+    run_query_grad_case(net, "case_j_v3_query_grad", 3, (64, 64), "ellipsoid", 400, seed=13)
 
 
 if __name__ == "__main__":

@@ -234,3 +234,18 @@ def geo_rows_backward(oscene, wflat, pts, d_x, keep=0xFFFFFFFF):
     lib().kpo_geo_rows_backward(ctypes.byref(oscene.struct), _ptr(wflat), ctypes.c_int64(N), _ptr(pts), ctypes.c_uint32(keep),
                                 _ptr(d_x), _ptr(d_w), _ptr(d_g0), _ptr(d_g1))
     return d_w, d_g0, d_g1
+
+
+def query_backward(oscene, wflat, pts, view, d_out, apply_eval_func=False, keep=0xFFFFFFFF, noise=None, noise_std=0.0):
+    """Reverse pass of the whole field evaluation (kpo_query_backward).
+    Returns (d_w flat like wflat, d_geo0, d_geo1, d_tex) — maps NCHW."""
+    pts, view = _f32(pts).reshape(-1, 3), _f32(view).reshape(-1, 3)
+    N = pts.shape[0]
+    d_out = _f32(d_out).reshape(N, 5)
+    d_w = np.zeros_like(wflat)
+    d_g0, d_g1, d_tx = (np.zeros_like(oscene.bufs[k]) for k in ("geo0", "geo1", "tex"))
+    nz = None if noise is None else _f32(noise).reshape(-1)
+    lib().kpo_query_backward(ctypes.byref(oscene.struct), _ptr(wflat), ctypes.c_int64(N), _ptr(pts), _ptr(view),
+                             ctypes.c_int(int(apply_eval_func)), ctypes.c_uint32(keep), None if nz is None else _ptr(nz),
+                             ctypes.c_float(noise_std), _ptr(d_out), _ptr(d_w), _ptr(d_g0), _ptr(d_g1), _ptr(d_tx))
+    return d_w, d_g0, d_g1, d_tx

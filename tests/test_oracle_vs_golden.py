@@ -179,3 +179,47 @@ def test_geo_rows_backward_vs_reference_autograd():
     assert np.all(d_w[off:] == 0)
     for got, ref in ((d_g0, g["d_geo0"]), (d_g1, g["d_geo1"])):
         assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def golden_flat_grads(g, variant):
+    """The reference autograd's effective-parameter gradients of golden case j in the flat layout of flatten_plain."""
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    parts = []
+    for lname, _, _, _ in HOTPATH_LAYERS:
+        parts += [g[f"{variant}.dW.{lname}"].reshape(-1), g[f"{variant}.db.{lname}"].reshape(-1)]
+    parts.append(g[f"{variant}.d_ani_al"].reshape(-1))
+    return np.concatenate(parts).astype(np.float32)
+
+
+def assert_flat_grads_close(got, ref, rtol, what=""):
+    """Per-layer (W and b separately) max-norm relative comparison of flat parameter gradients."""
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    off = 0
+    for lname, _, (o, i), _ in HOTPATH_LAYERS:
+        # one scale per layer: the last logit's bias gradient is identically 0 (softmax is shift invariant) and
+        # holds only rounding noise on both sides
+        scale = np.abs(ref[off:off + o * i + o]).max()
+        for nm, n in (("W", o * i), ("b", o)):
+            a, b = got[off:off + n], ref[off:off + n]
+            off += n
+            assert np.abs(a - b).max() <= rtol * scale + 1e-7, (what, lname, nm, float(np.abs(a - b).max()), float(scale))
+    assert abs(got[off] - ref[off]) <= rtol * abs(ref[off]) + 1e-7, (what, "ani_al", got[off], ref[off])
+    assert off + 1 == got.size == ref.size
+
+
+@pytest.mark.parametrize("variant", ["raw", "evalfunc"])
+def test_query_backward_vs_reference_autograd(variant):
+    """kpo_query_backward (the whole field evaluation's reverse pass) against loss.backward() of the unmodified
+    reference net.query (golden case j), raw outputs and through eval_func."""
+    scene, cfg, g = load_case("case_j_v3_query_grad")
+    sd = load_weights()
+    osc = oracle.OracleScene(scene)
+    wflat = oracle.flat_weights(sd)
+    out, valid = oracle.query(osc, wflat, g["pts"], g["view"], apply_eval_func=(variant == "evalfunc"))
+    assert np.array_equal(valid, g[variant + ".valid"].astype(bool))
+    assert np.abs(out - g[variant + ".out"]).max() < 2e-5
+    d_w, d_g0, d_g1, d_tx = oracle.query_backward(osc, wflat, g["pts"], g["view"], g["G"], apply_eval_func=(variant == "evalfunc"))
+    assert_flat_grads_close(d_w, golden_flat_grads(g, variant), 5e-5, variant)
+    for got, key in ((d_g0, "d_geo0"), (d_g1, "d_geo1"), (d_tx, "d_tex")):
+        ref = g[f"{variant}.{key}"]
+        assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max(), (key, np.abs(got - ref).max(), np.abs(ref).max())
