@@ -131,6 +131,20 @@ int kpn_geo_rows_backward(const kpn_scene_desc* desc, const void* scene_ws, cons
                           const float* pts, uint32_t keep_mask, const float* d_x, float* d_plain, float* d_geo0,
                           float* d_geo1, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of the field evaluation w.r.t. its two GEOMETRY outputs: query()'s [sdf_raw, rad] (mode 0) or eval_func's
+ * [sigma = mask*relu(rad + noise), sdf] (mode 1, src/model.py:981-996) — i.e. loss.backward() of training_step
+ * (src/model.py:128-155) through view pooling, MLPUNetFusion.layers2 (src/utils.py:500-518, 612-647, 722-748), and
+ * then layers1 + the feat_geo gathers as kpn_geo_rows_backward.  d_out (N,5): columns 0,1 are used; the colour
+ * columns 2..4 are NOT propagated yet (ibr_compress_gfeat / IBRRenderingHead / feat_tex reverse: next).
+ * Masked points contribute nothing in mode 1 (mask = 0); in mode 0 their constant layers2(0) output is not
+ * differentiated either (training uses mode 1).  noise (N) / noise_std: the density noise added before the relu.
+ * Outputs accumulate like kpn_geo_rows_backward's (d_plain: layers1 and layers2 blocks). */
+size_t kpn_query_backward_geometry_workspace_bytes(int64_t n_points, int32_t n_views);
+int kpn_query_backward_geometry(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
+                                int64_t n_points, const float* pts, int32_t mode, uint32_t keep_mask, const float* noise,
+                                float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).
  * mode 0: out = [sdf_raw, rad, r,g,b] exactly as query() returns;

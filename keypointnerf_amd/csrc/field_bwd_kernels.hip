@@ -46,11 +46,12 @@ struct kpn_bwd_bufs {
 // threshold (softplus == a, 100 a > 20) this is 1 to within 2e-9, the reference's exact 1
 __device__ __forceinline__ float kpn_softplus100_grad_from_value(float sp) { return 1.0f - kpn_exp2(sp * -144.269504088896341f); }
 
-// dx: upstream gradient d loss / d x_view, [N][V][64] row-major, indexed by the ORIGINAL point index
+// dx: upstream gradient d loss / d x_view: [N][V][64] indexed by the ORIGINAL point index, or (dx_compact) by
+// row = (tile*V + v)*32 + p as k_fuse_bwd writes it
 __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                          const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                          int* __restrict__ tickets, const float* __restrict__ dx,
-                                                         kpn_bwd_bufs bufs) {
+                                                         int dx_compact, kpn_bwd_bufs bufs) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int count = *count_ptr;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
 #pragma unroll
             for (int r = 0; r < 16; ++r) d3[ob][r] = 0.0f;
         {
-            const float* grow = dx + ((size_t)n * sc.V + v) * 64;
+            const float* grow = dx_compact ? dx + row * 64 : dx + ((size_t)n * sc.V + v) * 64;
             float* d3row = bufs.D3 + row * 64;
             kpn_mfma_layer<32, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
 // register order; k_weight_grad_reduce sums the workers in a fixed order (deterministic, no atomics).
 //   partial: [gridDim.z][workers][MV*2*16][64 lanes];  dbp: [workers][MV][64 lanes]
 template <int MV>
-__global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+__global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ dY, int ldy, int M, const float* __restrict__ X,
                                                      int ldx, int Kc, const int64_t* __restrict__ rows_ptr,
                                                      float* __restrict__ partial, float* __restrict__ dbp) {
     // block = one row worker; its waves are the column groups (wave z -> columns 64z..64z+63), so the dY rows
@@ -328,14 +329,17 @@ __global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ d
         for (int u = 0; u < U; ++u) {
             const int64_t r = 2 * (pr + u) + kk;
             const bool in = pr + u < pend;
+            const bool yin = in && MV * i < M;  // M is a multiple of MV
             if constexpr (MV == 4) {
                 float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) y4 = *reinterpret_cast<const float4*>(dY + r * ldy + 4 * i);
+                if (yin) y4 = *reinterpret_cast<const float4*>(dY + r * ldy + 4 * i);
                 y[u][0] = y4.x; y[u][1] = y4.y; y[u][2] = y4.z; y[u][3] = y4.w;
-            } else {
+            } else if constexpr (MV == 2) {
                 float2 y2 = make_float2(0.f, 0.f);
-                if (in) y2 = *reinterpret_cast<const float2*>(dY + r * ldy + 2 * i);
+                if (yin) y2 = *reinterpret_cast<const float2*>(dY + r * ldy + 2 * i);
                 y[u][0] = y2.x; y[u][1] = y2.y;
+            } else {
+                y[u][0] = yin ? dY[r * ldy + i] : 0.0f;
             }
             x[u] = make_float2(0.f, 0.f);
             if (in && cok) x[u] = *reinterpret_cast<const float2*>(X + r * ldx + c0 + 2 * i);

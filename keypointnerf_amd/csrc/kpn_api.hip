@@ -13,6 +13,7 @@
 #include "ray_kernels.hip"
 #include "field_kernels.hip"
 #include "field_bwd_kernels.hip"
+#include "fuse_bwd_kernels.hip"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -177,6 +178,14 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
     pack_segment_t(P, BSEG_G1_2T, pl.w[P_G1_2], 120, 136, [](int R) { return R < 128 ? R : (R < 136 ? R : -1); });
     pack_segment_t(P, BSEG_G1_1T, pl.w[P_G1_1], 128, 128, ident);
     pack_segment_t(P, BSEG_G1_0T, pl.w[P_G1_0], 128, 232, [](int R) { return R < 64 ? 168 + R : -1; });
+    // backward of layers2 (kpn_query_backward)
+    pack_segment_t(P, BSEG_G2_1T, pl.w[P_G2_1], 64, 64, ident);
+    pack_segment_t(P, BSEG_G2_0T, pl.w[P_G2_0], 64, 128, ident);
+    for (int o = 0; o < 2; ++o)
+        for (int b = 0; b < 2; ++b)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r)
+                    P[kpn_brow_off(BROW_G2_2_SDF + o) + (2 * b + h) * 16 + r] = pl.w[P_G2_2][o * 64 + 32 * b + KPN_ROWMAP(r, h)];
     // scalars: |ani_al| (model.py:1287) and layers2(0), the query() result of a fully masked point
     float* sc = P + kpn_scalar_off();
     sc[0] = fabsf(pl.ani_al);
@@ -407,7 +416,7 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward of the geometry rows
+// backward of the field evaluation
 namespace {
 const int64_t kBwdChunk = 262144;  // points per pass: V=3 -> 786432 rows x 4.3 KB of dumps = 3.4 GB
 #ifdef KPN_SIMT_EMU
@@ -415,11 +424,13 @@ const int kGradWorkers = 3;     // row workers (one workgroup each; its waves ar
 #else
 const int kGradWorkers = 512;   // 2 workgroups per CU
 #endif
-struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, partial, dbp, total; int64_t chunk; };
-BwdLayout bwd_layout(int64_t N, int V) {
-    BwdLayout L;
+// full = 1: the whole-query reverse (adds the forward row scratch, the per-point dumps and the d x_view rows)
+struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, partial, dbp, xscr, Xp, Xh0, Xh1, D20, D21, D22, dxrows, total; int64_t chunk; };
+BwdLayout bwd_layout(int64_t N, int V, int full) {
+    BwdLayout L{};
     L.chunk = N < kBwdChunk ? N : kBwdChunk;
-    const size_t rows = (size_t)((L.chunk + KPN_TILE - 1) / KPN_TILE) * KPN_TILE * V;
+    const size_t ntiles = (size_t)((L.chunk + KPN_TILE - 1) / KPN_TILE);
+    const size_t npts = ntiles * KPN_TILE, rows = npts * V;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
     L.count = take(256);
@@ -428,6 +439,12 @@ BwdLayout bwd_layout(int64_t N, int V) {
     L.D0 = take(rows * 128 * 4); L.D1 = take(rows * 128 * 4); L.D2 = take(rows * 128 * 4); L.D3 = take(rows * 64 * 4);
     L.partial = take((size_t)4 * kGradWorkers * (4 * 2 * 16 * 64) * 4);  // [column groups <= 4][workers][128 x 64 tile block]
     L.dbp = take((size_t)kGradWorkers * 4 * 64 * 4);
+    if (full) {
+        L.xscr = take(ntiles * (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4));
+        L.Xp = take(npts * 128 * 4); L.Xh0 = take(npts * 64 * 4); L.Xh1 = take(npts * 64 * 4);
+        L.D20 = take(npts * 64 * 4); L.D21 = take(npts * 64 * 4); L.D22 = take(npts * 2 * 4);
+        L.dxrows = take(rows * 64 * 4);
+    }
     L.total = o;
     return L;
 }
@@ -438,14 +455,84 @@ size_t plain_w_off(int layer) {
 }
 }  // namespace
 
-// rows of the current pass, from the device-side valid count
+// rows[0] = (point, view) rows of the current pass, rows[1] = points, both padded to whole tiles
 __global__ void k_bwd_rows(const int* __restrict__ count, int V, int64_t* __restrict__ rows) {
-    *rows = (int64_t)((*count + KPN_TILE - 1) / KPN_TILE) * KPN_TILE * V;
+    const int64_t npts = (int64_t)((*count + KPN_TILE - 1) / KPN_TILE) * KPN_TILE;
+    rows[0] = npts * V;
+    rows[1] = npts;
 }
+
+namespace {
+// d_x != nullptr: geometry rows only, upstream gradient given per (point, view).  Otherwise the whole-query reverse
+// from d_out (N,5) [geometry outputs only so far: the colour head's reverse is not built].
+int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts, const float* view,
+                 int mode, uint32_t keep_mask, const float* noise, float noise_std, const float* d_x, const float* d_out,
+                 float* d_plain, float* d_geo0, float* d_geo1, void* ws, size_t ws_bytes, void* stream) {
+    const int V = d->n_views;
+    const int full = d_x == nullptr;
+    const BwdLayout L = bwd_layout(N, V, full);
+    if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "backward workspace too small");
+    kpn_scene_dev sc = scene_dev(d, scene_ws);
+    sc.keep = keep_mask;
+    char* base = static_cast<char*>(ws);
+    auto fp = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    int* count = reinterpret_cast<int*>(base + L.count);  // [0] valid count, [1..3] work tickets of the three persistent kernels
+    int64_t* rows_dev = reinterpret_cast<int64_t*>(base + L.count + 64);
+    int* list = reinterpret_cast<int*>(base + L.list);
+    kpn_bwd_bufs B;
+    B.X0 = fp(L.X0); B.X1 = fp(L.X1); B.X2 = fp(L.X2); B.X3 = fp(L.X3);
+    B.D0 = fp(L.D0); B.D1 = fp(L.D1); B.D2 = fp(L.D2); B.D3 = fp(L.D3);
+    B.dgeo0 = d_geo0; B.dgeo1 = d_geo1;
+    kpn_fuse_bwd_bufs F{};
+    if (full) {
+        F.Xp = fp(L.Xp); F.Xh0 = fp(L.Xh0); F.Xh1 = fp(L.Xh1); F.D20 = fp(L.D20); F.D21 = fp(L.D21); F.D22 = fp(L.D22);
+        F.dxrows = fp(L.dxrows);
+    }
+    float* partial = fp(L.partial);
+    float* dbp = fp(L.dbp);
+    const int blocks = field_grid_blocks();
+    // dW[layer] += dY^T X over the rows (which = 0) or points (which = 1) of this pass
+    auto wgrad = [&](auto mv, auto enc, int which, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
+        constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value;
+        const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
+        float* dW = d_plain + plain_w_off(layer);
+        float* dB = dW + (size_t)plain_dims[layer][0] * plain_dims[layer][1];
+        KPN_LAUNCH(k_weight_grad<MV>, dim3(nworkers), dim3(64 * gz), stream, dY, ldy, M, X, ldx, Kc,
+                   (const int64_t*)(rows_dev + which), partial, dbp);
+        constexpr int nelem = MV * 2 * 16 * 64 + MV * 32;
+        KPN_LAUNCH((k_weight_grad_reduce<MV, ENC>), dim3((nelem + 31) / 32, gz), dim3(256), stream, (const float*)partial,
+                   (const float*)dbp, nworkers, M, Kc, dW, plain_dims[layer][1], dB);
+    };
+    for (int64_t c0 = 0; c0 < N; c0 += L.chunk) {
+        const int64_t n = (N - c0 < L.chunk) ? (N - c0) : L.chunk;
+        kpn_points ps{pts + c0 * 3, (view ? view : pts) + c0 * 3, nullptr, nullptr, nullptr, 1, noise ? noise + c0 : nullptr, noise_std};
+        hipMemsetAsync(count, 0, 8 * sizeof(int), (hipStream_t)stream);
+        KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
+                   (uint8_t*)nullptr, list, count);
+        KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, (const int*)count, V, rows_dev);
+        if (full) {
+            float* xscr = fp(L.xscr);
+            KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
+            KPN_LAUNCH(k_fuse_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 2,
+                       (const float*)xscr, mode, d_out + c0 * 5, F);
+            wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 1, F.D20, 64, 64, F.Xp, 128, 128, P_G2_0);
+            wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 1, F.D21, 64, 64, F.Xh0, 64, 64, P_G2_1);
+            wgrad(kpn_ic<1>{}, kpn_ic<0>{}, 1, F.D22, 2, 2, F.Xh1, 64, 64, P_G2_2);
+        }
+        KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 3,
+                   full ? (const float*)F.dxrows : d_x + c0 * V * 64, full, B);
+        wgrad(kpn_ic<4>{}, kpn_ic<1>{}, 0, B.D0, 128, 128, B.X0, KPN_LDX0, 232, P_G1_0);
+        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, 0, B.D1, 128, 128, B.X1, 128, 128, P_G1_1);
+        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, 0, B.D2, 128, 120, B.X2, KPN_LDX2, 136, P_G1_2);
+        wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 0, B.D3, 64, 64, B.X3, 128, 120, P_G1_3);
+    }
+    return check_launch("field backward");
+}
+}  // namespace
 
 extern "C" size_t kpn_geo_rows_backward_workspace_bytes(int64_t N, int32_t V) {
     if (N <= 0 || V <= 0) return 0;
-    return bwd_layout(N, V).total;
+    return bwd_layout(N, V, 0).total;
 }
 
 extern "C" int kpn_geo_rows_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N,
@@ -455,54 +542,26 @@ extern "C" int kpn_geo_rows_backward(const kpn_scene_desc* d, const void* scene_
     KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
     if (N == 0) return KPN_OK;
     KPN_REQUIRE(scene_ws && wp && pts && d_x && d_plain && d_geo0 && d_geo1 && ws, "null pointer");
-    const int V = d->n_views;
-    const BwdLayout L = bwd_layout(N, V);
-    if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "geo-rows backward workspace too small");
-    kpn_scene_dev sc = scene_dev(d, scene_ws);
-    sc.keep = keep_mask;
-    char* base = static_cast<char*>(ws);
-    int* count = reinterpret_cast<int*>(base + L.count);
-    int64_t* rows_dev = reinterpret_cast<int64_t*>(base + L.count + 64);
-    int* list = reinterpret_cast<int*>(base + L.list);
-    kpn_bwd_bufs B;
-    B.X0 = reinterpret_cast<float*>(base + L.X0); B.X1 = reinterpret_cast<float*>(base + L.X1);
-    B.X2 = reinterpret_cast<float*>(base + L.X2); B.X3 = reinterpret_cast<float*>(base + L.X3);
-    B.D0 = reinterpret_cast<float*>(base + L.D0); B.D1 = reinterpret_cast<float*>(base + L.D1);
-    B.D2 = reinterpret_cast<float*>(base + L.D2); B.D3 = reinterpret_cast<float*>(base + L.D3);
-    B.dgeo0 = d_geo0; B.dgeo1 = d_geo1;
-    float* dW[4]; float* dB[4];
-    for (int l = 0; l < 4; ++l) {
-        dW[l] = d_plain + plain_w_off(P_G1_0 + l);
-        dB[l] = dW[l] + (size_t)plain_dims[P_G1_0 + l][0] * plain_dims[P_G1_0 + l][1];
-    }
-    const int blocks = field_grid_blocks();
-    for (int64_t c0 = 0; c0 < N; c0 += L.chunk) {
-        const int64_t n = (N - c0 < L.chunk) ? (N - c0) : L.chunk;
-        kpn_points ps{pts + c0 * 3, pts + c0 * 3, nullptr, nullptr, nullptr, 1, nullptr, 0.0f};
-        hipMemsetAsync(count, 0, 4 * sizeof(int), (hipStream_t)stream);
-        KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
-                   (uint8_t*)nullptr, list, count);
-        KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, (const int*)count, V, rows_dev);
-        KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1,
-                   d_x + c0 * V * 64, B);
-        float* partial = reinterpret_cast<float*>(base + L.partial);
-        float* dbp = reinterpret_cast<float*>(base + L.dbp);
-        auto wgrad = [&](auto mv, auto enc, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
-            constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value;
-            const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
-            KPN_LAUNCH(k_weight_grad<MV>, dim3(nworkers), dim3(64 * gz), stream, dY, ldy, X, ldx, Kc,
-                       (const int64_t*)rows_dev, partial, dbp);
-            constexpr int nelem = MV * 2 * 16 * 64 + MV * 32;
-            KPN_LAUNCH((k_weight_grad_reduce<MV, ENC>), dim3((nelem + 31) / 32, gz), dim3(256), stream,
-                       (const float*)partial, (const float*)dbp, nworkers, M, Kc, dW[layer], plain_dims[P_G1_0 + layer][1],
-                       dB[layer]);
-        };
-        wgrad(kpn_ic<4>{}, kpn_ic<1>{}, B.D0, 128, 128, B.X0, KPN_LDX0, 232, 0);
-        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, B.D1, 128, 128, B.X1, 128, 128, 1);
-        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, B.D2, 128, 120, B.X2, KPN_LDX2, 136, 2);
-        wgrad(kpn_ic<2>{}, kpn_ic<0>{}, B.D3, 64, 64, B.X3, 128, 120, 3);
-    }
-    return check_launch("geo rows backward");
+    return run_backward(d, scene_ws, wp, N, pts, nullptr, 0, keep_mask, nullptr, 0.0f, d_x, nullptr, d_plain, d_geo0, d_geo1, ws,
+                        ws_bytes, stream);
+}
+
+extern "C" size_t kpn_query_backward_geometry_workspace_bytes(int64_t N, int32_t V) {
+    if (N <= 0 || V <= 0) return 0;
+    return bwd_layout(N, V, 1).total;
+}
+
+extern "C" int kpn_query_backward_geometry(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N,
+                                           const float* pts, int32_t mode, uint32_t keep_mask, const float* noise,
+                                           float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1,
+                                           void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (raw query) or 1 (eval_func)");
+    KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
+    if (N == 0) return KPN_OK;
+    KPN_REQUIRE(scene_ws && wp && pts && d_out && d_plain && d_geo0 && d_geo1 && ws, "null pointer");
+    return run_backward(d, scene_ws, wp, N, pts, nullptr, mode, keep_mask, noise, noise_std, nullptr, d_out, d_plain, d_geo0,
+                        d_geo1, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

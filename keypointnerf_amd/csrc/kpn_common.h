@@ -140,8 +140,9 @@ constexpr int kpn_k2_floats() { return kpn_fwd_floats() - kpn_k2_base(); }
 // accumulator is the B operand layout of the next MFMA layer in either direction).  No bias part is used.
 //   BSEG_G1_3T : dY3(64)  -> dX3(120 of 128)          BSEG_G1_2T : dA2(120 of 128) -> [dX2 chained 128 | hd 8 (block 4)]
 //   BSEG_G1_1T : dA1(128) -> dX1(128)                 BSEG_G1_0T : dA0(128) -> d(geometry channels 64)
-enum { BSEG_G1_3T, BSEG_G1_2T, BSEG_G1_1T, BSEG_G1_0T, BSEG_COUNT };
-#define KPN_BSEG_SHAPES {32, 4, 4}, {64, 5, 4}, {64, 4, 4}, {64, 2, 4}
+//   BSEG_G2_1T : dA(h1 pre)(64) -> d softplus(h0)(64)   BSEG_G2_0T : dA(h0 pre)(64) -> d pooled (128 = mean64 | var64)
+enum { BSEG_G1_3T, BSEG_G1_2T, BSEG_G1_1T, BSEG_G1_0T, BSEG_G2_1T, BSEG_G2_0T, BSEG_COUNT };
+#define KPN_BSEG_SHAPES {32, 4, 4}, {64, 5, 4}, {64, 4, 4}, {64, 2, 4}, {32, 2, 4}, {32, 4, 4}
 static constexpr kpn_seg_shape kpn_bseg_shapes[BSEG_COUNT] = {KPN_BSEG_SHAPES};
 constexpr int kpn_bseg_wfloats(int seg) { return kpn_bseg_shapes[seg].ks * kpn_bseg_shapes[seg].nob * 64; }
 constexpr int kpn_bseg_woff(int seg) {
@@ -149,7 +150,11 @@ constexpr int kpn_bseg_woff(int seg) {
     for (int i = 0; i < seg; ++i) o += kpn_bseg_wfloats(i);
     return o;
 }
-constexpr int kpn_packed_floats() { return kpn_bseg_woff(BSEG_COUNT); }
+// backward row vectors: one forward OUTPUT row of a narrow layer spread over the chained layout of its 64 inputs,
+// [2 blocks][2 halves][16 regs]: d in[32b + rowmap(r,h)] = row[(2b+h)*16 + r] * d out   (a rank-1 VALU update)
+enum { BROW_G2_2_SDF, BROW_G2_2_RAD, BROW_COUNT };  // layers2.2 rows 0 (sdf_raw) and 1 (rad)
+constexpr int kpn_brow_off(int row) { return kpn_bseg_woff(BSEG_COUNT) + row * 64; }
+constexpr int kpn_packed_floats() { return kpn_brow_off(BROW_COUNT); }
 
 // Row scratch written by k_geo_rows and read by k_fuse_color: per work item (tile, view) KPN_ROW_SLABS
 // slabs of [64 lanes] float4.  Slabs 0..7: the lane's 32 registers of the 64-vector (block b = slab/4);

@@ -235,6 +235,33 @@ def geo_rows_backward(scene, weights, pts, d_x, keep_mask=0xFFFFFFFF):
     return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2)
 
 
+def query_backward_geometry(scene, weights, pts, d_out, mode=1, keep_mask=0xFFFFFFFF, noise=None, noise_std=0.0):
+    """Reverse pass of the field evaluation w.r.t. its two geometry outputs (kpn_query_backward_geometry): pooling,
+    layers2, layers1 and the feat_geo gathers.  d_out (N,5) or (1,N,5): columns 0,1 are propagated (mode 1:
+    [sigma, sdf] of eval_func, the training path; mode 0: query's raw [sdf_raw, rad]); the colour columns are not yet.
+    Returns (d_plain, d_geo0, d_geo1) like geo_rows_backward."""
+    L = kl.get_library()
+    p = _dev(pts, "pts").reshape(-1, 3)
+    N, V = p.shape[0], scene.n_views
+    g = _dev(d_out, "d_out").reshape(-1, 5)
+    if g.shape[0] != N:
+        raise ValueError(f"d_out must have {N} rows")
+    nz = None if noise is None else _dev(noise, "noise").reshape(-1)
+    if nz is not None and nz.shape[0] != N:
+        raise ValueError("noise must have one value per point")
+    d = scene.desc
+    d_plain = torch.zeros(L.kpn_plain_weight_floats(), dtype=_f32, device=p.device)
+    d_g0 = torch.zeros(V, d.geo0_h, d.geo0_w, 64, dtype=_f32, device=p.device)
+    d_g1 = torch.zeros(V, d.geo1_h, d.geo1_w, 8, dtype=_f32, device=p.device)
+    if N > 0:
+        nb = L.kpn_query_backward_geometry_workspace_bytes(N, V)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=p.device)
+        L.check(L.kpn_query_backward_geometry(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), N, _p(p), int(mode),
+                                              int(keep_mask) & 0xFFFFFFFF, None if nz is None else _p(nz), float(noise_std), _p(g),
+                                              _p(d_plain), _p(d_g0), _p(d_g1), _p(ws), nb, _stream()))
+    return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2)
+
+
 class RenderPlan:
     """Pre-allocated outputs + workspace for repeated renders of one pixel grid (no per-call allocation)."""
 

@@ -16,7 +16,7 @@ SIMT_DIR = os.path.join(ROOT, "tests", "simt")
 SIMT_SO = os.path.join(SIMT_DIR, "_build", "libkpnerf_simt.so")
 CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
 _SOURCES = [os.path.join(ROOT, "keypointnerf_amd", "csrc", f) for f in
-            ("kpn_api.hip", "ray_kernels.hip", "field_kernels.hip", "field_bwd_kernels.hip", "kpn_device.h", "kpn_common.h")] + \
+            ("kpn_api.hip", "ray_kernels.hip", "field_kernels.hip", "field_bwd_kernels.hip", "fuse_bwd_kernels.hip", "kpn_device.h", "kpn_common.h")] + \
            [os.path.join(SIMT_DIR, f) for f in ("simt.h", "simt.cpp")] + [os.path.join(ROOT, "include", "kpnerf.h")]
 
 
@@ -166,4 +166,21 @@ def geo_rows_backward(lib, hs, packed, pts, d_x, keep=0xFFFFFFFF):
     ws = np.zeros(nb, np.uint8)
     lib.check(lib.kpn_geo_rows_backward(ctypes.byref(d), ptr(hs.ws), ptr(packed), N, ptr(pts), keep, ptr(d_x), ptr(d_plain),
                                         ptr(d_g0), ptr(d_g1), ptr(ws), nb, None))
+    return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2)
+
+
+def query_backward_geometry(lib, hs, packed, pts, d_out, mode=0, keep=0xFFFFFFFF, noise=None, noise_std=0.0):
+    """kpn_query_backward_geometry on host buffers -> (d_plain, d_geo0 NCHW, d_geo1 NCHW)."""
+    pts = f32(pts).reshape(-1, 3)
+    N = pts.shape[0]
+    d_out = f32(d_out).reshape(N, 5)
+    d = hs.desc
+    d_plain = np.zeros(lib.kpn_plain_weight_floats(), np.float32)
+    d_g0 = np.zeros((hs.V, d.geo0_h, d.geo0_w, 64), np.float32)
+    d_g1 = np.zeros((hs.V, d.geo1_h, d.geo1_w, 8), np.float32)
+    nz = None if noise is None else f32(noise).reshape(-1)
+    nb = lib.kpn_query_backward_geometry_workspace_bytes(N, hs.V)
+    ws = np.zeros(nb, np.uint8)
+    lib.check(lib.kpn_query_backward_geometry(ctypes.byref(d), ptr(hs.ws), ptr(packed), N, ptr(pts), mode, keep, ptr(nz), noise_std,
+                                              ptr(d_out), ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(ws), nb, None))
     return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2)

@@ -197,3 +197,39 @@ def test_geo_rows_backward_kernels(env):
     ref = oracle.geo_rows_backward(osc, wflat, pts, G, keep=0b101)
     assert_geo_grads_close(got, ref, 1e-5)
     assert np.all(got[1][1] == 0) and np.all(got[2][1] == 0)
+
+
+def geometry_only(d_w):
+    """Zero everything but the layers1 / layers2 blocks of a flat parameter gradient (what the geometry reverse fills)."""
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    n = sum(o * i + o for _, _, (o, i), _ in HOTPATH_LAYERS[:7])
+    out = d_w.copy()
+    out[n:] = 0
+    return out
+
+
+def test_query_backward_geometry_kernels(env):
+    """k_geo_rows -> k_fuse_bwd -> k_geo_rows_bwd -> k_weight_grad (emulated) against kpo_query_backward with the
+    colour gradients zeroed: through eval_func (training path, with density noise and a dropped view) and raw."""
+    from tests.test_oracle_vs_golden import assert_flat_grads_close
+    lib, packed, wflat = env
+    scene, cfg, g = load_case("case_j_v3_query_grad")
+    hs = sh.HostScene(lib, scene)
+    osc = oracle.OracleScene(scene)
+    N = 192
+    pts, view = g["pts"][:N], g["view"][:N]
+    G = g["G"][:N].copy()
+    G[:, 2:] = 0
+    rng = np.random.default_rng(3)
+    noise = rng.standard_normal(N).astype(np.float32)
+    for mode, keep, nz, std in ((1, 0xFFFFFFFF, None, 0.0), (1, 0b011, noise, 0.5), (0, 0xFFFFFFFF, None, 0.0)):
+        Gm = G.copy()
+        if mode == 0:  # masked points' constant layers2(0) output is not differentiated by the kernels (header)
+            _, valid = oracle.query(osc, wflat, pts, view)
+            Gm[~valid] = 0
+        got = sh.query_backward_geometry(lib, hs, packed, pts, Gm, mode=mode, keep=keep, noise=nz, noise_std=std)
+        ref = oracle.query_backward(osc, wflat, pts, view, Gm, apply_eval_func=(mode == 1), keep=keep, noise=nz, noise_std=std)
+        assert np.abs(ref[0]).max() > 0
+        assert_flat_grads_close(got[0], geometry_only(ref[0]), 1e-5, f"mode{mode}")
+        for k in (1, 2):
+            assert np.abs(got[k] - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max(), (mode, k)
