@@ -145,6 +145,17 @@ int kpn_query_backward_geometry(const kpn_scene_desc* desc, const void* scene_ws
                                 float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of the WHOLE field evaluation, colour head included (<= 3 source views): everything above plus
+ * ibr_compress_gfeat, IBRRenderingHead (src/model.py:784-843, 1267-1302: ray_encoder, the ani_al blend weights,
+ * weighted mean/var over views, base / vis / out layers, softmax blend of the source colours) and the feat_tex gather.
+ * view (N,3): the query rays' directions.  d_out (N,5): all five columns are propagated.
+ * d_plain: += all hot-path parameters incl. the raw ani_al (last entry); d_tex (V, tex_h, tex_w, 8) channels-last, +=. */
+size_t kpn_query_backward_workspace_bytes(int64_t n_points, int32_t n_views);
+int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights, int64_t n_points,
+                       const float* pts, const float* view, int32_t mode, uint32_t keep_mask, const float* noise,
+                       float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1, float* d_tex,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).
  * mode 0: out = [sdf_raw, rad, r,g,b] exactly as query() returns;

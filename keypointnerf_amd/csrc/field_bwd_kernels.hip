@@ -380,7 +380,14 @@ __global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ d
 // Fixed-order sum of the workers' partial blocks, added to the plain-layout gradient (no atomics: the weight
 // gradient is deterministic).  A workgroup owns 32 consecutive elements; its 8 waves-quarters stride over the
 // workers and combine through LDS.  ENC: the first 168 columns of X0 are in (keypoint, PE block) order.
-template <int MV, int ENC>
+// CMAP: 0 = X columns are plain input features; 1 = X0 dump (first 168 columns in (keypoint, PE block) order);
+//       2 = base_layer.0's [mean' | var' | x'] dump (3 x 36 columns, x' order).  OMAP: 1 = dY rows are in x' order.
+__device__ __forceinline__ int kpn_grad_col(int cmap, int c) {
+    if (cmap == 1) return c < 168 ? (c % 7) * 24 + c / 7 : c;
+    if (cmap == 2) { const int q = c % 36; return q < 35 ? (c / 36) * 35 + kpn_xprime_to_orig(q) : -1; }
+    return c;
+}
+template <int MV, int ENC, int OMAP = 0>
 __global__ __launch_bounds__(256) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ dbp,
                                                             int nworkers, int M, int Kc, float* __restrict__ dW, int in_dim,
                                                             float* __restrict__ db) {
@@ -404,15 +411,16 @@ __global__ __launch_bounds__(256) void k_weight_grad_reduce(const float* __restr
     for (int k = 1; k < 8; ++k) s += red[k][el];
     if (e < TILE_E) {
         const int lane = e & 63, r = (e >> 6) & 15, ab = e >> 10, a = ab >> 1, b = ab & 1;
-        const int o = MV * KPN_ROWMAP(r, lane >> 5) + a;
+        int o = MV * KPN_ROWMAP(r, lane >> 5) + a;
         const int c = z * 64 + 2 * (lane & 31) + b;
         if (o < M && c < Kc) {
-            const int f = (ENC && c < 168) ? (c % 7) * 24 + c / 7 : c;
-            dW[(size_t)o * in_dim + f] += s;
+            const int f = kpn_grad_col(ENC, c);
+            if (OMAP) o = kpn_xprime_to_orig(o);
+            if (f >= 0) dW[(size_t)o * in_dim + f] += s;
         }
     } else if (z == 0 && e < TILE_E + MV * 32) {
         const int q = e - TILE_E, a = q / 32, i = q % 32;
         const int o = MV * i + a;
-        if (o < M) db[o] += s;
+        if (o < M) db[OMAP ? kpn_xprime_to_orig(o) : o] += s;
     }
 }

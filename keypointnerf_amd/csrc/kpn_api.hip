@@ -86,8 +86,8 @@ void pack_segment(float* packed, int seg, const float* W, const float* b, int ou
 }
 // a transposed (backward) segment: out row R of the stream is forward INPUT feature in_of_row(R), K-step (s,h) is
 // forward OUTPUT feature chain_feature(s,h); value W[o][f]
-template <class RowMap>
-void pack_segment_t(float* packed, int bseg, const float* W, int out_dim, int in_dim, RowMap in_of_row) {
+template <class RowMap, class KMap>
+void pack_segment_t(float* packed, int bseg, const float* W, int out_dim, int in_dim, RowMap in_of_row, KMap out_of_kstep) {
     const int KS = kpn_bseg_shapes[bseg].ks, NOB = kpn_bseg_shapes[bseg].nob, G = kpn_bseg_shapes[bseg].g;
     const int NF = G * NOB;
     float* w = packed + kpn_bseg_woff(bseg);
@@ -96,11 +96,15 @@ void pack_segment_t(float* packed, int bseg, const float* W, int out_dim, int in
             for (int lane = 0; lane < 64; ++lane) {
                 const int i = lane & 31, h = lane >> 5;
                 const int f = in_of_row(ob * 32 + i);
-                const int o = chain_feature(s, h);
+                const int o = out_of_kstep(s, h);
                 float val = 0.0f;
-                if (f >= 0 && f < in_dim && o < out_dim) val = W[(size_t)o * in_dim + f];
+                if (f >= 0 && f < in_dim && o >= 0 && o < out_dim) val = W[(size_t)o * in_dim + f];
                 w[((size_t)(s / G) * 64 + lane) * NF + (s % G) * NOB + ob] = val;
             }
+}
+template <class RowMap>
+void pack_segment_t(float* packed, int bseg, const float* W, int out_dim, int in_dim, RowMap in_of_row) {
+    pack_segment_t(packed, bseg, W, out_dim, in_dim, in_of_row, [](int s, int h) { return chain_feature(s, h); });
 }
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
 }  // namespace
@@ -181,6 +185,21 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
     // backward of layers2 (kpn_query_backward)
     pack_segment_t(P, BSEG_G2_1T, pl.w[P_G2_1], 64, 64, ident);
     pack_segment_t(P, BSEG_G2_0T, pl.w[P_G2_0], 64, 128, ident);
+    // backward of the colour head (k_color_bwd)
+    pack_segment_t(P, BSEG_CMPT, pl.w[P_CMP], 24, 128, ident);
+    pack_segment_t(P, BSEG_RE_1T, pl.w[P_RE_1], 35, 16, [](int R) { return R < 16 ? R : -1; },
+                   [](int s, int h) { const int q = xstep_row(s, h); return q < 35 ? xprime_to_orig(q) : -1; });
+    pack_segment_t(P, BSEG_BL_0AT, pl.w[P_BL_0], 64, 105, [](int R) {
+        const int part = R / 64, q = R % 64;
+        return q < 35 ? part * 35 + xprime_to_orig(q) : -1;
+    });
+    pack_segment_t(P, BSEG_BL_0BT, pl.w[P_BL_0], 64, 105, [](int R) { return R < 35 ? 70 + xprime_to_orig(R) : -1; });
+    pack_segment_t(P, BSEG_BL_1T, pl.w[P_BL_1], 32, 64, ident);
+    pack_segment_t(P, BSEG_V1_0T, pl.w[P_V1_0], 32, 32, ident);
+    pack_segment_t(P, BSEG_V1_1T, pl.w[P_V1_1], 32, 32, ident);  // the vis row (32) is a rank-1 VALU update (ROW_V1_VIS)
+    pack_segment_t(P, BSEG_V2_0T, pl.w[P_V2_0], 32, 32, ident);
+    pack_segment_t(P, BSEG_O_0T, pl.w[P_O_0], 16, 37, [](int R) { return R <= 32 ? R : -1; });
+    pack_segment_t(P, BSEG_O_1T, pl.w[P_O_1], 8, 16, [](int R) { return R < 16 ? R : -1; });
     for (int o = 0; o < 2; ++o)
         for (int b = 0; b < 2; ++b)
             for (int h = 0; h < 2; ++h)
@@ -202,7 +221,8 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
             for (int i = 0; i < 64; ++i) acc += pl.w[P_G2_2][o * 64 + i] * b2[i];
             o2[o] = acc + pl.b[P_G2_2][o];
         }
-        sc[1] = o2[0]; sc[2] = o2[1]; sc[3] = 0.0f;
+        sc[1] = o2[0]; sc[2] = o2[1];
+        sc[3] = pl.ani_al > 0.0f ? 1.0f : (pl.ani_al < 0.0f ? -1.0f : 0.0f);  // d|a|/da for the colour-head reverse
     }
     return KPN_OK;
 }
@@ -425,7 +445,12 @@ const int kGradWorkers = 3;     // row workers (one workgroup each; its waves ar
 const int kGradWorkers = 512;   // 2 workgroups per CU
 #endif
 // full = 1: the whole-query reverse (adds the forward row scratch, the per-point dumps and the d x_view rows)
-struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, partial, dbp, xscr, Xp, Xh0, Xh1, D20, D21, D22, dxrows, total; int64_t chunk; };
+// colour-head dumps, floats per (point, view) row, in kpn_color_bufs order (X buffers then dA buffers)
+const int kColorLd[25] = {4, 16, KPN_LD_XDIR, KPN_LD_XBL, 64, 32, 32, 32, 2, 32, 32, KPN_LD_XO0, 16, 8,
+                          2, 8, 16, 2, 32, KPN_LD_DV11, 32, 32, 64, KPN_LD_XDIR, 16};
+struct BwdLayout { size_t count, list, X0, X1, X2, X3, D0, D1, D2, D3, partial, dbp, xscr, Xp, Xh0, Xh1, D20, D21, D22, dxrows,
+                   color, color_bytes, Dcmp, total; int64_t chunk; };
+// full: 0 = geometry rows only; 1 = whole query, geometry outputs; 2 = whole query incl. the colour head
 BwdLayout bwd_layout(int64_t N, int V, int full) {
     BwdLayout L{};
     L.chunk = N < kBwdChunk ? N : kBwdChunk;
@@ -444,6 +469,13 @@ BwdLayout bwd_layout(int64_t N, int V, int full) {
         L.Xp = take(npts * 128 * 4); L.Xh0 = take(npts * 64 * 4); L.Xh1 = take(npts * 64 * 4);
         L.D20 = take(npts * 64 * 4); L.D21 = take(npts * 64 * 4); L.D22 = take(npts * 2 * 4);
         L.dxrows = take(rows * 64 * 4);
+    }
+    if (full == 2) {
+        size_t per_row = 0;
+        for (int i = 0; i < 25; ++i) per_row += kColorLd[i];
+        L.color_bytes = rows * per_row * 4;
+        L.color = take(L.color_bytes);
+        L.Dcmp = take(npts * 24 * 4);
     }
     L.total = o;
     return L;
@@ -467,9 +499,9 @@ namespace {
 // from d_out (N,5) [geometry outputs only so far: the colour head's reverse is not built].
 int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts, const float* view,
                  int mode, uint32_t keep_mask, const float* noise, float noise_std, const float* d_x, const float* d_out,
-                 float* d_plain, float* d_geo0, float* d_geo1, void* ws, size_t ws_bytes, void* stream) {
+                 float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws, size_t ws_bytes, void* stream) {
     const int V = d->n_views;
-    const int full = d_x == nullptr;
+    const int full = d_x != nullptr ? 0 : (d_tex ? 2 : 1);
     const BwdLayout L = bwd_layout(N, V, full);
     if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "backward workspace too small");
     kpn_scene_dev sc = scene_dev(d, scene_ws);
@@ -488,10 +520,37 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         F.Xp = fp(L.Xp); F.Xh0 = fp(L.Xh0); F.Xh1 = fp(L.Xh1); F.D20 = fp(L.D20); F.D21 = fp(L.D21); F.D22 = fp(L.D22);
         F.dxrows = fp(L.dxrows);
     }
+    kpn_color_bufs C{};
+    if (full == 2) {
+        const size_t rows = (size_t)((L.chunk + KPN_TILE - 1) / KPN_TILE) * KPN_TILE * V;
+        float* q = fp(L.color);
+        float** slots[25] = {&C.Xrd, &C.Xe1, &C.Xdir, &C.Xbl, &C.Xb1, &C.Xa, &C.Xv10, &C.Xv11, &C.Xt33, &C.Xv20, &C.Xv21, &C.Xo0,
+                             &C.Xo1, &C.Xo2, &C.Do2, &C.Do1, &C.Do0, &C.Dv21, &C.Dv20, &C.Dv11, &C.Dv10, &C.Dbl1, &C.Dbl0,
+                             &C.Dre1, &C.Dre0};
+        for (int i = 0; i < 25; ++i) { *slots[i] = q; q += rows * kColorLd[i]; }
+        C.Dcmp = fp(L.Dcmp);
+        C.dtex = d_tex;
+        C.dani = d_plain + kpn_plain_weight_floats() - 1;
+        F.Dcmp = C.Dcmp;
+    }
     float* partial = fp(L.partial);
     float* dbp = fp(L.dbp);
     const int blocks = field_grid_blocks();
+    const bool views_dropped = (keep_mask & ((1u << V) - 1u)) != ((1u << V) - 1u);
     // dW[layer] += dY^T X over the rows (which = 0) or points (which = 1) of this pass
+    // Kc: columns of the X dump (even); Kt: how many of them are real input features (<= Kc)
+    auto wgrad_ex = [&](auto mv, auto enc, auto omap, int which, const float* dY, int ldy, int M, const float* X, int ldx, int Kc,
+                        int Kt, int layer) {
+        constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value, OMAP = decltype(omap)::value;
+        const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
+        float* dW = d_plain + plain_w_off(layer);
+        float* dB = dW + (size_t)plain_dims[layer][0] * plain_dims[layer][1];
+        KPN_LAUNCH(k_weight_grad<MV>, dim3(nworkers), dim3(64 * gz), stream, dY, ldy, M, X, ldx, Kc,
+                   (const int64_t*)(rows_dev + which), partial, dbp);
+        constexpr int nelem = MV * 2 * 16 * 64 + MV * 32;
+        KPN_LAUNCH((k_weight_grad_reduce<MV, ENC, OMAP>), dim3((nelem + 31) / 32, gz), dim3(256), stream, (const float*)partial,
+                   (const float*)dbp, nworkers, M, Kt, dW, plain_dims[layer][1], dB);
+    };
     auto wgrad = [&](auto mv, auto enc, int which, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
         constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value;
         const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
@@ -513,14 +572,33 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         if (full) {
             float* xscr = fp(L.xscr);
             KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
+            if (full == 2) {
+                // rows of dropped views are skipped by k_color_bwd: their dumps must read as zeros in k_weight_grad
+                if (views_dropped) hipMemsetAsync(fp(L.color), 0, L.color_bytes, (hipStream_t)stream);
+                KPN_LAUNCH(k_color_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 4,
+                           (const float*)xscr, d_out + c0 * 5, C);
+                const kpn_ic<0> n0; const kpn_ic<1> n1; const kpn_ic<2> n2;
+                wgrad_ex(n1, n0, n0, 0, C.Do2, 2, 1, C.Xo2, 8, 8, 8, P_O_2);
+                wgrad_ex(n1, n0, n0, 0, C.Do1, 8, 8, C.Xo1, 16, 16, 16, P_O_1);
+                wgrad_ex(n1, n0, n0, 0, C.Do0, 16, 16, C.Xo0, KPN_LD_XO0, KPN_LD_XO0, 37, P_O_0);
+                wgrad_ex(n1, n0, n0, 0, C.Dv21, 2, 1, C.Xv21, 32, 32, 32, P_V2_1);
+                wgrad_ex(n1, n0, n0, 0, C.Dv20, 32, 32, C.Xv20, 32, 32, 32, P_V2_0);
+                wgrad_ex(n2, n0, n0, 0, C.Dv11, KPN_LD_DV11, 33, C.Xv11, 32, 32, 32, P_V1_1);
+                wgrad_ex(n1, n0, n0, 0, C.Dv10, 32, 32, C.Xv10, 32, 32, 32, P_V1_0);
+                wgrad_ex(n1, n0, n0, 0, C.Dbl1, 32, 32, C.Xb1, 64, 64, 64, P_BL_1);
+                wgrad_ex(n2, n2, n0, 0, C.Dbl0, 64, 64, C.Xbl, KPN_LD_XBL, KPN_LD_XBL, KPN_LD_XBL, P_BL_0);
+                wgrad_ex(n2, n0, n1, 0, C.Dre1, KPN_LD_XDIR, 35, C.Xe1, 16, 16, 16, P_RE_1);
+                wgrad_ex(n1, n0, n0, 0, C.Dre0, 16, 16, C.Xrd, 4, 4, 4, P_RE_0);
+            }
             KPN_LAUNCH(k_fuse_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 2,
                        (const float*)xscr, mode, d_out + c0 * 5, F);
             wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 1, F.D20, 64, 64, F.Xp, 128, 128, P_G2_0);
             wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 1, F.D21, 64, 64, F.Xh0, 64, 64, P_G2_1);
             wgrad(kpn_ic<1>{}, kpn_ic<0>{}, 1, F.D22, 2, 2, F.Xh1, 64, 64, P_G2_2);
+            if (full == 2) wgrad(kpn_ic<1>{}, kpn_ic<0>{}, 1, C.Dcmp, 24, 24, F.Xp, 128, 128, P_CMP);
         }
         KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 3,
-                   full ? (const float*)F.dxrows : d_x + c0 * V * 64, full, B);
+                   full ? (const float*)F.dxrows : d_x + c0 * V * 64, full ? 1 : 0, B);
         wgrad(kpn_ic<4>{}, kpn_ic<1>{}, 0, B.D0, 128, 128, B.X0, KPN_LDX0, 232, P_G1_0);
         wgrad(kpn_ic<4>{}, kpn_ic<0>{}, 0, B.D1, 128, 128, B.X1, 128, 128, P_G1_1);
         wgrad(kpn_ic<4>{}, kpn_ic<0>{}, 0, B.D2, 128, 120, B.X2, KPN_LDX2, 136, P_G1_2);
@@ -542,8 +620,8 @@ extern "C" int kpn_geo_rows_backward(const kpn_scene_desc* d, const void* scene_
     KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
     if (N == 0) return KPN_OK;
     KPN_REQUIRE(scene_ws && wp && pts && d_x && d_plain && d_geo0 && d_geo1 && ws, "null pointer");
-    return run_backward(d, scene_ws, wp, N, pts, nullptr, 0, keep_mask, nullptr, 0.0f, d_x, nullptr, d_plain, d_geo0, d_geo1, ws,
-                        ws_bytes, stream);
+    return run_backward(d, scene_ws, wp, N, pts, nullptr, 0, keep_mask, nullptr, 0.0f, d_x, nullptr, d_plain, d_geo0, d_geo1, nullptr,
+                        ws, ws_bytes, stream);
 }
 
 extern "C" size_t kpn_query_backward_geometry_workspace_bytes(int64_t N, int32_t V) {
@@ -561,7 +639,26 @@ extern "C" int kpn_query_backward_geometry(const kpn_scene_desc* d, const void* 
     if (N == 0) return KPN_OK;
     KPN_REQUIRE(scene_ws && wp && pts && d_out && d_plain && d_geo0 && d_geo1 && ws, "null pointer");
     return run_backward(d, scene_ws, wp, N, pts, nullptr, mode, keep_mask, noise, noise_std, nullptr, d_out, d_plain, d_geo0,
-                        d_geo1, ws, ws_bytes, stream);
+                        d_geo1, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" size_t kpn_query_backward_workspace_bytes(int64_t N, int32_t V) {
+    if (N <= 0 || V <= 0) return 0;
+    return bwd_layout(N, V, 2).total;
+}
+
+extern "C" int kpn_query_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts,
+                                  const float* view, int32_t mode, uint32_t keep_mask, const float* noise, float noise_std,
+                                  const float* d_out, float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (raw query) or 1 (eval_func)");
+    KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
+    KPN_REQUIRE(d->n_views <= 3, "the colour-head reverse is built for <= 3 source views (use kpn_query_backward_geometry beyond)");
+    if (N == 0) return KPN_OK;
+    KPN_REQUIRE(scene_ws && wp && pts && view && d_out && d_plain && d_geo0 && d_geo1 && d_tex && ws, "null pointer");
+    return run_backward(d, scene_ws, wp, N, pts, view, mode, keep_mask, noise, noise_std, nullptr, d_out, d_plain, d_geo0, d_geo1,
+                        d_tex, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -141,8 +141,17 @@ constexpr int kpn_k2_floats() { return kpn_fwd_floats() - kpn_k2_base(); }
 //   BSEG_G1_3T : dY3(64)  -> dX3(120 of 128)          BSEG_G1_2T : dA2(120 of 128) -> [dX2 chained 128 | hd 8 (block 4)]
 //   BSEG_G1_1T : dA1(128) -> dX1(128)                 BSEG_G1_0T : dA0(128) -> d(geometry channels 64)
 //   BSEG_G2_1T : dA(h1 pre)(64) -> d softplus(h0)(64)   BSEG_G2_0T : dA(h0 pre)(64) -> d pooled (128 = mean64 | var64)
-enum { BSEG_G1_3T, BSEG_G1_2T, BSEG_G1_1T, BSEG_G1_0T, BSEG_G2_1T, BSEG_G2_0T, BSEG_COUNT };
-#define KPN_BSEG_SHAPES {32, 4, 4}, {64, 5, 4}, {64, 4, 4}, {64, 2, 4}, {32, 2, 4}, {32, 4, 4}
+// colour head (k_color_bwd); "x'" is the forward kernels' [lat24 | rgb3 | tex8] order of the 35-vector:
+//   BSEG_CMPT  : d lat(24) -> d pooled(128)                 BSEG_RE_1T : d dir(35, x' K-steps) -> d elu(ray_encoder.0)(16)
+//   BSEG_BL_0AT: sum_v dA(base_layer.0)(64) -> [d mean'(35) in blocks 0,1 | d var'(35) in blocks 2,3]
+//   BSEG_BL_0BT: dA(base_layer.0)(64) -> d x'(35)           BSEG_BL_1T : dA(base_layer.2)(32) -> d elu(base_layer.0)(64)
+//   BSEG_V1_0T, BSEG_V1_1T (rows 0..31), BSEG_V2_0T : 32 -> 32
+//   BSEG_O_0T  : dA(out_layer.0)(16) -> [d x(32) | d vis (block 1, row 0)]      BSEG_O_1T : dA(out_layer.2)(8) -> d elu(out_layer.0)(16)
+enum { BSEG_G1_3T, BSEG_G1_2T, BSEG_G1_1T, BSEG_G1_0T, BSEG_G2_1T, BSEG_G2_0T,
+       BSEG_CMPT, BSEG_RE_1T, BSEG_BL_0AT, BSEG_BL_0BT, BSEG_BL_1T, BSEG_V1_0T, BSEG_V1_1T, BSEG_V2_0T, BSEG_O_0T, BSEG_O_1T,
+       BSEG_COUNT };
+#define KPN_BSEG_SHAPES {32, 4, 4}, {64, 5, 4}, {64, 4, 4}, {64, 2, 4}, {32, 2, 4}, {32, 4, 4}, \
+    {12, 4, 4}, {20, 1, 4}, {32, 4, 4}, {32, 2, 4}, {16, 2, 4}, {16, 1, 4}, {16, 1, 4}, {16, 1, 4}, {8, 2, 4}, {4, 1, 4}
 static constexpr kpn_seg_shape kpn_bseg_shapes[BSEG_COUNT] = {KPN_BSEG_SHAPES};
 constexpr int kpn_bseg_wfloats(int seg) { return kpn_bseg_shapes[seg].ks * kpn_bseg_shapes[seg].nob * 64; }
 constexpr int kpn_bseg_woff(int seg) {
@@ -162,5 +171,7 @@ constexpr int kpn_packed_floats() { return kpn_brow_off(BROW_COUNT); }
 // [r,g,b, pooling weight | ray_diff(3), dot], h=1 lanes hold the 8 texture channels.
 #define KPN_ROW_SLABS 10
 
+// x' order of the colour head's 35-vector: rows 0..23 = lat (orig 11..34), 24..26 = rgb (orig 0..2), 27..34 = tex (orig 3..10)
+constexpr int kpn_xprime_to_orig(int q) { return q < 24 ? 11 + q : q - 24; }
 // row of the 32x32 D tile held by register r of a lane in half h
 #define KPN_ROWMAP(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

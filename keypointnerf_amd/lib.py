@@ -68,6 +68,9 @@ _SIGNATURES = {
     "kpn_query_backward_geometry_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "kpn_query_backward_geometry": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_i32, ctypes.c_uint32, c_p,
                                                    ctypes.c_float, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "kpn_query_backward_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "kpn_query_backward": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, ctypes.c_uint32, c_p,
+                                          ctypes.c_float, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "kpn_query_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "kpn_query": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_sz, c_p]),
     "kpn_render_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),

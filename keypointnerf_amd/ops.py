@@ -262,6 +262,35 @@ def query_backward_geometry(scene, weights, pts, d_out, mode=1, keep_mask=0xFFFF
     return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2)
 
 
+def query_backward(scene, weights, pts, view, d_out, mode=1, keep_mask=0xFFFFFFFF, noise=None, noise_std=0.0):
+    """Reverse pass of the whole field evaluation incl. the colour head (kpn_query_backward, <= 3 source views):
+    what loss.backward() does for KeypointNeRF.query + eval_func in training_step (reference src/model.py:128-155).
+    pts, view (N,3)/(1,N,3); d_out (N,5) = d loss / d [sigma, sdf, r, g, b] (mode 1) or d [sdf_raw, rad, r, g, b] (mode 0).
+    Returns (d_plain, d_geo0, d_geo1, d_tex): flat effective-parameter gradient (weights.plain_grads_to_state_dict maps it
+    to weight_g / weight_v / bias / ani_al) and the feature-map gradients shaped like feat_geo[0], feat_geo[1], feat_tex."""
+    L = kl.get_library()
+    p, vw = _dev(pts, "pts").reshape(-1, 3), _dev(view, "view").reshape(-1, 3)
+    N, V = p.shape[0], scene.n_views
+    g = _dev(d_out, "d_out").reshape(-1, 5)
+    if g.shape[0] != N or vw.shape[0] != N:
+        raise ValueError(f"view and d_out must have {N} rows")
+    nz = None if noise is None else _dev(noise, "noise").reshape(-1)
+    if nz is not None and nz.shape[0] != N:
+        raise ValueError("noise must have one value per point")
+    d = scene.desc
+    d_plain = torch.zeros(L.kpn_plain_weight_floats(), dtype=_f32, device=p.device)
+    d_g0 = torch.zeros(V, d.geo0_h, d.geo0_w, 64, dtype=_f32, device=p.device)
+    d_g1 = torch.zeros(V, d.geo1_h, d.geo1_w, 8, dtype=_f32, device=p.device)
+    d_tx = torch.zeros(V, d.tex_h, d.tex_w, 8, dtype=_f32, device=p.device)
+    if N > 0:
+        nb = L.kpn_query_backward_workspace_bytes(N, V)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=p.device)
+        L.check(L.kpn_query_backward(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), N, _p(p), _p(vw), int(mode),
+                                     int(keep_mask) & 0xFFFFFFFF, None if nz is None else _p(nz), float(noise_std), _p(g), _p(d_plain),
+                                     _p(d_g0), _p(d_g1), _p(d_tx), _p(ws), nb, _stream()))
+    return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2), d_tx.permute(0, 3, 1, 2)
+
+
 class RenderPlan:
     """Pre-allocated outputs + workspace for repeated renders of one pixel grid (no per-call allocation)."""
 

@@ -39,6 +39,21 @@ def main():
     mac = 62400 + 48576 + 70080
     print(f"geo_rows_backward: {N} points, {rows} valid rows: {dt*1e3:.2f} ms/call, {rows/dt/1e6:.2f} M rows/s, "
           f"{2*mac*rows/dt/1e12:.1f} TFLOP/s (fp32 MFMA peak 157.3)")
+    # the whole field evaluation: forward (kpn_query, mode 1) and its full reverse (kpn_query_backward)
+    Vw = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
+    Gq = torch.randn(N, 5, device=dev)
+    for name, fn in (("query forward", lambda: ops.query(ps, w, P[None], Vw[None], mode=1)),
+                     ("query_backward (full)", lambda: ops.query_backward(ps, w, P, Vw, Gq, mode=1)),
+                     ("query_backward_geometry", lambda: ops.query_backward_geometry(ps, w, P, Gq, mode=1))):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        print(f"{name}: {dt*1e3:.2f} ms/call = {N/dt/1e6:.1f} M points/s")
 
 
 if __name__ == "__main__":

@@ -184,3 +184,21 @@ def query_backward_geometry(lib, hs, packed, pts, d_out, mode=0, keep=0xFFFFFFFF
     lib.check(lib.kpn_query_backward_geometry(ctypes.byref(d), ptr(hs.ws), ptr(packed), N, ptr(pts), mode, keep, ptr(nz), noise_std,
                                               ptr(d_out), ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(ws), nb, None))
     return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2)
+
+
+def query_backward(lib, hs, packed, pts, view, d_out, mode=0, keep=0xFFFFFFFF, noise=None, noise_std=0.0):
+    """kpn_query_backward on host buffers -> (d_plain, d_geo0, d_geo1, d_tex) (maps as NCHW views)."""
+    pts, view = f32(pts).reshape(-1, 3), f32(view).reshape(-1, 3)
+    N = pts.shape[0]
+    d_out = f32(d_out).reshape(N, 5)
+    d = hs.desc
+    d_plain = np.zeros(lib.kpn_plain_weight_floats(), np.float32)
+    d_g0 = np.zeros((hs.V, d.geo0_h, d.geo0_w, 64), np.float32)
+    d_g1 = np.zeros((hs.V, d.geo1_h, d.geo1_w, 8), np.float32)
+    d_tx = np.zeros((hs.V, d.tex_h, d.tex_w, 8), np.float32)
+    nz = None if noise is None else f32(noise).reshape(-1)
+    nb = lib.kpn_query_backward_workspace_bytes(N, hs.V)
+    ws = np.zeros(nb, np.uint8)
+    lib.check(lib.kpn_query_backward(ctypes.byref(d), ptr(hs.ws), ptr(packed), N, ptr(pts), ptr(view), mode, keep, ptr(nz), noise_std,
+                                     ptr(d_out), ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(d_tx), ptr(ws), nb, None))
+    return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2), d_tx.transpose(0, 3, 1, 2)

@@ -338,3 +338,42 @@ def test_query_backward_geometry(ops, golden_weights):
         assert_flat_grads_close(got[0].cpu().numpy(), geometry_only(ref[0]), 2e-5, f"keep{keep:b}")
         for k in (1, 2):
             assert np.abs(got[k].cpu().numpy() - ref[k]).max() <= 2e-5 * np.abs(ref[k]).max(), k
+
+
+@pytest.mark.parametrize("keep", [0xFFFFFFFF, 0b011])
+def test_query_backward(ops, golden_weights, keep):
+    """kpn_query_backward (whole field evaluation incl. the colour head) on the MI355X: against the reference's own
+    loss.backward() through net.query + eval_func (golden case j, all views kept) and against the oracle (dropped view,
+    density noise); weight-norm parameter gradients as the optimizer sees them."""
+    from oracle import oracle
+    from keypointnerf_amd.weights import plain_grads_to_state_dict
+    from tests.test_oracle_vs_golden import assert_flat_grads_close, golden_flat_grads
+    sd, w = golden_weights
+    scene, cfg, g = load_case("case_j_v3_query_grad")
+    s, ps = _prep(ops, scene)
+    pts, view, G = (torch.from_numpy(g[k]).cuda() for k in ("pts", "view", "G"))
+    noise = np.random.default_rng(9).standard_normal(G.shape[0]).astype(np.float32) if keep != 0xFFFFFFFF else None
+    std = 0.4 if noise is not None else 0.0
+    got = ops.query_backward(ps, w, pts, view, G, mode=1, keep_mask=keep, noise=None if noise is None else torch.from_numpy(noise).cuda(),
+                             noise_std=std)
+    got = [x.cpu().numpy() for x in got]
+    osc, wflat = oracle.OracleScene(scene), oracle.flat_weights(sd)
+    ref = oracle.query_backward(osc, wflat, g["pts"], g["view"], g["G"], apply_eval_func=True, keep=keep, noise=noise, noise_std=std)
+    assert_flat_grads_close(got[0], ref[0], 3e-5, "oracle", ani_rtol=5e-4)
+    for k in (1, 2, 3):
+        assert np.abs(got[k] - ref[k]).max() <= 3e-5 * np.abs(ref[k]).max(), k
+    if keep == 0xFFFFFFFF:
+        assert_flat_grads_close(got[0], golden_flat_grads(g, "evalfunc"), 6e-5, "golden", ani_rtol=5e-4)
+        for k, key in ((1, "d_geo0"), (2, "d_geo1"), (3, "d_tex")):
+            refk = g[f"evalfunc.{key}"]
+            assert np.abs(got[k] - refk).max() <= 6e-5 * np.abs(refk).max(), key
+        pg = plain_grads_to_state_dict(sd, got[0])
+        checked = 0
+        for k in g:
+            if k.startswith("evalfunc.param_grad."):
+                name = k[len("evalfunc.param_grad."):]
+                refp = g[k]
+                tol = 5e-4 if name.endswith("ani_al") else 6e-5
+                assert np.abs(pg[name].numpy().reshape(refp.shape) - refp).max() <= tol * np.abs(refp).max() + 2e-6, name
+                checked += 1
+        assert checked >= 40

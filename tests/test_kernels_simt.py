@@ -233,3 +233,28 @@ def test_query_backward_geometry_kernels(env):
         assert_flat_grads_close(got[0], geometry_only(ref[0]), 1e-5, f"mode{mode}")
         for k in (1, 2):
             assert np.abs(got[k] - ref[k]).max() <= 1e-5 * np.abs(ref[k]).max(), (mode, k)
+
+
+@pytest.mark.parametrize("mode,keep", [(1, 0xFFFFFFFF), (1, 0b110), (0, 0xFFFFFFFF)])
+def test_query_backward_kernels(env, mode, keep):
+    """The whole reverse pass (k_geo_rows -> k_color_bwd -> k_fuse_bwd -> k_geo_rows_bwd -> k_weight_grad, emulated)
+    against kpo_query_backward, and for the un-dropped cases directly against the reference autograd (golden j)."""
+    from tests.test_oracle_vs_golden import assert_flat_grads_close, golden_flat_grads
+    lib, packed, wflat = env
+    scene, cfg, g = load_case("case_j_v3_query_grad")
+    hs = sh.HostScene(lib, scene)
+    osc = oracle.OracleScene(scene)
+    pts, view, G = g["pts"], g["view"], g["G"].copy()
+    variant = "evalfunc" if mode == 1 else "raw"
+    if mode == 0:  # masked points' constant layers2(0) output is not differentiated by the kernels (header)
+        G[~g["raw.valid"].astype(bool), :2] = 0
+    got = sh.query_backward(lib, hs, packed, pts, view, G, mode=mode, keep=keep)
+    ref = oracle.query_backward(osc, wflat, pts, view, G, apply_eval_func=(mode == 1), keep=keep)
+    assert_flat_grads_close(got[0], ref[0], 2e-5, f"mode{mode}", ani_rtol=5e-4)
+    for k in (1, 2, 3):
+        assert np.abs(got[k] - ref[k]).max() <= 2e-5 * np.abs(ref[k]).max(), (mode, k)
+    if keep == 0xFFFFFFFF and mode == 1:
+        assert_flat_grads_close(got[0], golden_flat_grads(g, variant), 6e-5, "golden")
+        for k, key in ((1, "d_geo0"), (2, "d_geo1"), (3, "d_tex")):
+            refk = g[f"{variant}.{key}"]
+            assert np.abs(got[k] - refk).max() <= 6e-5 * np.abs(refk).max(), key
