@@ -333,6 +333,82 @@ def run_query_grad_case(net, name, n_views, src_hw, mask, n_pts, seed, S=8, keep
     print(f"{name} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_train_grad_case(net, name, n_views, src_hw, tar_hw, mask, Sc, Sf, seed, patch=8, noise_std=0.01):
+    """loss.backward() through the TRAIN branch of batch_render_pifu_nerf (the field part of training_step,
+    src/model.py:128-155): the unmodified reference in train mode, every random draw recorded as in run_train_case,
+    loss = sum_k <out_k, G_k> over its seven outputs.  Recorded: the gradients of every hot-path parameter
+    (weight_g / weight_v / weight / bias / ani_al) and of feat_geo[0], feat_geo[1], feat_tex."""
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=tar_hw, mask=mask, seed=seed)
+    Ht, Wt = tar_hw
+    yy, xx = torch.meshgrid(torch.arange(Ht), torch.arange(Wt), indexing="ij")
+    msk = (((yy - Ht / 2) ** 2 + (xx - Wt / 2) ** 2) < (0.3 * min(Ht, Wt)) ** 2)[None, None]
+    log = []
+    orig = {"rand_like": torch.rand_like, "randn_like": torch.randn_like, "rand": torch.rand}
+
+    def wrap(nm):
+        def f(*a, **k):
+            r = orig[nm](*a, **k)
+            log.append((nm, r.clone()))
+            return r
+        return f
+
+    feat_geo = [f.clone().requires_grad_(True) for f in scene["feat_geo"]]
+    feat_tex = scene["feat_tex"].clone().requires_grad_(True)
+    net.train()
+    net.train_out_h = net.train_out_w = patch
+    rec = Recorder(net)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.rand_like, torch.randn_like, torch.rand = wrap("rand_like"), wrap("randn_like"), wrap("rand")
+    try:
+        cfg = dict(fine=True, uniform=False, sample_per_ray_c=Sc, sample_per_ray_f=Sf, rand_noise_std=noise_std,
+                   src_foreground_mask=scene["src_foreground_mask"], bounds=scene["bounds"], msk=msk)
+        net.zero_grad()
+        out = net.batch_render_pifu_nerf(net, scene["img"], scene["cam"], n_views, scene["cam_tar"], 5, 0, None,
+                                         feat_geo, feat_tex, dict(scene["sp_data"]), None, **cfg)
+        gen = torch.Generator().manual_seed(seed + 100)
+        keys = ["tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf"]
+        G = {k: torch.randn(out[k].shape, generator=gen) for k in keys}
+        sum((out[k] * G[k]).sum() for k in keys).backward()
+    finally:
+        torch.rand_like, torch.randn_like, torch.rand = orig["rand_like"], orig["randn_like"], orig["rand"]
+        rec.restore()
+        net.eval()
+    names = [n for n, _ in log]
+    assert names == ["rand_like", "rand_like", "rand_like", "randn_like", "rand", "rand_like", "rand_like", "randn_like"], names
+    t = [x for _, x in log]
+
+    def keep_vec(r_mask, r_perm):                                  # src/model.py:743-747
+        dd = torch.zeros(1, n_views, 1, 1)
+        dd[:, :1] = 1.0
+        dd[:, 1:] = (r_mask > 0.5).float()
+        return torch.gather(dd, 1, r_perm.argsort(dim=1)).reshape(-1)
+
+    keep_c, keep_f = keep_vec(t[1], t[2]), keep_vec(t[5], t[6])
+    np.random.seed(seed)
+    coords = torch.stack(torch.where(msk.squeeze())[::-1], -1)
+    center = coords[np.random.randint(0, coords.shape[0], 1)]
+    yg, xg = torch.meshgrid(torch.arange(0, patch), torch.arange(0, patch), indexing="ij")
+    grids = torch.stack([xg, yg], -1).view(-1, 2) + (center - patch // 2)
+    grids = grids.clamp(0, min(Wt - 1, Ht - 1))
+    d = scene_to_npz(scene)
+    d.update({"cfg": np.array([n_views, 5, 0, 0, Sc, Sf], np.int64), "pix": _np(grids).astype(np.int32),
+              "u_c": _np(t[0])[0], "noise_c": _np(t[3]).reshape(-1), "u_f": _np(t[4])[0], "noise_f": _np(t[7]).reshape(-1),
+              "keep_c": _np(keep_c), "keep_f": _np(keep_f), "noise_std": np.float32(noise_std)})
+    for k in keys:
+        d["out." + k] = _np(out[k])
+        d["G." + k] = _np(G[k])
+    d["d_geo0"], d["d_geo1"], d["d_tex"] = _np(feat_geo[0].grad), _np(feat_geo[1].grad), _np(feat_tex.grad)
+    for k, v in net.named_parameters():
+        if k.startswith(HOT_PREFIXES) and v.grad is not None:
+            d["param_grad." + k] = _np(v.grad)
+    net.zero_grad()
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: rays={grids.shape[0]} keep_c={keep_c.tolist()} keep_f={keep_f.tolist()} alpha_fine={float(out['alpha_fine'].mean()):.3f} "
+          f"|d_tex|max={float(feat_tex.grad.abs().max()):.3g} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def run_output_case(name, seed=9):
     """Output side: the reference's own frame arrangement / quantisation / PSNR."""
     rmodel = ref_shim.load_reference()
@@ -374,6 +450,9 @@ def main():
     run_train_case(net, "case_g_v4_train", 4, (48, 80), (32, 48), "ellipsoid", 16, 8, seed=8)
     run_geo_rows_grad_case(net, "case_i_v3_geo_rows_grad", 3, (64, 64), "ellipsoid", 600, seed=12)
     run_query_grad_case(net, "case_j_v3_query_grad", 3, (64, 64), "ellipsoid", 400, seed=13)
+    # seeds chosen for informative dropout patterns: k = coarse all views / fine drops view 1; l = nothing dropped
+    run_train_grad_case(net, "case_k_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=6)
+    run_train_grad_case(net, "case_l_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=10)
 
 
 if __name__ == "__main__":
