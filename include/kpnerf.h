@@ -216,7 +216,7 @@ int kpn_profile_collect(double* geo_rows_ms_host, int64_t* launches_host, int64_
  * be the reference's own: src/model.py:1008-1017 (patch pixels), :1049-1053 (stratified jitter), :993-994 (density
  * noise, coarse and fine eval), :742-748 (per-view dropout of the coarse and of the fine query), :1129 (random
  * importance samples).  `args` as for kpn_render_rays with nx*ny = n rays (x0,y0,step unused); outputs are (C,ny,nx)
- * planar in patch order.  Backward is not implemented yet. */
+ * planar in patch order.  Backward: kpn_render_rays_train_backward. */
 typedef struct kpn_train_args {
     const int32_t* pix;          /* (R,2) target pixels (x,y) */
     const float* u_coarse;       /* (R,Sc)        th.rand_like(z) */
@@ -230,6 +230,22 @@ typedef struct kpn_train_args {
 int kpn_render_rays_train(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
                           const kpn_render_args* args, const kpn_train_args* train, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* loss.backward() through the train branch (the field part of training_step, src/model.py:128-155): given the
+ * gradients of kpn_render_rays_train's seven outputs — planar (C, ny*nx) like the outputs, NULL = zero — accumulate the
+ * gradients of every hot-path parameter (d_plain, flat layout of kpn_pack_weights' input, raw ani_al last) and of the
+ * three feature maps (channels-last, like kpn_query_backward).  Same `args` / `train` as the forward call (outputs in
+ * `args` are ignored).  Nothing is kept from the forward pass: z, rgba and the field activations are recomputed per
+ * pass; the sample positions carry no gradient (drawn under no_grad, src/model.py:1038,1118).  <= 3 source views. */
+typedef struct kpn_render_grads {
+    const float* d_tex_fg; const float* d_depth; const float* d_alpha;
+    const float* d_tex_fg_fine; const float* d_depth_fine; const float* d_alpha_fine; const float* d_sdf;
+} kpn_render_grads;
+size_t kpn_render_rays_train_backward_workspace_bytes(const kpn_scene_desc* desc, const kpn_render_args* args);
+int kpn_render_rays_train_backward(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
+                                   const kpn_render_args* args, const kpn_train_args* train, const kpn_render_grads* grads,
+                                   float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* FLOP / byte model of one field evaluation, for roofline reporting */
 double kpn_flops_per_point(int32_t n_views);

@@ -499,11 +499,15 @@ namespace {
 // from d_out (N,5) [geometry outputs only so far: the colour head's reverse is not built].
 int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts, const float* view,
                  int mode, uint32_t keep_mask, const float* noise, float noise_std, const float* d_x, const float* d_out,
-                 float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws, size_t ws_bytes, void* stream) {
+                 float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws, size_t ws_bytes, void* stream,
+                 const kpn_points* marched = nullptr) {
+    // marched: the points are ray-marched (cam_pos + dirs * z, as kpn_render_rays evaluates them) instead of explicit;
+    // one pass only (N <= kBwdChunk)
     const int V = d->n_views;
     const int full = d_x != nullptr ? 0 : (d_tex ? 2 : 1);
     const BwdLayout L = bwd_layout(N, V, full);
     if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "backward workspace too small");
+    if (marched && N > L.chunk) return fail(KPN_EINVAL, "ray-marched backward pass too large");
     kpn_scene_dev sc = scene_dev(d, scene_ws);
     sc.keep = keep_mask;
     char* base = static_cast<char*>(ws);
@@ -564,7 +568,9 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
     };
     for (int64_t c0 = 0; c0 < N; c0 += L.chunk) {
         const int64_t n = (N - c0 < L.chunk) ? (N - c0) : L.chunk;
-        kpn_points ps{pts + c0 * 3, (view ? view : pts) + c0 * 3, nullptr, nullptr, nullptr, 1, noise ? noise + c0 : nullptr, noise_std};
+        const kpn_points ps = marched ? *marched
+                                      : kpn_points{pts + c0 * 3, (view ? view : pts) + c0 * 3, nullptr, nullptr, nullptr, 1,
+                                                   noise ? noise + c0 : nullptr, noise_std};
         hipMemsetAsync(count, 0, 8 * sizeof(int), (hipStream_t)stream);
         KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
                    (uint8_t*)nullptr, list, count);
@@ -795,6 +801,116 @@ extern "C" int kpn_render_rays_train(const kpn_scene_desc* d, const void* scene_
                                      const kpn_train_args* t, void* ws, size_t ws_bytes, void* stream) {
     KPN_REQUIRE(t != nullptr, "train args null");
     return render_impl(d, scene_ws, wp, a, t, ws, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the train-branch render
+namespace {
+struct TrainBwdLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, rgba_c, rgba_f, contrib, scratch, g3, g1a, g1b, g1c, drgba_c, drgba_f,
+                        query, bwd, total; int64_t chunk; };
+TrainBwdLayout train_bwd_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
+    TrainBwdLayout L;
+    const int64_t R = (int64_t)a->nx * a->ny;
+    const int64_t Sfull = a->n_coarse + a->n_fine;
+    int64_t C = a->chunk_rays > 0 ? a->chunk_rays : kBwdChunk / Sfull;   // one backward pass per point set
+    if (C * Sfull > kBwdChunk) C = kBwdChunk / Sfull;
+    if (C > R) C = R;
+    L.chunk = C;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
+    L.cam_pos = take(64);
+    L.dirs = take((size_t)R * 3 * 4); L.nearv = take((size_t)R * 4); L.farv = take((size_t)R * 4);
+    L.zc = take((size_t)C * a->n_coarse * 4); L.zf = take((size_t)C * Sfull * 4);
+    L.rgba_c = take((size_t)C * a->n_coarse * 5 * 4); L.rgba_f = take((size_t)C * Sfull * 5 * 4);
+    L.contrib = take((size_t)C * Sfull * 4);
+    L.scratch = take((size_t)C * 8 * 4);  // colour / depth / alpha / sdf of the recomputed forward (unused results)
+    L.g3 = take((size_t)C * 3 * 4); L.g1a = take((size_t)C * 4); L.g1b = take((size_t)C * 4); L.g1c = take((size_t)C * 4);
+    L.drgba_c = take((size_t)C * a->n_coarse * 5 * 4); L.drgba_f = take((size_t)C * Sfull * 5 * 4);
+    L.query = take(query_layout(C * Sfull, d->n_views).total);
+    L.bwd = take(bwd_layout(C * Sfull, d->n_views, 2).total);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+// gather of a chunk's upstream gradients from the planar (C, R) layout the outputs use; src == nullptr -> zeros
+__global__ void k_load_planar(int64_t r0, int64_t n, int64_t R, int C, const float* __restrict__ src, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i - r * C);
+    dst[i] = src ? src[(int64_t)c * R + r0 + r] : 0.0f;
+}
+
+extern "C" size_t kpn_render_rays_train_backward_workspace_bytes(const kpn_scene_desc* d, const kpn_render_args* a) {
+    if (check_desc(d) != KPN_OK || check_render(a) != KPN_OK || !a->fine) return 0;
+    return train_bwd_layout(d, a).total;
+}
+
+extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
+                                              const kpn_render_args* a, const kpn_train_args* t, const kpn_render_grads* g,
+                                              float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (int e = check_render(a)) return e;
+    KPN_REQUIRE(t && g, "train args / gradients null");
+    KPN_REQUIRE(a->fine, "the train branch renders coarse + fine (dr_kwargs.fine)");
+    KPN_REQUIRE(d->n_views <= 3, "the colour-head reverse is built for <= 3 source views");
+    KPN_REQUIRE(scene_ws && wp && ws && d_plain && d_geo0 && d_geo1 && d_tex, "null pointer");
+    KPN_REQUIRE(t->pix && t->u_coarse && t->u_fine, "train args: pix, u_coarse, u_fine are required");
+    KPN_REQUIRE(t->rand_noise_std == 0.0f || (t->noise_coarse && t->noise_fine), "train args: noise tensors missing");
+    KPN_REQUIRE((t->keep_coarse & ((1u << d->n_views) - 1u)) && (t->keep_fine & ((1u << d->n_views) - 1u)),
+                "train args: view dropout must keep at least one view (reference src/model.py:744)");
+    const TrainBwdLayout L = train_bwd_layout(d, a);
+    if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "train backward workspace too small");
+    char* base = static_cast<char*>(ws);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    kpn_scene_dev sc = scene_dev(d, scene_ws);
+    const int64_t R = (int64_t)a->nx * a->ny;
+    const int Sc = a->n_coarse, Sf = a->n_fine, Sfull = Sc + Sf;
+    const int V = d->n_views;
+    KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
+               (int)a->step, (int)a->nx, (int)a->ny, (const int*)t->pix, F(L.dirs), F(L.cam_pos), F(L.nearv), F(L.farv));
+    const float std_ = t->rand_noise_std;
+    for (int64_t r0 = 0; r0 < R; r0 += L.chunk) {
+        const int64_t n = (R - r0) < L.chunk ? (R - r0) : L.chunk;
+        const float* dirs = F(L.dirs) + r0 * 3;
+        float* sc4 = F(L.scratch);
+        // ---- forward again (nothing is kept from kpn_render_rays_train): z, rgba of both passes ----
+        KPN_LAUNCH(k_coarse_z, grid1d(n * Sc, 256), dim3(256), stream, n, Sc, (const float*)(F(L.nearv) + r0),
+                   (const float*)(F(L.farv) + r0), t->u_coarse + r0 * Sc, F(L.zc));
+        kpn_points pc{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc, std_ != 0.0f ? t->noise_coarse + r0 * Sc : nullptr, std_};
+        sc.keep = t->keep_coarse;
+        if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream)) return e;
+        if (int e = kpn_rgba2out(F(L.rgba_c), F(L.zc), n, Sc, sc4, sc4 + 3 * n, sc4 + 4 * n, F(L.contrib), sc4 + 5 * n, stream)) return e;
+        if (Sc <= 64 && Sf <= 64)
+            KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib),
+                       t->u_fine + r0 * Sf, F(L.zf));
+        else
+            KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc),
+                       (const float*)F(L.contrib), t->u_fine + r0 * Sf, F(L.zf));
+        kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
+        sc.keep = t->keep_fine;
+        if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream)) return e;
+        // ---- compositor reverse: d rgba of both passes (sample positions carry no gradient, model.py:1038,1118) ----
+        KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg, F(L.g3));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth, F(L.g1a));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha, F(L.g1b));
+        if (int e = kpn_rgba2out_backward(F(L.rgba_c), F(L.zc), n, Sc, F(L.g3), F(L.g1a), F(L.g1b), nullptr, F(L.drgba_c), stream)) return e;
+        KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg_fine, F(L.g3));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth_fine, F(L.g1a));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha_fine, F(L.g1b));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_sdf, F(L.g1c));
+        if (int e = kpn_rgba2out_backward(F(L.rgba_f), F(L.zf), n, Sfull, F(L.g3), F(L.g1a), F(L.g1b), F(L.g1c), F(L.drgba_f), stream)) return e;
+        // ---- field reverse of both point sets ----
+        const size_t bwd_bytes = L.total - L.bwd;
+        if (int e = run_backward(d, scene_ws, wp, n * Sc, nullptr, nullptr, 1, t->keep_coarse, nullptr, 0.0f, nullptr, F(L.drgba_c),
+                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pc)) return e;
+        if (int e = run_backward(d, scene_ws, wp, n * Sfull, nullptr, nullptr, 1, t->keep_fine, nullptr, 0.0f, nullptr, F(L.drgba_f),
+                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pf)) return e;
+    }
+    (void)V;
+    return check_launch("kpn_render_rays_train_backward");
 }
 
 extern "C" int kpn_frame_to_rgb8(const float* chw, int32_t H, int32_t W, int32_t bgr, uint8_t* hwc_out, void* stream) {

@@ -47,6 +47,11 @@ class TrainArgs(ctypes.Structure):
                [("keep_coarse", ctypes.c_uint32), ("keep_fine", ctypes.c_uint32), ("rand_noise_std", c_f)]
 
 
+class RenderGrads(ctypes.Structure):
+    """struct kpn_render_grads"""
+    _fields_ = [(n, c_p) for n in ("d_tex_fg", "d_depth", "d_alpha", "d_tex_fg_fine", "d_depth_fine", "d_alpha_fine", "d_sdf")]
+
+
 # name -> (restype, argtypes); mirrors include/kpnerf.h one to one
 _SIGNATURES = {
     "kpn_abi_version": (ctypes.c_int, []),
@@ -71,6 +76,10 @@ _SIGNATURES = {
     "kpn_query_backward_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "kpn_query_backward": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, ctypes.c_uint32, c_p,
                                           ctypes.c_float, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "kpn_render_rays_train_backward_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),
+    "kpn_render_rays_train_backward": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs),
+                                                      ctypes.POINTER(TrainArgs), ctypes.POINTER(RenderGrads), c_p, c_p, c_p, c_p,
+                                                      c_p, c_sz, c_p]),
     "kpn_query_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "kpn_query": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_sz, c_p]),
     "kpn_render_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),

@@ -372,6 +372,56 @@ def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, ke
     return {k: v.reshape(1, *v.shape[1:-2], R) if v.dim() == 4 else v.reshape(1, R) for k, v in plan.out.items()}
 
 
+def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, keep_coarse, keep_fine, grads,
+                               noise_coarse=None, noise_fine=None, rand_noise_std=0.0, n_coarse=64, n_fine=64, chunk_rays=0):
+    """loss.backward() through render_rays_train (kpn_render_rays_train_backward): `grads` maps output names
+    ('tex_fg', 'depth', 'alpha', 'tex_fg_fine', 'depth_fine', 'alpha_fine', 'sdf') to the gradients of those outputs,
+    shaped like them ((1,3,R) / (1,R)); missing keys are zero.  Same other arguments as the forward call.
+    Returns (d_plain, d_geo0, d_geo1, d_tex) as ops.query_backward."""
+    L = kl.get_library()
+    px = pix.to(torch.int32).contiguous()
+    if not px.is_cuda:
+        raise RuntimeError("pix must live on the GPU")
+    R, V = px.shape[0], scene.n_views
+    K, RT, b = _dev(cam_tar["K"], "cam_tar['K']").reshape(4, 4), _dev(cam_tar["RT"], "cam_tar['RT']").reshape(4, 4), _dev(bounds, "bounds").reshape(2, 3)
+    a = kl.RenderArgs()
+    a.K, a.RT, a.bounds = K.data_ptr(), RT.data_ptr(), b.data_ptr()
+    a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    a.x0, a.y0, a.step, a.nx, a.ny = 0, 0, 1, R, 1
+    a.n_coarse, a.n_fine, a.fine, a.chunk_rays = int(n_coarse), int(n_fine), 1, int(chunk_rays)
+    bits = lambda k: int(k) if isinstance(k, int) else int(sum(1 << i for i, x in enumerate(k.reshape(-1).tolist()) if x > 0.5))
+    uc, uf = _dev(u_coarse, "u_coarse").reshape(R, n_coarse), _dev(u_fine, "u_fine").reshape(R, n_fine)
+    nc = _dev(noise_coarse, "noise_coarse").reshape(-1) if noise_coarse is not None else None
+    nf = _dev(noise_fine, "noise_fine").reshape(-1) if noise_fine is not None else None
+    t = kl.TrainArgs()
+    t.pix, t.u_coarse, t.u_fine = px.data_ptr(), uc.data_ptr(), uf.data_ptr()
+    t.noise_coarse = nc.data_ptr() if nc is not None else None
+    t.noise_fine = nf.data_ptr() if nf is not None else None
+    t.keep_coarse, t.keep_fine, t.rand_noise_std = bits(keep_coarse), bits(keep_fine), float(rand_noise_std)
+    g, keep_alive = kl.RenderGrads(), []
+    for name in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf"):
+        if grads.get(name) is not None:
+            gt = _dev(grads[name], "grads['%s']" % name).reshape(-1)
+            if gt.numel() != (3 * R if name.startswith("tex") else R):
+                raise ValueError(f"grads['{name}'] has the wrong size")
+            keep_alive.append(gt)
+            setattr(g, "d_" + name, gt.data_ptr())
+    d = scene.desc
+    dv = px.device
+    d_plain = torch.zeros(L.kpn_plain_weight_floats(), dtype=_f32, device=dv)
+    d_g0 = torch.zeros(V, d.geo0_h, d.geo0_w, 64, dtype=_f32, device=dv)
+    d_g1 = torch.zeros(V, d.geo1_h, d.geo1_w, 8, dtype=_f32, device=dv)
+    d_tx = torch.zeros(V, d.tex_h, d.tex_w, 8, dtype=_f32, device=dv)
+    nb = L.kpn_render_rays_train_backward_workspace_bytes(ctypes.byref(d), ctypes.byref(a))
+    if nb == 0:
+        raise kl.KpnError("bad render arguments: " + L.kpn_last_error().decode())
+    ws = torch.empty(nb, dtype=torch.uint8, device=dv)
+    L.check(L.kpn_render_rays_train_backward(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
+                                             ctypes.byref(g), _p(d_plain), _p(d_g0), _p(d_g1), _p(d_tx), _p(ws), nb, _stream()))
+    torch.cuda.current_stream().synchronize()  # the argument tensors above must outlive the launches
+    return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2), d_tx.permute(0, 3, 1, 2)
+
+
 def frame_to_rgb8(img, bgr=False):
     """(3,H,W) or (1,3,H,W) fp32 -> (H,W,3) uint8 on the device: clamp to [0,1] (_arrange_nerf_images, reference
     src/model.py:427-430), x255 and truncate (`.astype(np.uint8)`, :496), optional B,G,R order for cv2.imwrite (:222)."""

@@ -202,3 +202,37 @@ def query_backward(lib, hs, packed, pts, view, d_out, mode=0, keep=0xFFFFFFFF, n
     lib.check(lib.kpn_query_backward(ctypes.byref(d), ptr(hs.ws), ptr(packed), N, ptr(pts), ptr(view), mode, keep, ptr(nz), noise_std,
                                      ptr(d_out), ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(d_tx), ptr(ws), nb, None))
     return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2), d_tx.transpose(0, 3, 1, 2)
+
+
+def render_train_backward(lib, hs, packed, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std, grads):
+    """kpn_render_rays_train_backward on host buffers; grads: name -> array shaped like the output (any layout with
+    the planar (C,R) order when flattened).  Returns (d_plain, d_geo0, d_geo1, d_tex) (maps as NCHW views)."""
+    K, RT, b = f32(cam_tar["K"]).reshape(4, 4), f32(cam_tar["RT"]).reshape(4, 4), f32(bounds).reshape(2, 3)
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    a = kl.RenderArgs()
+    a.K, a.RT, a.bounds = K.ctypes.data, RT.ctypes.data, b.ctypes.data
+    a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    a.x0, a.y0, a.step, a.nx, a.ny = 0, 0, 1, R, 1
+    a.n_coarse, a.n_fine, a.fine, a.chunk_rays = Sc, Sf, 1, 0
+    bufs = dict(u_c=f32(u_c).reshape(R, Sc), noise_c=f32(noise_c).reshape(-1), noise_f=f32(noise_f).reshape(-1), u_f=f32(u_f).reshape(R, Sf))
+    t = kl.TrainArgs()
+    t.pix, t.u_coarse, t.noise_coarse, t.noise_fine, t.u_fine = (pix.ctypes.data, bufs["u_c"].ctypes.data, bufs["noise_c"].ctypes.data,
+                                                                 bufs["noise_f"].ctypes.data, bufs["u_f"].ctypes.data)
+    t.keep_coarse, t.keep_fine, t.rand_noise_std = keep_c, keep_f, float(noise_std)
+    g, keep_alive = kl.RenderGrads(), []
+    for name, arr in grads.items():
+        arr = f32(arr).reshape(-1)
+        keep_alive.append(arr)
+        setattr(g, "d_" + name, arr.ctypes.data)
+    d = hs.desc
+    d_plain = np.zeros(lib.kpn_plain_weight_floats(), np.float32)
+    d_g0 = np.zeros((hs.V, d.geo0_h, d.geo0_w, 64), np.float32)
+    d_g1 = np.zeros((hs.V, d.geo1_h, d.geo1_w, 8), np.float32)
+    d_tx = np.zeros((hs.V, d.tex_h, d.tex_w, 8), np.float32)
+    nb = lib.kpn_render_rays_train_backward_workspace_bytes(ctypes.byref(d), ctypes.byref(a))
+    assert nb > 0, lib.kpn_last_error()
+    ws = np.zeros(nb, np.uint8)
+    lib.check(lib.kpn_render_rays_train_backward(ctypes.byref(d), ptr(hs.ws), ptr(packed), ctypes.byref(a), ctypes.byref(t), ctypes.byref(g),
+                                                 ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(d_tx), ptr(ws), nb, None))
+    return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2), d_tx.transpose(0, 3, 1, 2)

@@ -377,3 +377,26 @@ def test_query_backward(ops, golden_weights, keep):
                 assert np.abs(pg[name].numpy().reshape(refp.shape) - refp).max() <= tol * np.abs(refp).max() + 2e-6, name
                 checked += 1
         assert checked >= 40
+
+
+@pytest.mark.parametrize("case", ["case_k_v3_train_grad", "case_l_v3_train_grad"])
+def test_train_render_backward(ops, golden_weights, case):
+    """kpn_render_rays_train_backward on the MI355X against the reference's loss.backward() through the train branch of
+    batch_render_pifu_nerf (recorded random draws; coarse / fine dropout masks; density noise): every hot-path parameter
+    gradient as the optimizer sees it, and the three feature-map gradients."""
+    from tests.golden_io import keep_bits
+    from tests.test_kernels_simt import assert_train_grads_vs_golden, train_grad_inputs
+    sd, w = golden_weights
+    scene, cfg, g = load_case(case)
+    s, ps = _prep(ops, scene)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    grads = {k: cu(v) for k, v in train_grad_inputs(g).items()}
+    args = dict(n_coarse=cfg["Sc"], n_fine=cfg["Sf"], noise_coarse=cu(g["noise_c"]), noise_fine=cu(g["noise_f"]),
+                rand_noise_std=float(g["noise_std"]))
+    # forward of the same call first: the outputs the gradients belong to
+    out = ops.render_rays_train(ps, w, s["cam_tar"], s["bounds"], cu(g["pix"]), cu(g["u_c"]), cu(g["u_f"]), keep_bits(g["keep_c"]),
+                                keep_bits(g["keep_f"]), **args)
+    assert np.abs(out["tex_fg_fine"].cpu().numpy().reshape(3, -1) - g["out.tex_fg_fine"][0].reshape(3, -1)).max() < RGBA_TOL
+    got = ops.render_rays_train_backward(ps, w, s["cam_tar"], s["bounds"], cu(g["pix"]), cu(g["u_c"]), cu(g["u_f"]),
+                                         keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), grads, **args)
+    assert_train_grads_vs_golden([x.cpu().numpy() for x in got], g, sd, 1e-4)

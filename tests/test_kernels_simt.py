@@ -258,3 +258,52 @@ def test_query_backward_kernels(env, mode, keep):
         for k, key in ((1, "d_geo0"), (2, "d_geo1"), (3, "d_tex")):
             refk = g[f"{variant}.{key}"]
             assert np.abs(got[k] - refk).max() <= 6e-5 * np.abs(refk).max(), key
+
+
+TRAIN_GRAD_CASES = ["case_k_v3_train_grad", "case_l_v3_train_grad"]
+
+
+def assert_train_grads_vs_golden(got, g, sd, rtol, ani_rtol=2e-3):
+    """got = (d_plain, d_geo0, d_geo1, d_tex) of kpn_render_rays_train_backward; g = golden k/l (reference
+    loss.backward()): parameter gradients are compared as the optimizer sees them (weight_g / weight_v / weight / bias /
+    ani_al, through the weight-norm fold), one max-norm scale per layer."""
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    from keypointnerf_amd.weights import plain_grads_to_state_dict
+    pg = plain_grads_to_state_dict(sd, got[0])
+    checked = 0
+    for lname, prefix, shape, wn in HOTPATH_LAYERS:
+        keys = [k for k in g if k.startswith("param_grad." + prefix + ".")]
+        assert keys, prefix
+        scale = max(np.abs(g[k]).max() for k in keys)
+        for k in keys:
+            name = k[len("param_grad."):]
+            ref = g[k]
+            err = np.abs(pg[name].numpy().reshape(ref.shape) - ref).max()
+            assert err <= rtol * scale + 1e-7, (name, float(err), float(scale))
+            checked += 1
+    ref = float(g["param_grad.mlp_tex.ani_al"])
+    assert abs(float(pg["mlp_tex.ani_al"]) - ref) <= ani_rtol * abs(ref) + 1e-6, ("ani_al", float(pg["mlp_tex.ani_al"]), ref)
+    assert checked >= 40
+    for k, key in ((1, "d_geo0"), (2, "d_geo1"), (3, "d_tex")):
+        assert np.abs(got[k] - g[key]).max() <= rtol * np.abs(g[key]).max(), (key, float(np.abs(got[k] - g[key]).max()))
+
+
+def train_grad_inputs(g):
+    """upstream gradients of golden k/l in the planar (C, R) order of the outputs"""
+    return {k: (g["G." + k][0].reshape(3, -1) if k.startswith("tex") else g["G." + k].reshape(-1))
+            for k in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")}
+
+
+@pytest.mark.parametrize("case", TRAIN_GRAD_CASES)
+def test_train_render_backward_kernels(env, case):
+    """kpn_render_rays_train_backward (emulated): forward recompute, compositor reverse, field reverse of the coarse and
+    the fine point sets with their own dropout masks / density noise — against the reference's loss.backward() through
+    the train branch of batch_render_pifu_nerf (goldens k, l)."""
+    from tests.golden_io import keep_bits
+    lib, packed, wflat = env
+    scene, cfg, g = load_case(case)
+    hs = sh.HostScene(lib, scene)
+    got = sh.render_train_backward(lib, hs, packed, scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"], g["u_c"],
+                                   g["noise_c"], g["noise_f"], g["u_f"], keep_bits(g["keep_c"]), keep_bits(g["keep_f"]),
+                                   float(g["noise_std"]), train_grad_inputs(g))
+    assert_train_grads_vs_golden(got, g, load_weights(), 1e-4)
