@@ -55,6 +55,19 @@ class PackedWeights:
         L.check(L.kpn_pack_weights(plain.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p)))
         self.tensor = torch.from_numpy(packed).to(device)
 
+    @classmethod
+    def from_plain(cls, plain, device="cuda"):
+        """From the flat effective-parameter vector (weights.flatten_plain / plain_tensor_from_module layout)."""
+        L = kl.get_library()
+        flat = np.ascontiguousarray(plain.detach().float().cpu().numpy() if isinstance(plain, torch.Tensor) else plain, dtype=np.float32)
+        if flat.size != L.kpn_plain_weight_floats():
+            raise ValueError("unexpected hot-path parameter count")
+        packed = np.zeros(L.kpn_packed_weight_floats(), np.float32)
+        L.check(L.kpn_pack_weights(flat.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p)))
+        self = cls.__new__(cls)
+        self.tensor = torch.from_numpy(packed).to(device)
+        return self
+
 
 class PreparedScene:
     """kpn_scene_desc + the prepared (channels-last) device workspace for one set of source views.

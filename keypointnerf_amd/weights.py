@@ -88,3 +88,27 @@ def plain_grads_to_state_dict(state_dict, d_plain):
             grads[prefix + ".weight"] = dW.clone()
     grads["mlp_tex.ani_al"] = d_plain[off:off + 1].clone()
     return grads
+
+
+def plain_tensor_from_module(net):
+    """The flat effective-parameter vector (``flatten_plain`` layout) as a DIFFERENTIABLE torch tensor built from a
+    live module's parameters: weight-norm folded with ``torch._weight_norm`` (reference src/utils.py:542-543), raw
+    ``ani_al`` last.  Gradients of a loss w.r.t. this tensor reach ``weight_g`` / ``weight_v`` / ``weight`` / ``bias``
+    through autograd — this is how the training drop-in hands the library's ``d_plain`` to the optimizer."""
+    params = dict(net.named_parameters())
+    if any(k.startswith("model.") for k in params):
+        params = {k[len("model."):]: v for k, v in params.items() if k.startswith("model.")}
+    parts = []
+    for name, prefix, shape, wn in HOTPATH_LAYERS:
+        if (prefix + ".weight_g") in params:
+            w = torch._weight_norm(params[prefix + ".weight_v"], params[prefix + ".weight_g"], 0)
+        elif (prefix + ".parametrizations.weight.original0") in params:
+            w = torch._weight_norm(params[prefix + ".parametrizations.weight.original1"],
+                                   params[prefix + ".parametrizations.weight.original0"], 0)
+        else:
+            w = params[prefix + ".weight"]
+        if tuple(w.shape) != tuple(shape):
+            raise ValueError(f"unsupported architecture: {prefix} has shape {tuple(w.shape)}, expected {shape}")
+        parts += [w.reshape(-1).float(), params[prefix + ".bias"].reshape(-1).float()]
+    parts.append(params["mlp_tex.ani_al"].reshape(1).float())
+    return torch.cat(parts)

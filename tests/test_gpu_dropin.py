@@ -97,3 +97,74 @@ def test_render_pifu_nerf_full_frame_and_weight_refresh():
                                 uniform=True, sample_per_ray_c=cfg["Sc"], sample_per_ray_f=cfg["Sf"],
                                 src_foreground_mask=s["src_foreground_mask"], bounds=s["bounds"])
     assert float(out2["alpha_fine"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case,seed", [("case_k_v3_train_grad", 6), ("case_l_v3_train_grad", 10)])
+def test_training_step_through_the_dropin(monkeypatch, case, seed):
+    """The reference's train-mode call `net.batch_render_pifu_nerf(net, ...)` served by the drop-in, then
+    `loss.backward()`: parameter gradients (weight_g / weight_v / weight / bias / ani_al, as the optimizer reads them from
+    `p.grad`) and the feature-map gradients equal the unmodified reference's (goldens k, l).  The reference's random
+    draws are replayed: numpy seeded as the generator did; torch.rand / rand_like / randn answered from the record."""
+    scene, cfg, g = load_case(case)
+    net, s = _net(scene)
+    V, Sc, Sf = cfg["n_views"], cfg["Sc"], cfg["Sf"]
+    patch = int(round(g["pix"].shape[0] ** 0.5))
+    Ht, Wt = s["cam_tar"]["height"], s["cam_tar"]["width"]
+    yy, xx = torch.meshgrid(torch.arange(Ht), torch.arange(Wt), indexing="ij")
+    msk = (((yy - Ht / 2) ** 2 + (xx - Wt / 2) ** 2) < (0.3 * min(Ht, Wt)) ** 2)[None, None].cuda()   # as oracle/make_golden.py
+
+    def dropout_draws(keep):
+        """two uniform tensors that make src/model.py:743-747 produce the recorded keep vector"""
+        k = [int(x > 0.5) for x in keep]
+        n1 = sum(k)
+        d = [1] + [1] * (n1 - 1) + [0] * (V - n1)                     # dropout before the permutation
+        ones, zeros = [i for i in range(V) if d[i]], [i for i in range(V) if not d[i]]
+        perm = [ones.pop(0) if k[i] else zeros.pop(0) for i in range(V)]
+        r1 = torch.tensor([0.9 if x else 0.1 for x in d[1:]]).view(1, V - 1, 1, 1)
+        r2 = torch.empty(V)
+        for i, src in enumerate(perm):
+            r2[src] = (i + 1) / (V + 1)                              # argsort(r2) == perm
+        return [r1.cuda(), r2.view(1, V, 1, 1).cuda()]
+
+    R = g["pix"].shape[0]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    queue = [cu(g["u_c"]).view(1, R, Sc).cuda()] + dropout_draws(g["keep_c"]) + [cu(g["noise_c"]).view(1, R * Sc, 1).cuda(),
+             cu(g["u_f"]).view(1, R, Sf)] + dropout_draws(g["keep_f"]) + [cu(g["noise_f"]).view(1, R * (Sc + Sf), 1).cuda()]
+    replay = lambda *a, **k: queue.pop(0)
+    for fn in ("rand", "rand_like", "randn", "randn_like"):
+        monkeypatch.setattr(torch, fn, replay)
+    net.train()
+    net.train_out_h = net.train_out_w = patch
+    feat_geo = [f.clone().requires_grad_(True) for f in s["feat_geo"]]
+    feat_tex = s["feat_tex"].clone().requires_grad_(True)
+    np.random.seed(seed)
+    out = net.batch_render_pifu_nerf(net, s["img"], s["cam"], V, s["cam_tar"], 5, 0, None, feat_geo, feat_tex, dict(s["sp_data"]), None,
+                                     fine=True, uniform=False, sample_per_ray_c=Sc, sample_per_ray_f=Sf,
+                                     rand_noise_std=float(g["noise_std"]), src_foreground_mask=s["src_foreground_mask"],
+                                     bounds=s["bounds"], msk=msk)
+    monkeypatch.undo()
+    assert not queue
+    keys = ["tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf"]
+    for k in keys:
+        assert out[k].shape == g["out." + k].shape, k
+        assert np.abs(out[k].detach().cpu().numpy() - g["out." + k]).max() <= 1e-4, k
+    sum((out[k] * torch.from_numpy(g["G." + k]).cuda()).sum() for k in keys).backward()
+    # p.grad of the module's own parameters -> the flat layout the shared checker reads
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    params = dict(net.named_parameters())
+    got_params = {n: p.grad.detach().cpu() for n, p in params.items() if p.grad is not None}
+    checked = 0
+    for lname, prefix, shape, wn in HOTPATH_LAYERS:
+        keys_l = [k for k in g if k.startswith("param_grad." + prefix + ".")]
+        scale = max(np.abs(g[k]).max() for k in keys_l)
+        for k in keys_l:
+            name = k[len("param_grad."):]
+            ref = g[k]
+            err = np.abs(got_params[name].numpy().reshape(ref.shape) - ref).max()
+            assert err <= 1e-4 * scale + 1e-7, (name, float(err), float(scale))
+            checked += 1
+    assert checked >= 40
+    ref = float(g["param_grad.mlp_tex.ani_al"])
+    assert abs(float(got_params["mlp_tex.ani_al"]) - ref) <= 2e-3 * abs(ref) + 1e-6
+    for t, key in ((feat_geo[0], "d_geo0"), (feat_geo[1], "d_geo1"), (feat_tex, "d_tex")):
+        assert np.abs(t.grad.cpu().numpy() - g[key]).max() <= 1e-4 * np.abs(g[key]).max(), key
