@@ -291,18 +291,32 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_p
 // loads MV consecutive features of dY (16 B for MV = 4) and 2 consecutive columns of X per K-step and feeds
 // MV x 2 tiles: tile (a, b) holds output feature MV*i + a (A lane i) x column c0 + 2*j + b (B lane j) — the
 // strided labelling makes the vector loads the operands of several MFMAs at once (8 MFMAs per 24 bytes).
-// grid (row workers / 4, 1, ceil(Kc/64)); every wave writes its partial tile block to `partial` in raw
+// One launch serves several layers ("jobs", blockIdx.y): the small layers of the colour head would each fill a
+// fraction of the chip on their own.  grid (row workers, jobs); a workgroup = one row slice of one job, its waves =
+// the job's 64-column groups (dY is fetched from HBM once).  Every wave writes its partial tile block in raw
 // register order; k_weight_grad_reduce sums the workers in a fixed order (deterministic, no atomics).
-//   partial: [gridDim.z][workers][MV*2*16][64 lanes];  dbp: [workers][MV][64 lanes]
+//   partial: [column groups][workers][MV*2*16][64 lanes];  dbp: [workers][MV][64 lanes]
+#define KPN_WGRAD_MAX_JOBS 20
+struct kpn_wgrad_job {
+    const float* dY; const float* X;   // row-major dumps
+    float* partial; float* dbp;
+    float* dW; float* dB;              // plain (out, in) layout + bias, accumulated by the reduce
+    int ldy, M, ldx, Kc;               // Kc: columns of X read (even)
+    int Kt, in_dim, cmap, omap;        // reduce: real columns, row stride of dW, column / row maps
+    int mv, which;                     // MV of the job (reduce), rows[which] = row count
+};
+struct kpn_wgrad_jobs { kpn_wgrad_job j[KPN_WGRAD_MAX_JOBS]; int n; };
+
 template <int MV>
-__global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ dY, int ldy, int M, const float* __restrict__ X,
-                                                     int ldx, int Kc, const int64_t* __restrict__ rows_ptr,
-                                                     float* __restrict__ partial, float* __restrict__ dbp) {
-    // block = one row worker; its waves are the column groups (wave z -> columns 64z..64z+63), so the dY rows
-    // of the slice are fetched from HBM once and hit in cache for the sibling waves
-    const int64_t rows = *rows_ptr;
-    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+__global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const int64_t* __restrict__ rows_ptr) {
+    const kpn_wgrad_job& J = jobs.j[blockIdx.y];
     const int z = threadIdx.x >> 6;
+    if (64 * z >= J.Kc) return;  // this job has fewer column groups than the launch's widest
+    const float* __restrict__ dY = J.dY;
+    const float* __restrict__ X = J.X;
+    const int ldy = J.ldy, M = J.M, ldx = J.ldx, Kc = J.Kc;
+    const int64_t rows = rows_ptr[J.which];
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
     const int worker = blockIdx.x, nworkers = gridDim.x;
     const int c0 = z * 64;
     const int64_t npairs = rows / 2;
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ d
             consume(ya[1], xb[1]);
         }
     }
-    float* dst = partial + ((size_t)z * nworkers + worker) * (MV * 2 * 16 * 64) + lane;
+    float* dst = J.partial + ((size_t)z * nworkers + worker) * (MV * 2 * 16 * 64) + lane;
 #pragma unroll
     for (int a = 0; a < MV; ++a)
 #pragma unroll
@@ -373,36 +387,36 @@ __global__ __launch_bounds__(256) void k_weight_grad(const float* __restrict__ d
             for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
     if (z == 0) {
 #pragma unroll
-        for (int a = 0; a < MV; ++a) dbp[((size_t)worker * MV + a) * 64 + lane] = bs[a];
+        for (int a = 0; a < MV; ++a) J.dbp[((size_t)worker * MV + a) * 64 + lane] = bs[a];
     }
 }
 
-// Fixed-order sum of the workers' partial blocks, added to the plain-layout gradient (no atomics: the weight
-// gradient is deterministic).  A workgroup owns 32 consecutive elements; its 8 waves-quarters stride over the
-// workers and combine through LDS.  ENC: the first 168 columns of X0 are in (keypoint, PE block) order.
-// CMAP: 0 = X columns are plain input features; 1 = X0 dump (first 168 columns in (keypoint, PE block) order);
-//       2 = base_layer.0's [mean' | var' | x'] dump (3 x 36 columns, x' order).  OMAP: 1 = dY rows are in x' order.
+// cmap: 0 = X columns are plain input features; 1 = X0 dump (first 168 columns in (keypoint, PE block) order);
+//       2 = base_layer.0's [mean' | var' | x'] dump (3 x 36 columns, x' order).  omap: 1 = dY rows are in x' order.
 __device__ __forceinline__ int kpn_grad_col(int cmap, int c) {
     if (cmap == 1) return c < 168 ? (c % 7) * 24 + c / 7 : c;
     if (cmap == 2) { const int q = c % 36; return q < 35 ? (c / 36) * 35 + kpn_xprime_to_orig(q) : -1; }
     return c;
 }
-template <int MV, int ENC, int OMAP = 0>
-__global__ __launch_bounds__(256) void k_weight_grad_reduce(const float* __restrict__ partial, const float* __restrict__ dbp,
-                                                            int nworkers, int M, int Kc, float* __restrict__ dW, int in_dim,
-                                                            float* __restrict__ db) {
-    constexpr int TILE_E = MV * 2 * 16 * 64;
+// Fixed-order sum of the workers' partial blocks, added to the plain-layout gradient (no atomics: the weight
+// gradient is deterministic).  grid (element groups of 32, column groups, jobs); a workgroup owns 32 consecutive
+// elements; its 8 thread-octets stride over the workers and combine through LDS.
+__global__ __launch_bounds__(256) void k_weight_grad_reduce(kpn_wgrad_jobs jobs, int nworkers) {
+    const kpn_wgrad_job& J = jobs.j[blockIdx.z];
+    const int MV = J.mv, M = J.M, Kc = J.Kt;
+    const int TILE_E = MV * 2 * 16 * 64;
     __shared__ float red[8][32];
     const int el = threadIdx.x & 31, wl = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
     const int z = blockIdx.y;
+    if (64 * z >= J.Kc || blockIdx.x * 32 >= TILE_E + MV * 32) return;  // uniform per workgroup
     float s = 0.0f;
     if (e < TILE_E) {
-        const float* src = partial + (size_t)z * nworkers * TILE_E + e;
+        const float* src = J.partial + (size_t)z * nworkers * TILE_E + e;
         for (int w = wl; w < nworkers; w += 8) s += src[(size_t)w * TILE_E];
     } else if (z == 0 && e < TILE_E + MV * 32) {
         const int q = e - TILE_E, a = q / 32, i = q % 32;
-        for (int w = wl; w < nworkers; w += 8) s += dbp[((size_t)w * MV + a) * 64 + i] + dbp[((size_t)w * MV + a) * 64 + 32 + i];
+        for (int w = wl; w < nworkers; w += 8) s += J.dbp[((size_t)w * MV + a) * 64 + i] + J.dbp[((size_t)w * MV + a) * 64 + 32 + i];
     }
     red[wl][el] = s;
     __syncthreads();
@@ -414,13 +428,13 @@ __global__ __launch_bounds__(256) void k_weight_grad_reduce(const float* __restr
         int o = MV * KPN_ROWMAP(r, lane >> 5) + a;
         const int c = z * 64 + 2 * (lane & 31) + b;
         if (o < M && c < Kc) {
-            const int f = kpn_grad_col(ENC, c);
-            if (OMAP) o = kpn_xprime_to_orig(o);
-            if (f >= 0) dW[(size_t)o * in_dim + f] += s;
+            const int f = kpn_grad_col(J.cmap, c);
+            if (J.omap) o = kpn_xprime_to_orig(o);
+            if (f >= 0) J.dW[(size_t)o * J.in_dim + f] += s;
         }
     } else if (z == 0 && e < TILE_E + MV * 32) {
         const int q = e - TILE_E, a = q / 32, i = q % 32;
         const int o = MV * i + a;
-        if (o < M) db[OMAP ? kpn_xprime_to_orig(o) : o] += s;
+        if (o < M) J.dB[J.omap ? kpn_xprime_to_orig(o) : o] += s;
     }
 }

@@ -444,6 +444,7 @@ const int kGradWorkers = 3;     // row workers (one workgroup each; its waves ar
 #else
 const int kGradWorkers = 512;   // 2 workgroups per CU
 #endif
+const int kPartialUnits = 72;   // capacity of the partial-tile scratch in units of (workers x 2048 floats)
 // full = 1: the whole-query reverse (adds the forward row scratch, the per-point dumps and the d x_view rows)
 // colour-head dumps, floats per (point, view) row, in kpn_color_bufs order (X buffers then dA buffers)
 const int kColorLd[25] = {4, 16, KPN_LD_XDIR, KPN_LD_XBL, 64, 32, 32, 32, 2, 32, 32, KPN_LD_XO0, 16, 8,
@@ -462,8 +463,10 @@ BwdLayout bwd_layout(int64_t N, int V, int full) {
     L.list = take((size_t)L.chunk * sizeof(int));
     L.X0 = take(rows * KPN_LDX0 * 4); L.X1 = take(rows * 128 * 4); L.X2 = take(rows * KPN_LDX2 * 4); L.X3 = take(rows * 128 * 4);
     L.D0 = take(rows * 128 * 4); L.D1 = take(rows * 128 * 4); L.D2 = take(rows * 128 * 4); L.D3 = take(rows * 64 * 4);
-    L.partial = take((size_t)4 * kGradWorkers * (4 * 2 * 16 * 64) * 4);  // [column groups <= 4][workers][128 x 64 tile block]
-    L.dbp = take((size_t)kGradWorkers * 4 * 64 * 4);
+    // partial tile blocks of all weight-gradient jobs of a pass (they run in shared launches): sum over the 19 layers of
+    // column groups x MV = 65 -> 72 x workers x 8 KB (checked when the jobs are queued); bias partials per job
+    L.partial = take((size_t)kPartialUnits * kGradWorkers * (2 * 16 * 64) * 4);
+    L.dbp = take((size_t)KPN_WGRAD_MAX_JOBS * kGradWorkers * 4 * 64 * 4);
     if (full) {
         L.xscr = take(ntiles * (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4));
         L.Xp = take(npts * 128 * 4); L.Xh0 = take(npts * 64 * 4); L.Xh1 = take(npts * 64 * 4);
@@ -500,7 +503,9 @@ namespace {
 int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts, const float* view,
                  int mode, uint32_t keep_mask, const float* noise, float noise_std, const float* d_x, const float* d_out,
                  float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws, size_t ws_bytes, void* stream,
-                 const kpn_points* marched = nullptr) {
+                 const kpn_points* marched = nullptr, void* fwd_query_ws = nullptr) {
+    // fwd_query_ws: the workspace a run_field() call on the SAME points just used: its valid list and row scratch are
+    // reused instead of being recomputed (the train-branch backward runs the forward anyway to get rgba)
     // marched: the points are ray-marched (cam_pos + dirs * z, as kpn_render_rays evaluates them) instead of explicit;
     // one pass only (N <= kBwdChunk)
     const int V = d->n_views;
@@ -542,73 +547,96 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
     const int blocks = field_grid_blocks();
     const bool views_dropped = (keep_mask & ((1u << V) - 1u)) != ((1u << V) - 1u);
     // dW[layer] += dY^T X over the rows (which = 0) or points (which = 1) of this pass
-    // Kc: columns of the X dump (even); Kt: how many of them are real input features (<= Kc)
-    auto wgrad_ex = [&](auto mv, auto enc, auto omap, int which, const float* dY, int ldy, int M, const float* X, int ldx, int Kc,
-                        int Kt, int layer) {
-        constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value, OMAP = decltype(omap)::value;
-        const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
-        float* dW = d_plain + plain_w_off(layer);
-        float* dB = dW + (size_t)plain_dims[layer][0] * plain_dims[layer][1];
-        KPN_LAUNCH(k_weight_grad<MV>, dim3(nworkers), dim3(64 * gz), stream, dY, ldy, M, X, ldx, Kc,
-                   (const int64_t*)(rows_dev + which), partial, dbp);
-        constexpr int nelem = MV * 2 * 16 * 64 + MV * 32;
-        KPN_LAUNCH((k_weight_grad_reduce<MV, ENC, OMAP>), dim3((nelem + 31) / 32, gz), dim3(256), stream, (const float*)partial,
-                   (const float*)dbp, nworkers, M, Kt, dW, plain_dims[layer][1], dB);
+    // weight-gradient jobs of a pass: queued while the producers are launched, then run in one launch per MV class
+    // and one reduce launch
+    kpn_wgrad_jobs jobs[3], all;  // MV = 1, 2, 4
+    int gzmax[3];
+    size_t partial_used = 0;
+    bool overflow = false;
+    auto reset_jobs = [&]() { jobs[0].n = jobs[1].n = jobs[2].n = all.n = 0; gzmax[0] = gzmax[1] = gzmax[2] = 0; partial_used = 0; };
+    // which: 0 = (point, view) rows, 1 = points.  Kc: columns of the X dump read (even); Kt: real input features
+    auto wgrad = [&](int mv, int which, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int Kt, int layer,
+                     int cmap, int omap) {
+        const int cls = mv == 1 ? 0 : (mv == 2 ? 1 : 2);
+        const int gz = (Kc + 63) / 64;
+        kpn_wgrad_job j;
+        j.dY = dY; j.X = X; j.ldy = ldy; j.M = M; j.ldx = ldx; j.Kc = Kc; j.Kt = Kt; j.cmap = cmap; j.omap = omap; j.mv = mv; j.which = which;
+        j.partial = partial + partial_used;
+        partial_used += (size_t)gz * kGradWorkers * mv * 2048;
+        if (partial_used > (size_t)kPartialUnits * kGradWorkers * 2048 || all.n >= KPN_WGRAD_MAX_JOBS) { overflow = true; return; }
+        j.dbp = dbp + (size_t)all.n * kGradWorkers * 4 * 64;
+        j.dW = d_plain + plain_w_off(layer);
+        j.dB = j.dW + (size_t)plain_dims[layer][0] * plain_dims[layer][1];
+        j.in_dim = plain_dims[layer][1];
+        jobs[cls].j[jobs[cls].n++] = j;
+        all.j[all.n++] = j;
+        if (gz > gzmax[cls]) gzmax[cls] = gz;
     };
-    auto wgrad = [&](auto mv, auto enc, int which, const float* dY, int ldy, int M, const float* X, int ldx, int Kc, int layer) {
-        constexpr int MV = decltype(mv)::value, ENC = decltype(enc)::value;
-        const int gz = (Kc + 63) / 64, nworkers = kGradWorkers;
-        float* dW = d_plain + plain_w_off(layer);
-        float* dB = dW + (size_t)plain_dims[layer][0] * plain_dims[layer][1];
-        KPN_LAUNCH(k_weight_grad<MV>, dim3(nworkers), dim3(64 * gz), stream, dY, ldy, M, X, ldx, Kc,
-                   (const int64_t*)(rows_dev + which), partial, dbp);
-        constexpr int nelem = MV * 2 * 16 * 64 + MV * 32;
-        KPN_LAUNCH((k_weight_grad_reduce<MV, ENC>), dim3((nelem + 31) / 32, gz), dim3(256), stream, (const float*)partial,
-                   (const float*)dbp, nworkers, M, Kc, dW, plain_dims[layer][1], dB);
+    auto run_jobs = [&]() {
+        if (jobs[0].n) KPN_LAUNCH(k_weight_grad<1>, dim3(kGradWorkers, jobs[0].n), dim3(64 * gzmax[0]), stream, jobs[0], (const int64_t*)rows_dev);
+        if (jobs[1].n) KPN_LAUNCH(k_weight_grad<2>, dim3(kGradWorkers, jobs[1].n), dim3(64 * gzmax[1]), stream, jobs[1], (const int64_t*)rows_dev);
+        if (jobs[2].n) KPN_LAUNCH(k_weight_grad<4>, dim3(kGradWorkers, jobs[2].n), dim3(64 * gzmax[2]), stream, jobs[2], (const int64_t*)rows_dev);
+        int gz_all = gzmax[0] > gzmax[1] ? gzmax[0] : gzmax[1];
+        if (gzmax[2] > gz_all) gz_all = gzmax[2];
+        const int mv_all = jobs[2].n ? 4 : (jobs[1].n ? 2 : 1);
+        if (all.n) KPN_LAUNCH(k_weight_grad_reduce, dim3((mv_all * 2048 + mv_all * 32 + 31) / 32, gz_all, all.n), dim3(256), stream, all,
+                              (int)kGradWorkers);
     };
     for (int64_t c0 = 0; c0 < N; c0 += L.chunk) {
         const int64_t n = (N - c0 < L.chunk) ? (N - c0) : L.chunk;
         const kpn_points ps = marched ? *marched
                                       : kpn_points{pts + c0 * 3, (view ? view : pts) + c0 * 3, nullptr, nullptr, nullptr, 1,
                                                    noise ? noise + c0 : nullptr, noise_std};
+        reset_jobs();
         hipMemsetAsync(count, 0, 8 * sizeof(int), (hipStream_t)stream);
-        KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
-                   (uint8_t*)nullptr, list, count);
-        KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, (const int*)count, V, rows_dev);
+        const int* vcount = count;  // valid count of this pass
+        float* xscr = full ? fp(L.xscr) : nullptr;
+        if (fwd_query_ws && full) {
+            const QueryLayout Q = query_layout(n, V);
+            char* qb = static_cast<char*>(fwd_query_ws);
+            vcount = reinterpret_cast<const int*>(qb + Q.count);
+            list = reinterpret_cast<int*>(qb + Q.list);
+            xscr = reinterpret_cast<float*>(qb + Q.xscr);
+        } else {
+            KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
+                       (uint8_t*)nullptr, list, count);
+        }
+        KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, vcount, V, rows_dev);
         if (full) {
-            float* xscr = fp(L.xscr);
-            KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
+            if (!fwd_query_ws)
+                KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 1, xscr);
             if (full == 2) {
                 // rows of dropped views are skipped by k_color_bwd: their dumps must read as zeros in k_weight_grad
                 if (views_dropped) hipMemsetAsync(fp(L.color), 0, L.color_bytes, (hipStream_t)stream);
-                KPN_LAUNCH(k_color_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 4,
+                KPN_LAUNCH(k_color_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
                            (const float*)xscr, d_out + c0 * 5, C);
-                const kpn_ic<0> n0; const kpn_ic<1> n1; const kpn_ic<2> n2;
-                wgrad_ex(n1, n0, n0, 0, C.Do2, 2, 1, C.Xo2, 8, 8, 8, P_O_2);
-                wgrad_ex(n1, n0, n0, 0, C.Do1, 8, 8, C.Xo1, 16, 16, 16, P_O_1);
-                wgrad_ex(n1, n0, n0, 0, C.Do0, 16, 16, C.Xo0, KPN_LD_XO0, KPN_LD_XO0, 37, P_O_0);
-                wgrad_ex(n1, n0, n0, 0, C.Dv21, 2, 1, C.Xv21, 32, 32, 32, P_V2_1);
-                wgrad_ex(n1, n0, n0, 0, C.Dv20, 32, 32, C.Xv20, 32, 32, 32, P_V2_0);
-                wgrad_ex(n2, n0, n0, 0, C.Dv11, KPN_LD_DV11, 33, C.Xv11, 32, 32, 32, P_V1_1);
-                wgrad_ex(n1, n0, n0, 0, C.Dv10, 32, 32, C.Xv10, 32, 32, 32, P_V1_0);
-                wgrad_ex(n1, n0, n0, 0, C.Dbl1, 32, 32, C.Xb1, 64, 64, 64, P_BL_1);
-                wgrad_ex(n2, n2, n0, 0, C.Dbl0, 64, 64, C.Xbl, KPN_LD_XBL, KPN_LD_XBL, KPN_LD_XBL, P_BL_0);
-                wgrad_ex(n2, n0, n1, 0, C.Dre1, KPN_LD_XDIR, 35, C.Xe1, 16, 16, 16, P_RE_1);
-                wgrad_ex(n1, n0, n0, 0, C.Dre0, 16, 16, C.Xrd, 4, 4, 4, P_RE_0);
+                wgrad(1, 0, C.Do2, 2, 1, C.Xo2, 8, 8, 8, P_O_2, 0, 0);
+                wgrad(1, 0, C.Do1, 8, 8, C.Xo1, 16, 16, 16, P_O_1, 0, 0);
+                wgrad(1, 0, C.Do0, 16, 16, C.Xo0, KPN_LD_XO0, KPN_LD_XO0, 37, P_O_0, 0, 0);
+                wgrad(1, 0, C.Dv21, 2, 1, C.Xv21, 32, 32, 32, P_V2_1, 0, 0);
+                wgrad(1, 0, C.Dv20, 32, 32, C.Xv20, 32, 32, 32, P_V2_0, 0, 0);
+                wgrad(2, 0, C.Dv11, KPN_LD_DV11, 33, C.Xv11, 32, 32, 32, P_V1_1, 0, 0);
+                wgrad(1, 0, C.Dv10, 32, 32, C.Xv10, 32, 32, 32, P_V1_0, 0, 0);
+                wgrad(1, 0, C.Dbl1, 32, 32, C.Xb1, 64, 64, 64, P_BL_1, 0, 0);
+                wgrad(2, 0, C.Dbl0, 64, 64, C.Xbl, KPN_LD_XBL, KPN_LD_XBL, KPN_LD_XBL, P_BL_0, 2, 0);
+                wgrad(2, 0, C.Dre1, KPN_LD_XDIR, 35, C.Xe1, 16, 16, 16, P_RE_1, 0, 1);
+                wgrad(1, 0, C.Dre0, 16, 16, C.Xrd, 4, 4, 4, P_RE_0, 0, 0);
             }
-            KPN_LAUNCH(k_fuse_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 2,
+            KPN_LAUNCH(k_fuse_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 2,
                        (const float*)xscr, mode, d_out + c0 * 5, F);
-            wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 1, F.D20, 64, 64, F.Xp, 128, 128, P_G2_0);
-            wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 1, F.D21, 64, 64, F.Xh0, 64, 64, P_G2_1);
-            wgrad(kpn_ic<1>{}, kpn_ic<0>{}, 1, F.D22, 2, 2, F.Xh1, 64, 64, P_G2_2);
-            if (full == 2) wgrad(kpn_ic<1>{}, kpn_ic<0>{}, 1, C.Dcmp, 24, 24, F.Xp, 128, 128, P_CMP);
+            wgrad(2, 1, F.D20, 64, 64, F.Xp, 128, 128, 128, P_G2_0, 0, 0);
+            wgrad(2, 1, F.D21, 64, 64, F.Xh0, 64, 64, 64, P_G2_1, 0, 0);
+            wgrad(1, 1, F.D22, 2, 2, F.Xh1, 64, 64, 64, P_G2_2, 0, 0);
+            if (full == 2) wgrad(1, 1, C.Dcmp, 24, 24, F.Xp, 128, 128, 128, P_CMP, 0, 0);
         }
-        KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 3,
+        KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 3,
                    full ? (const float*)F.dxrows : d_x + c0 * V * 64, full ? 1 : 0, B);
-        wgrad(kpn_ic<4>{}, kpn_ic<1>{}, 0, B.D0, 128, 128, B.X0, KPN_LDX0, 232, P_G1_0);
-        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, 0, B.D1, 128, 128, B.X1, 128, 128, P_G1_1);
-        wgrad(kpn_ic<4>{}, kpn_ic<0>{}, 0, B.D2, 128, 120, B.X2, KPN_LDX2, 136, P_G1_2);
-        wgrad(kpn_ic<2>{}, kpn_ic<0>{}, 0, B.D3, 64, 64, B.X3, 128, 120, P_G1_3);
+        wgrad(4, 0, B.D0, 128, 128, B.X0, KPN_LDX0, 232, 232, P_G1_0, 1, 0);
+        wgrad(4, 0, B.D1, 128, 128, B.X1, 128, 128, 128, P_G1_1, 0, 0);
+        wgrad(4, 0, B.D2, 128, 120, B.X2, KPN_LDX2, 136, 136, P_G1_2, 0, 0);
+        wgrad(2, 0, B.D3, 64, 64, B.X3, 128, 120, 120, P_G1_3, 0, 0);
+        if (overflow) return fail(KPN_EWORKSPACE, "weight-gradient scratch too small (internal)");
+        run_jobs();
     }
     return check_launch("field backward");
 }
@@ -883,6 +911,16 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
         sc.keep = t->keep_coarse;
         if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream)) return e;
         if (int e = kpn_rgba2out(F(L.rgba_c), F(L.zc), n, Sc, sc4, sc4 + 3 * n, sc4 + 4 * n, F(L.contrib), sc4 + 5 * n, stream)) return e;
+        // ---- coarse pass reverse (before the fine forward overwrites the query workspace whose valid list and row
+        //      scratch it reuses); sample positions carry no gradient (model.py:1038,1118) ----
+        const size_t bwd_bytes = L.total - L.bwd;
+        KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg, F(L.g3));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth, F(L.g1a));
+        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha, F(L.g1b));
+        if (int e = kpn_rgba2out_backward(F(L.rgba_c), F(L.zc), n, Sc, F(L.g3), F(L.g1a), F(L.g1b), nullptr, F(L.drgba_c), stream)) return e;
+        if (int e = run_backward(d, scene_ws, wp, n * Sc, nullptr, nullptr, 1, t->keep_coarse, nullptr, 0.0f, nullptr, F(L.drgba_c),
+                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pc, base + L.query)) return e;
+        // ---- fine pass: samples, forward, reverse ----
         if (Sc <= 64 && Sf <= 64)
             KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib),
                        t->u_fine + r0 * Sf, F(L.zf));
@@ -892,22 +930,13 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
         kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
         sc.keep = t->keep_fine;
         if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream)) return e;
-        // ---- compositor reverse: d rgba of both passes (sample positions carry no gradient, model.py:1038,1118) ----
-        KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg, F(L.g3));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth, F(L.g1a));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha, F(L.g1b));
-        if (int e = kpn_rgba2out_backward(F(L.rgba_c), F(L.zc), n, Sc, F(L.g3), F(L.g1a), F(L.g1b), nullptr, F(L.drgba_c), stream)) return e;
         KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg_fine, F(L.g3));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth_fine, F(L.g1a));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha_fine, F(L.g1b));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_sdf, F(L.g1c));
         if (int e = kpn_rgba2out_backward(F(L.rgba_f), F(L.zf), n, Sfull, F(L.g3), F(L.g1a), F(L.g1b), F(L.g1c), F(L.drgba_f), stream)) return e;
-        // ---- field reverse of both point sets ----
-        const size_t bwd_bytes = L.total - L.bwd;
-        if (int e = run_backward(d, scene_ws, wp, n * Sc, nullptr, nullptr, 1, t->keep_coarse, nullptr, 0.0f, nullptr, F(L.drgba_c),
-                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pc)) return e;
         if (int e = run_backward(d, scene_ws, wp, n * Sfull, nullptr, nullptr, 1, t->keep_fine, nullptr, 0.0f, nullptr, F(L.drgba_f),
-                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pf)) return e;
+                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pf, base + L.query)) return e;
     }
     (void)V;
     return check_launch("kpn_render_rays_train_backward");
