@@ -39,6 +39,9 @@ struct kpn_bwd_bufs {
 #define KPN_ST1(p, v) (*(p) = (v))
 #endif
 #define KPN_SCAT_LD 76  // 72 floats + pad: rows start on different banks, float4-aligned
+#ifndef KPN_BWD_OCC
+#define KPN_BWD_OCC 2
+#endif
 #define KPN_LDX0 232
 #define KPN_LDX2 136
 
@@ -48,7 +51,7 @@ __device__ __forceinline__ float kpn_softplus100_grad_from_value(float sp) { ret
 
 // dx: upstream gradient d loss / d x_view: [N][V][64] indexed by the ORIGINAL point index, or (dx_compact) by
 // row = (tile*V + v)*32 + p as k_fuse_bwd writes it
-__global__ __launch_bounds__(256, 2) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                          const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                          int* __restrict__ tickets, const float* __restrict__ dx,
                                                          int dx_compact, kpn_bwd_bufs bufs) {
