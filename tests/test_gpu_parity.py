@@ -400,3 +400,40 @@ def test_train_render_backward(ops, golden_weights, case):
     got = ops.render_rays_train_backward(ps, w, s["cam_tar"], s["bounds"], cu(g["pix"]), cu(g["u_c"]), cu(g["u_f"]),
                                          keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), grads, **args)
     assert_train_grads_vs_golden([x.cpu().numpy() for x in got], g, sd, 1e-4)
+
+
+def test_backward_multi_pass_and_chunking(ops, golden_weights):
+    """More points than one backward pass holds (262,144): the passes' gradients add up — equal to the sum of two separate
+    calls on the halves; the train-branch backward with 512-ray passes equals the single-pass result."""
+    from keypointnerf_amd.synthetic import make_scene
+    sd, w = golden_weights
+    big = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(64, 64), mask="ellipsoid", seed=23)
+    s, ps = _prep(ops, big)
+    N = 300_000
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    lo, hi = s["bounds"].reshape(2, 3)[0], s["bounds"].reshape(2, 3)[1]
+    P = lo + (hi - lo) * torch.rand(N, 3, device="cuda", generator=gen)
+    Vw = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=gen), dim=-1)
+    G = torch.randn(N, 5, device="cuda", generator=gen)
+    full = ops.query_backward(ps, w, P, Vw, G, mode=1)
+    h = 150_016
+    a = ops.query_backward(ps, w, P[:h], Vw[:h], G[:h], mode=1)
+    b = ops.query_backward(ps, w, P[h:], Vw[h:], G[h:], mode=1)
+    for i in range(4):
+        ref = a[i] + b[i]
+        assert torch.isfinite(full[i]).all()
+        assert (full[i] - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-6, i
+    # train branch: 1024 rays, one pass vs 512-ray passes
+    R, Sc, Sf = 1024, 16, 16
+    yy, xx = torch.meshgrid(torch.arange(32), torch.arange(32), indexing="ij")
+    pix = torch.stack([xx.reshape(-1) + 16, yy.reshape(-1) + 16], -1).to(torch.int32).cuda()
+    u_c, u_f = torch.rand(R, Sc, device="cuda", generator=gen), torch.rand(R, Sf, device="cuda", generator=gen)
+    n_c, n_f = torch.randn(R * Sc, device="cuda", generator=gen), torch.randn(R * (Sc + Sf), device="cuda", generator=gen)
+    kw = dict(noise_coarse=n_c, noise_fine=n_f, rand_noise_std=0.05, n_coarse=Sc, n_fine=Sf)
+    out = ops.render_rays_train(ps, w, s["cam_tar"], s["bounds"], pix, u_c, u_f, 0b111, 0b110, **kw)
+    grads = {k: torch.randn(v.shape, device="cuda", generator=gen) for k, v in out.items()}
+    one = ops.render_rays_train_backward(ps, w, s["cam_tar"], s["bounds"], pix, u_c, u_f, 0b111, 0b110, grads, **kw)
+    two = ops.render_rays_train_backward(ps, w, s["cam_tar"], s["bounds"], pix, u_c, u_f, 0b111, 0b110, grads, chunk_rays=512, **kw)
+    for i in range(4):
+        assert one[i].abs().max() > 0
+        assert (one[i] - two[i]).abs().max() <= 2e-4 * one[i].abs().max() + 1e-6, i
