@@ -498,8 +498,8 @@ __global__ void k_bwd_rows(const int* __restrict__ count, int V, int64_t* __rest
 }
 
 namespace {
-// d_x != nullptr: geometry rows only, upstream gradient given per (point, view).  Otherwise the whole-query reverse
-// from d_out (N,5) [geometry outputs only so far: the colour head's reverse is not built].
+// d_x != nullptr: geometry rows only, upstream gradient given per (point, view).  Otherwise the whole-query reverse from
+// d_out (N,5): its geometry columns only (d_tex == nullptr) or all five incl. the colour head (d_tex != nullptr).
 int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts, const float* view,
                  int mode, uint32_t keep_mask, const float* noise, float noise_std, const float* d_x, const float* d_out,
                  float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws, size_t ws_bytes, void* stream,
@@ -896,7 +896,6 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
     kpn_scene_dev sc = scene_dev(d, scene_ws);
     const int64_t R = (int64_t)a->nx * a->ny;
     const int Sc = a->n_coarse, Sf = a->n_fine, Sfull = Sc + Sf;
-    const int V = d->n_views;
     KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
                (int)a->step, (int)a->nx, (int)a->ny, (const int*)t->pix, F(L.dirs), F(L.cam_pos), F(L.nearv), F(L.farv));
     const float std_ = t->rand_noise_std;
@@ -938,7 +937,6 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
         if (int e = run_backward(d, scene_ws, wp, n * Sfull, nullptr, nullptr, 1, t->keep_fine, nullptr, 0.0f, nullptr, F(L.drgba_f),
                                  d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pf, base + L.query)) return e;
     }
-    (void)V;
     return check_launch("kpn_render_rays_train_backward");
 }
 
