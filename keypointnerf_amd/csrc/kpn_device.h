@@ -172,38 +172,50 @@ __device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, 
     }
 }
 // in_fn(kpn_ic<g>, float (&x)[G]) produces the B operands of K-steps [g*G, (g+1)*G)
+#ifndef KPN_WDEPTH
+#define KPN_WDEPTH 1   // weight groups in flight ahead of the one being multiplied (global streams); 2 measured: no gain
+#endif
 template <int KS, int NOB, int G, int MEM = 0, class InFn>
 __device__ __forceinline__ void kpn_mfma_layer(const float* __restrict__ wseg, int lane, InFn&& in_fn,
                                                kpn_f32x16 (&acc)[NOB]) {
     static_assert(KS % G == 0, "K-steps come in whole groups");
     static_assert((G * NOB) % 4 == 0, "a lane's operands of one group are whole float4s");
     constexpr int NG = KS / G, NQ = G * NOB / 4;
-    kpn_f32x4 w[2][NQ];
+    constexpr int DEPTH = (MEM == 0) ? KPN_WDEPTH : 1, NBUF = DEPTH + 1;
+    kpn_f32x4 w[NBUF][NQ];
     float x[2][G];
-    kpn_load_group<NQ, MEM>(wseg, lane, w[0]);
+    kpn_static_for<0, DEPTH>([&](auto di) {
+        constexpr int dg = decltype(di)::value;
+        if constexpr (dg < NG) {
+            const float* gp = wseg + (size_t)dg * 64 * (4 * NQ);
+            kpn_load_group<NQ, MEM>(gp, lane, w[dg % NBUF]);
+        }
+    });
     in_fn(kpn_ic<0>{}, x[0]);
     kpn_static_for<0, NG>([&](auto gi) {
         constexpr int g = decltype(gi)::value;
         constexpr int cur = g & 1, nxt = cur ^ 1;
-        if constexpr (g + 1 < NG) {
-            const float* gp = wseg + (size_t)(g + 1) * 64 * (4 * NQ);
+        constexpr int wcur = g % NBUF, wnext = (g + 1) % NBUF, wload = (g + DEPTH) % NBUF;
+        if constexpr (g + DEPTH < NG) {
+            const float* gp = wseg + (size_t)(g + DEPTH) * 64 * (4 * NQ);
             if constexpr (MEM == 0) KPN_PIN_POINTER(gp);
-            kpn_load_group<NQ, MEM>(gp, lane, w[nxt]);
-            in_fn(kpn_ic<g + 1>{}, x[nxt]);
+            kpn_load_group<NQ, MEM>(gp, lane, w[wload]);
         }
+        if constexpr (g + 1 < NG) in_fn(kpn_ic<g + 1>{}, x[nxt]);
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob)
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][(i * NOB + ob) / 4][(i * NOB + ob) % 4], x[cur][i],
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[wcur][(i * NOB + ob) / 4][(i * NOB + ob) % 4], x[cur][i],
                                                                acc[ob], 0, 0, 0);
 
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) KPN_FENCE_RW(acc[ob]);
         if constexpr (g + 1 < NG) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) KPN_FENCE_R(w[nxt][q]);
-            KPN_SCHED_GROUP(MEM == 0 ? 0x020 : 0x100, NQ);  // VMEM reads (global) / DS reads (LDS) of the next group first
+            for (int q = 0; q < NQ; ++q) KPN_FENCE_R(w[wnext][q]);
+            if constexpr (g + DEPTH < NG)
+                KPN_SCHED_GROUP(MEM == 0 ? 0x020 : 0x100, NQ);  // VMEM reads (global) / DS reads (LDS) of a later group first
             // then this group's MFMAs, each followed by a few of the VALU / transcendental instructions that
             // produce the next group's B operands, so that no VALU clump leaves the matrix pipe idle
 #pragma unroll
