@@ -318,6 +318,38 @@ __device__ __forceinline__ void kpn_encode_view(const float* __restrict__ wl, in
     o.xb1[2] = kpn_elu(a2[1][2]) + g.fadd[6];
 }
 
+// View pooling of the 64-vector (PoolModule / pool_ops, utils.py:612-647, 731-748): weighted mean and variance over
+// the source views, two passes in the reference's order.  The un-normalised boundary-smooth weights (model.py:752-759;
+// mask == 1 in every view for listed points) come with the gather records k_geo_rows wrote; dropped views weigh 0.
+// pooled[16b + r] = mean of feature 32b + rowmap(r,h), pooled[32 + 16b + r] = its variance (a lane's half of the point).
+// Returns the weights' sum (before the + 1e-6 of the normalisation).
+__device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows, int V, uint32_t keep, int lane, float (&pooled)[64]) {
+    const int p = lane & 31;
+    float pwsum = 0.0f;
+    for (int v = 0; v < V; ++v)
+        if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
+#pragma unroll
+    for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int v = 0; v < V; ++v) {
+            if (!((keep >> v) & 1u)) continue;
+            const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
+            const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) {
+                const float4 x = src[q4 * 64 + lane];
+                const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q4 + e;
+                    if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
+                    else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
+                }
+            }
+        }
+    return pwsum;
+}
+
 // VC > 0: requires V <= VC; the views' gathers, their 64-vectors from k_geo_rows and their x' vectors stay in
 // registers (fully unrolled over views).  VC == 0: any V <= KPN_MAXV, per-view data are recomputed per pass.
 template <int VC>
@@ -355,33 +387,11 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         const int ci = ci_raw < count ? ci_raw : count - 1;
         const int64_t n = list[ci];
 
-        // ---- pooled mean / var over views of the 64-vector (utils.py:731-748).  Pooling weights
-        //      (model.py:752-759; mask == 1 in every view for listed points) come with the gather records. ----
+        // ---- pooled mean / var over views of the 64-vector ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
-        float pwsum = 0.0f;
-        for (int v = 0; v < V; ++v)
-            if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
-#pragma unroll
-        for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int v = 0; v < V; ++v) {
-                if (!((keep >> v) & 1u)) continue;
-                const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-                const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
-#pragma unroll
-                for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x = src[q4 * 64 + lane];
-                    const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * q4 + e;
-                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
-                        else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
-                    }
-                }
-            }
+        kpn_pool_views(rows, V, keep, lane, pooled);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
         {

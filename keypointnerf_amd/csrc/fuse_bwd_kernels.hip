@@ -62,29 +62,8 @@ __global__ __launch_bounds__(256, 2) void k_fuse_bwd(kpn_scene_dev sc, kpn_point
 
         // ---- recompute: pooling (as k_fuse_color) ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
-        float pwsum = 0.0f;
-        for (int v = 0; v < V; ++v)
-            if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);
         float pooled[64];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int v = 0; v < V; ++v) {
-                if (!((keep >> v) & 1u)) continue;
-                const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-                const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
-#pragma unroll
-                for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x = src[q4 * 64 + lane];
-                    const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * q4 + e;
-                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
-                        else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
-                    }
-                }
-            }
+        const float pwsum = kpn_pool_views(rows, V, keep, lane, pooled);
         // pooled[16b + r] = mean feature 32b + rowmap(r,h); pooled[32 + 16b + r] = var of the same feature
         {
             float* xp = bufs.Xp + prow * 128;
@@ -281,29 +260,8 @@ __global__ __launch_bounds__(256, 1) void k_color_bwd(kpn_scene_dev sc, kpn_poin
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         float lat0[16];
         {
-            float pwsum = 0.0f;
-            for (int v = 0; v < V; ++v)
-                if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);
             float pooled[64];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-            for (int pass = 0; pass < 2; ++pass)
-                for (int v = 0; v < V; ++v) {
-                    if (!((keep >> v) & 1u)) continue;
-                    const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-                    const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
-#pragma unroll
-                    for (int q4 = 0; q4 < 8; ++q4) {
-                        const float4 x = src[q4 * 64 + lane];
-                        const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int i = 4 * q4 + e;
-                            if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
-                            else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
-                        }
-                    }
-                }
+            kpn_pool_views(rows, V, keep, lane, pooled);
             kpn_f32x16 acc[1];
             kpn_load_bias<1>(wp + kpn_seg_boff(SEG_CMP), h, acc);
             kpn_mfma_layer_regs<64, 1, 4, 0>(wp + kpn_seg_woff(SEG_CMP), lane, pooled, acc);
