@@ -323,8 +323,8 @@ __device__ __forceinline__ void kpn_encode_view(const float* __restrict__ wl, in
 // mask == 1 in every view for listed points) come with the gather records k_geo_rows wrote; dropped views weigh 0.
 // pooled[16b + r] = mean of feature 32b + rowmap(r,h), pooled[32 + 16b + r] = its variance (a lane's half of the point).
 // Returns the weights' sum (before the + 1e-6 of the normalisation).
-__device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows, int V, uint32_t keep, int lane, float (&pooled)[64]) {
-    const int p = lane & 31;
+__device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows, int V, uint32_t keep, int lane, int p,
+                                                float (&pooled)[64]) {
     float pwsum = 0.0f;
     for (int v = 0; v < V; ++v)
         if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
@@ -350,9 +350,9 @@ __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows,
     return pwsum;
 }
 
-// VC > 0: requires V <= VC; the views' gathers, their 64-vectors from k_geo_rows and their x' vectors stay in
-// registers (fully unrolled over views).  VC == 0: any V <= KPN_MAXV, per-view data are recomputed per pass.
-template <int VC>
+// Any V <= KPN_MAXV: the per-view x' vectors are recomputed in each of the three passes over the views (two for the
+// weighted mean / variance, one for the head).  A V <= 3 variant that kept them in registers was measured slower: this
+// kernel is register-bound, and every spilled VGPR costs more than re-running the 624-MAC ray encoder.
 __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
@@ -364,7 +364,6 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
     const int V = sc.V;
-    constexpr int NV = VC > 0 ? VC : 1;
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
     // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
     __shared__ __attribute__((aligned(16))) float wlds[kpn_k2_floats()];
@@ -390,8 +389,30 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         // ---- pooled mean / var over views of the 64-vector ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
+        // (kpn_pool_views spelled out: through the helper this kernel measured 1.7 ms per frame slower)
+        float pwsum = 0.0f;
+        for (int v = 0; v < V; ++v)
+            if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
-        kpn_pool_views(rows, V, keep, lane, pooled);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int v = 0; v < V; ++v) {
+                if (!((keep >> v) & 1u)) continue;
+                const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
+                const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    const float4 x = src[q4 * 64 + lane];
+                    const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q4 + e;
+                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
+                        else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
+                    }
+                }
+            }
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
         {
@@ -424,35 +445,22 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         }
         // ---- IBR head (model.py:1267-1302) ----
         // blend weights (model.py:1287-1289): w_v = (e_v - min_v e) / (sum + 1e-8), e_v = exp(|a|(dot_v - 1))
-        kpn_view_gather gv[NV];
-        kpn_ibr_view ivs[NV];
+        kpn_view_gather gv;
+        kpn_ibr_view iv;
         float emin = 3.0e38f, esum = 0.0f;
-        if constexpr (VC > 0) {
-#pragma unroll
-            for (int v = 0; v < VC; ++v)
-                if (v < V) {
-                    kpn_gather_view(xscr, t, V, v, lane, h, gv[v]);
-                    if ((keep >> v) & 1u) kpn_encode_view(wl, lane, h, gv[v], lat0, ivs[v]);
-                    emin = fminf(emin, kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))));  // min over ALL views (:1288)
-                }
-#pragma unroll
-            for (int v = 0; v < VC; ++v)
-                if (v < V && ((keep >> v) & 1u)) esum = KADD(esum, KSUB(kpn_fast_exp(KMUL(ani, KSUB(gv[v].rd[3], 1.0f))), emin));
-        } else {
-            for (int pass = 0; pass < 2; ++pass)
-                for (int v = 0; v < V; ++v) {
-                    const float dot = rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w;
-                    const float e = kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f)));
-                    if (pass == 0) emin = fminf(emin, e);
-                    else if ((keep >> v) & 1u) esum = KADD(esum, KSUB(e, emin));
-                }
-        }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int v = 0; v < V; ++v) {
+                const float dot = rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w;
+                const float e = kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f)));
+                if (pass == 0) emin = fminf(emin, e);  // min over ALL views (:1288)
+                else if ((keep >> v) & 1u) esum = KADD(esum, KSUB(e, emin));
+            }
         // fused mean/var over views of x' (utils.py:91-95): K-steps mean' (16 + 3 + pad), var' (16 + 3 + pad)
         float mv[40];
 #pragma unroll
         for (int i = 0; i < 40; ++i) mv[i] = 0.0f;
-        auto stats = [&](int pass, const kpn_view_gather& g, const kpn_ibr_view& iv) {
-            const float wv = KSUB(kpn_fast_exp(KMUL(ani, KSUB(g.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
+        auto stats = [&](int pass, float dot, const kpn_ibr_view& iv) {
+            const float wv = KSUB(kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f))), emin) / KADD(esum, 1e-8f);
 #pragma unroll
             for (int i = 0; i < 19; ++i) {
                 const float x = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
@@ -460,19 +468,13 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                 else { const float d = KSUB(x, mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
             }
         };
-        for (int pass = 0; pass < 2; ++pass) {
-            if constexpr (VC > 0) {
-#pragma unroll
-                for (int v = 0; v < VC; ++v) if (v < V && ((keep >> v) & 1u)) stats(pass, gv[v], ivs[v]);
-            } else {
-                for (int v = 0; v < V; ++v) {
-                    if (!((keep >> v) & 1u)) continue;
-                    kpn_gather_view(xscr, t, V, v, lane, h, gv[0]);
-                    kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
-                    stats(pass, gv[0], ivs[0]);
-                }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int v = 0; v < V; ++v) {
+                if (!((keep >> v) & 1u)) continue;
+                kpn_gather_view(xscr, t, V, v, lane, h, gv);
+                kpn_encode_view(wl, lane, h, gv, lat0, iv);
+                stats(pass, gv.rd[3], iv);
             }
-        }
         // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
         kpn_f32x16 base[2];
         kpn_load_bias<2>(wl + kpn_seg_boff(SEG_BL_0A), h, base);
@@ -538,16 +540,11 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             c0 = c0 * sc_old + g.rgb[0] * pn; c1 = c1 * sc_old + g.rgb[1] * pn; c2 = c2 * sc_old + g.rgb[2] * pn;
             lmax = nmax;
         };
-        if constexpr (VC > 0) {
-#pragma unroll
-            for (int v = 0; v < VC; ++v) if (v < V && ((keep >> v) & 1u)) head(gv[v], ivs[v]);
-        } else {
-            for (int v = 0; v < V; ++v) {
-                if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
-                kpn_gather_view(xscr, t, V, v, lane, h, gv[0]);
-                kpn_encode_view(wl, lane, h, gv[0], lat0, ivs[0]);
-                head(gv[0], ivs[0]);
-            }
+        for (int v = 0; v < V; ++v) {
+            if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
+            kpn_gather_view(xscr, t, V, v, lane, h, gv);
+            kpn_encode_view(wl, lane, h, gv, lat0, iv);
+            head(gv, iv);
         }
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;

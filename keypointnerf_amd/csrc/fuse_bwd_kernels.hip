@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_fuse_bwd(kpn_scene_dev sc, kpn_point
         // ---- recompute: pooling (as k_fuse_color) ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         float pooled[64];
-        const float pwsum = kpn_pool_views(rows, V, keep, lane, pooled);
+        const float pwsum = kpn_pool_views(rows, V, keep, lane, p, pooled);
         // pooled[16b + r] = mean feature 32b + rowmap(r,h); pooled[32 + 16b + r] = var of the same feature
         {
             float* xp = bufs.Xp + prow * 128;
@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256, 2) void k_fuse_bwd(kpn_scene_dev sc, kpn_point
 //             mean/var over views, the blend weights' dependence on ani_al, ray_encoder, d feat_tex (LDS-transposed
 //             scatter), and d lat per point (Dcmp), which k_fuse_bwd turns into d pooled.
 // Row strides of the dumps (floats); "x'" order = [lat24 | rgb3 | tex8] (kpn_common.h):
+#ifndef KPN_COLOR_OCC
+#define KPN_COLOR_OCC 1
+#endif
 #define KPN_LD_XDIR 36   // elu(ray_encoder.2) in x' order (+1 pad)
 #define KPN_LD_XBL 108   // [mean'(35)+pad | var'(35)+pad | x'(35)+pad]
 #define KPN_LD_XO0 40    // [x(32) | vis | ray_diff(4) | pad 3]
@@ -229,7 +232,7 @@ __device__ __forceinline__ float kpn_elu_grad_from_out(float y) { return y > 0.0
 // sum over the two halves of a point (lanes p and p + 32)
 __device__ __forceinline__ float kpn_pair_sum(float x) { return x + __shfl_xor(x, 32); }
 
-__global__ __launch_bounds__(256, 1) void k_color_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                       int* __restrict__ tickets, const float* __restrict__ xscr,
                                                       const float* __restrict__ d_out, kpn_color_bufs B) {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void k_color_bwd(kpn_scene_dev sc, kpn_poin
         float lat0[16];
         {
             float pooled[64];
-            kpn_pool_views(rows, V, keep, lane, pooled);
+            kpn_pool_views(rows, V, keep, lane, p, pooled);
             kpn_f32x16 acc[1];
             kpn_load_bias<1>(wp + kpn_seg_boff(SEG_CMP), h, acc);
             kpn_mfma_layer_regs<64, 1, 4, 0>(wp + kpn_seg_woff(SEG_CMP), lane, pooled, acc);

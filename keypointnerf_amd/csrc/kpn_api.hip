@@ -407,12 +407,8 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 #endif
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
     static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
-    if (sc.V <= 3)  // per-view IBR inputs cached in registers
-        KPN_LAUNCH(k_fuse_color<3>, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count,
-                   count + 1, (const float*)xscr, mode, out);
-    else
-        KPN_LAUNCH(k_fuse_color<0>, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count,
-                   count + 1, (const float*)xscr, mode, out);
+    KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1,
+               (const float*)xscr, mode, out);
     return check_launch("field query");
 }
 }  // namespace
