@@ -48,6 +48,10 @@ int kpn_is_device_build(void);
 size_t kpn_plain_weight_floats(void);
 size_t kpn_packed_weight_floats(void);
 int kpn_pack_weights(const float* plain_host, float* packed_host);
+/* The same re-ordering on the device (plain_dev -> packed_dev, both device pointers, asynchronous on `stream`): a
+ * training loop re-packs after every optimizer step without a host round trip.  The index map is taken once per
+ * process from kpn_pack_weights. */
+int kpn_pack_weights_device(const float* plain_dev, float* packed_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scene = what KeypointNeRF.query() receives besides the points: source cameras, keypoints, source

@@ -3,6 +3,7 @@
 // synchronises or allocates (except kpn_selftest_mfma, a diagnostic).
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -225,6 +226,69 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
         sc[3] = pl.ani_al > 0.0f ? 1.0f : (pl.ani_al < 0.0f ? -1.0f : 0.0f);  // d|a|/da for the colour-head reverse
     }
     return KPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side packing: the host packer above is a pure gather apart from four derived scalars, so its index map is
+// taken once (by packing a ramp) and applied on the device — a training loop re-packs after every optimizer step
+__global__ void k_pack_gather(const float* __restrict__ plain, const int32_t* __restrict__ map, int n, float* __restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = map[i];
+    packed[i] = m >= 0 ? plain[m] : 0.0f;
+}
+// scalars: |ani_al|, layers2(0) = query()'s [sdf_raw, rad] of a point masked in every view, sign(ani_al)
+__global__ void k_pack_scalars(const float* __restrict__ plain, size_t w0, size_t b0, size_t w1, size_t b1, size_t w2, size_t b2,
+                               size_t ani, float* __restrict__ sc) {
+    __shared__ float a[64], b[64];
+    const int o = threadIdx.x;  // 64 threads
+    auto sp = [](float x) { const float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; };
+    a[o] = sp(plain[b0 + o]);   // layers2.0 on pooled = 0
+    __syncthreads();
+    float acc = 0.0f;
+    for (int i = 0; i < 64; ++i) acc += plain[w1 + (size_t)o * 64 + i] * a[i];
+    b[o] = sp(acc + plain[b1 + o]);
+    __syncthreads();
+    if (o < 2) {
+        float s = 0.0f;
+        for (int i = 0; i < 64; ++i) s += plain[w2 + (size_t)o * 64 + i] * b[i];
+        sc[1 + o] = s + plain[b2 + o];
+    }
+    if (o == 2) {
+        const float al = plain[ani];
+        sc[0] = fabsf(al);
+        sc[3] = al > 0.0f ? 1.0f : (al < 0.0f ? -1.0f : 0.0f);
+    }
+    (void)w0;
+}
+
+extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev, void* stream) {
+    KPN_REQUIRE(plain_dev && packed_dev, "null pointer");
+    static int32_t* map_dev = nullptr;
+    static std::mutex mtx;
+    static bool built = false;
+    static int rc = KPN_OK;
+    const size_t np = kpn_plain_weight_floats(), nk = kpn_packed_weight_floats();
+    std::lock_guard<std::mutex> lock(mtx);
+    if (!built) [&] {
+        built = true;
+        std::vector<float> ramp(np), pk(nk, 0.0f);
+        for (size_t i = 0; i < np; ++i) ramp[i] = (float)(i + 1);  // exact in fp32 (np < 2^24)
+        if (kpn_pack_weights(ramp.data(), pk.data()) != KPN_OK) { rc = KPN_EINVAL; return; }
+        std::vector<int32_t> map(nk);
+        // (the four derived scalars are not gathers: k_pack_scalars writes them)
+        for (size_t i = 0; i < nk; ++i) map[i] = (pk[i] >= 1.0f && pk[i] <= (float)np) ? (int32_t)pk[i] - 1 : -1;
+        for (int i = 0; i < 4; ++i) map[kpn_scalar_off() + i] = -1;
+        if (hipMalloc((void**)&map_dev, nk * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(map_dev, map.data(), nk * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = KPN_ELAUNCH;
+    }();
+    if (rc != KPN_OK || !map_dev) return fail(KPN_ELAUNCH, "could not build the device pack map");
+    KPN_LAUNCH(k_pack_gather, grid1d((int64_t)nk, 256), dim3(256), stream, plain_dev, (const int32_t*)map_dev, (int)nk, packed_dev);
+    auto woff = [](int layer) { size_t o = 0; for (int l = 0; l < layer; ++l) o += (size_t)plain_dims[l][0] * plain_dims[l][1] + plain_dims[l][0]; return o; };
+    auto boff = [&](int layer) { return woff(layer) + (size_t)plain_dims[layer][0] * plain_dims[layer][1]; };
+    KPN_LAUNCH(k_pack_scalars, dim3(1), dim3(64), stream, plain_dev, woff(P_G2_0), boff(P_G2_0), woff(P_G2_1), boff(P_G2_1),
+               woff(P_G2_2), boff(P_G2_2), np - 1, packed_dev + kpn_scalar_off());
+    return check_launch("kpn_pack_weights_device");
 }
 
 // ---------------------------------------------------------------------------------------------

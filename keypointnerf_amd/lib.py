@@ -60,6 +60,7 @@ _SIGNATURES = {
     "kpn_plain_weight_floats": (c_sz, []),
     "kpn_packed_weight_floats": (c_sz, []),
     "kpn_pack_weights": (ctypes.c_int, [c_p, c_p]),
+    "kpn_pack_weights_device": (ctypes.c_int, [c_p, c_p, c_p]),
     "kpn_scene_workspace_bytes": (c_sz, [ctypes.POINTER(SceneDesc)]),
     "kpn_scene_prepare": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p]),
     "kpn_ray_bbox_intersection": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),

@@ -57,8 +57,18 @@ class PackedWeights:
 
     @classmethod
     def from_plain(cls, plain, device="cuda"):
-        """From the flat effective-parameter vector (weights.flatten_plain / plain_tensor_from_module layout)."""
+        """From the flat effective-parameter vector (weights.flatten_plain / plain_tensor_from_module layout).  A CUDA
+        tensor is packed on the device (kpn_pack_weights_device: no host round trip, asynchronous)."""
         L = kl.get_library()
+        if isinstance(plain, torch.Tensor) and plain.is_cuda:
+            flat = plain.detach().to(_f32).contiguous()
+            if flat.numel() != L.kpn_plain_weight_floats():
+                raise ValueError("unexpected hot-path parameter count")
+            self = cls.__new__(cls)
+            self.tensor = torch.empty(L.kpn_packed_weight_floats(), dtype=_f32, device=flat.device)
+            L.check(L.kpn_pack_weights_device(_p(flat), _p(self.tensor), _stream()))
+            self._plain = flat  # keeps the source alive until the stream has consumed it
+            return self
         flat = np.ascontiguousarray(plain.detach().float().cpu().numpy() if isinstance(plain, torch.Tensor) else plain, dtype=np.float32)
         if flat.size != L.kpn_plain_weight_floats():
             raise ValueError("unexpected hot-path parameter count")

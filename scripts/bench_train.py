@@ -44,9 +44,21 @@ def main():
             fn()
         torch.cuda.synchronize()
         res[name] = (time.perf_counter() - t0) / K
+    # re-packing the weights after an optimizer step (device-side gather; the training drop-in does this every iteration)
+    from keypointnerf_amd.weights import effective_weights, flatten_plain
+    plain = torch.from_numpy(flatten_plain(effective_weights(random_hotpath_state_dict(seed=3)))).to(dev)
+    for _ in range(3):
+        ops.PackedWeights.from_plain(plain)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ops.PackedWeights.from_plain(plain)
+    torch.cuda.synchronize()
+    res["pack"] = (time.perf_counter() - t0) / 20
     tot = res["forward"] + res["backward"]
     print(f"train iteration, field part: {R} rays x ({Sc}+{Sc + Sf}) samples, V=3, alpha_fine mean {float(out['alpha_fine'].mean()):.2f}: "
-          f"forward {res['forward']*1e3:.2f} ms, backward {res['backward']*1e3:.2f} ms, {1.0/tot:.1f} it/s, {R/tot/1e3:.1f} k rays/s")
+          f"forward {res['forward']*1e3:.2f} ms, backward {res['backward']*1e3:.2f} ms, {1.0/tot:.1f} it/s, {R/tot/1e3:.1f} k rays/s; "
+          f"weight re-pack {res['pack']*1e3:.3f} ms")
 
 
 if __name__ == "__main__":

@@ -210,6 +210,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyDeviceToHost 2
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

@@ -437,3 +437,19 @@ def test_backward_multi_pass_and_chunking(ops, golden_weights):
     for i in range(4):
         assert one[i].abs().max() > 0
         assert (one[i] - two[i]).abs().max() <= 2e-4 * one[i].abs().max() + 1e-6, i
+
+
+def test_device_weight_packer(ops, golden_weights):
+    """PackedWeights.from_plain on a CUDA tensor (kpn_pack_weights_device) equals the host packer; a query with the
+    device-packed weights equals one with host-packed weights."""
+    from keypointnerf_amd.weights import effective_weights, flatten_plain
+    sd, w = golden_weights
+    plain = torch.from_numpy(flatten_plain(effective_weights(sd))).cuda()
+    wd = ops.PackedWeights.from_plain(plain)
+    assert (wd.tensor - w.tensor).abs().max() <= 1e-6
+    scene, cfg, g = load_case(CASES[0])
+    s, ps = _prep(ops, scene)
+    pts, view = torch.from_numpy(g["query.0.pts"]).cuda(), torch.from_numpy(g["query.0.view"]).cuda()
+    a, va = ops.query(ps, w, pts, view)
+    b, vb = ops.query(ps, wd, pts, view)
+    assert torch.equal(va, vb) and (a - b).abs().max() <= 1e-6

@@ -345,3 +345,19 @@ def test_query_backward_nothing_valid(env):
     got = sh.query_backward(lib, hs, packed, pts, g["view"][:40], g["G"][:40], mode=1)
     assert all(np.all(x == 0) for x in got)
     assert all(np.all(x == 0) for x in sh.query_backward_geometry(lib, hs, packed, pts, g["G"][:40], mode=1))
+
+
+def test_device_weight_packer(env):
+    """kpn_pack_weights_device (index map taken from the host packer + the scalar kernel) == kpn_pack_weights."""
+    from keypointnerf_amd.synthetic import random_hotpath_state_dict
+    from keypointnerf_amd.weights import effective_weights, flatten_plain
+    lib = env[0]
+    plain = flatten_plain(effective_weights(random_hotpath_state_dict(seed=21)))
+    plain[-1] = -0.37  # negative ani_al: |.| and sign
+    host = np.zeros(lib.kpn_packed_weight_floats(), np.float32)
+    dev = np.full(lib.kpn_packed_weight_floats(), np.nan, np.float32)
+    lib.check(lib.kpn_pack_weights(sh.ptr(plain), sh.ptr(host)))
+    lib.check(lib.kpn_pack_weights_device(sh.ptr(plain), sh.ptr(dev), None))
+    assert np.abs(dev - host).max() <= 1e-6 and np.isfinite(dev).all()
+    nz = host != 0
+    assert np.array_equal(dev[nz][np.abs(host[nz]) > 1e-3] != 0, np.ones((np.abs(host[nz]) > 1e-3).sum(), bool))
