@@ -160,6 +160,14 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
                        float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1, float* d_tex,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Arithmetic of the dominant kernel (MLPUNet.layers1 per (point, view) row):
+ *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands);
+ *   1 = v_mfma_f32_32x32x16_bf16 with every fp32 operand carried as three bf16 pieces and six products per term set
+ *       (all terms above 2^-24 relative: fp32-class results, about twice the matrix rate).
+ * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 0). */
+int kpn_set_geo_rows_mode(int32_t mode);
+int kpn_get_geo_rows_mode(void);
+
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).
  * mode 0: out = [sdf_raw, rad, r,g,b] exactly as query() returns;

@@ -267,6 +267,127 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_geo_rows with split-bf16 operands on v_mfma_f32_32x32x16_bf16 (kpn_mfma16_layer): same rows, same row scratch,
+// fp32-class arithmetic (every product term above 2^-24 relative is kept), about twice the matrix rate.
+__global__ __launch_bounds__(256, 2) void k_geo_rows_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                       int* __restrict__ tickets, float* __restrict__ xscr) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int count = *count_ptr;
+    const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
+    const int nwork = ntiles * sc.V;
+    const float pe_pi = 3.14159274101257324f;
+    __shared__ __attribute__((aligned(16))) float bias_s[4][128];
+    {
+        const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
+        for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
+            const int sg = i >> 7, k = i & 127;
+            bias_s[sg][k] = k < kpn_seg_bfloats(segs[sg]) ? wp[kpn_seg_boff(segs[sg]) + k] : 0.0f;
+        }
+    }
+    __syncthreads();
+    for (;;) {
+        int wi = 0;
+        if (lane == 0) wi = atomicAdd(tickets + 0, 1);
+        wi = __shfl(wi, 0);
+        if (wi >= nwork) break;
+        const int t = wi / sc.V, v = wi - t * sc.V;
+        int ci = t * KPN_TILE + p;
+        if (ci >= count) ci = count - 1;
+        const int64_t n = list[ci];
+        float P[3], D[3];
+        kpn_get_point(ps, n, P, D);
+        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+        const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+        float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
+        if (!((sc.keep >> v) & 1u)) {
+            float4 rec0, rec1;
+            kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[8 * 64] = rec0;
+            dst[9 * 64] = rec1;
+            continue;
+        }
+        // ---- layers1.0 ----
+        kpn_f32x16 a0[4];
+        {
+            const float* E = tb + KPN_TBL_EXT;
+            const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
+            const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
+            const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
+            const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
+            kpn_load_bias<4>(bias_s[0], h, a0);
+            kpn_mfma16_layer<12, 4>(wp + kpn_hseg_off(HSEG_G1_0A), lane, [&](auto gi, float (&x)[8]) {
+                constexpr int j = decltype(gi)::value;
+                const float dx = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
+                const float d2 = KADD(KADD(KMUL(dx, dx), KMUL(dy, dy)), KMUL(dz, dz));
+                const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
+                float s1, c1;
+                kpn_sincos(KMUL(dz, pe_pi), s1, c1);
+                const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
+                const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
+                x[0] = dz * w;
+                x[1] = s1 * w; x[2] = c1 * w;
+                x[3] = s2 * w; x[4] = c2 * w;
+                x[5] = s4 * w; x[6] = c4 * w;
+                x[7] = 0.0f;
+            }, a0);
+            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);
+            const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
+            kpn_mfma16_layer<4, 4>(wp + kpn_hseg_off(HSEG_G1_0B), lane, [&](auto gi, float (&x)[8]) {
+                constexpr int g = decltype(gi)::value;
+                const float4 f0 = kpn_tap4(g0, 64, 32 * h + 8 * g, tp), f1 = kpn_tap4(g0, 64, 32 * h + 8 * g + 4, tp);
+                x[0] = f0.x; x[1] = f0.y; x[2] = f0.z; x[3] = f0.w; x[4] = f1.x; x[5] = f1.y; x[6] = f1.z; x[7] = f1.w;
+            }, a0);
+        }
+        // chained step s of a 128-vector: registers 8(s%2)..+7 of block s/2
+        kpn_f32x16 a1[4];
+        kpn_load_bias<4>(bias_s[1], h, a1);
+        kpn_mfma16_layer<8, 4>(wp + kpn_hseg_off(HSEG_G1_1), lane, [&](auto gi, float (&x)[8]) {
+            constexpr int s = decltype(gi)::value;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a0[s / 2][(s % 2) * 8 + i]);
+        }, a1);
+        kpn_f32x16 a2[4];
+        {
+            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
+            const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
+            kpn_load_bias<4>(bias_s[2], h, a2);
+            kpn_mfma16_layer<9, 4>(wp + kpn_hseg_off(HSEG_G1_2), lane, [&](auto gi, float (&x)[8]) {
+                constexpr int s = decltype(gi)::value;
+                if constexpr (s < 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a1[s / 2][(s % 2) * 8 + i]);
+                } else {
+                    x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w; x[4] = 0.0f; x[5] = 0.0f; x[6] = 0.0f; x[7] = 0.0f;
+                }
+            }, a2);
+        }
+        {
+            kpn_f32x16 acc[2];
+            float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
+            kpn_load_bias<2>(bias_s[3], h, acc);
+            kpn_mfma16_layer<8, 2>(wp + kpn_hseg_off(HSEG_G1_3), lane, [&](auto gi, float (&x)[8]) {
+                constexpr int s = decltype(gi)::value;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a2[s / 2][(s % 2) * 8 + i]);
+                if constexpr (s == 1) kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
+            }, acc);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    dst[(b * 4 + qd) * 64] =
+                        make_float4(acc[b][4 * qd + 0], acc[b][4 * qd + 1], acc[b][4 * qd + 2], acc[b][4 * qd + 3]);
+            dst[8 * 64] = rec0;
+            dst[9 * 64] = rec1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-view inputs of the IBR head for this lane's point (query_color, model.py:806-832), in two steps:
 // the gather (projection, bilinear taps, ray-direction difference: VALU + memory only) and the
 // ray_encoder MLP (MFMA).  With V <= 3 the gathers of all views are issued up front.

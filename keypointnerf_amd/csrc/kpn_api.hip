@@ -3,6 +3,7 @@
 // synchronises or allocates (except kpn_selftest_mfma, a diagnostic).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -107,6 +108,50 @@ template <class RowMap>
 void pack_segment_t(float* packed, int bseg, const float* W, int out_dim, int in_dim, RowMap in_of_row) {
     pack_segment_t(packed, bseg, W, out_dim, in_dim, in_of_row, [](int s, int h) { return chain_feature(s, h); });
 }
+// split-bf16 stream of one layer (kpn_common.h HSEG_*): feat(step, h, e) = input feature of the e-th value the half-h
+// lanes supply in 16-deep K-step `step`, or -1 (pad)
+inline uint16_t host_f2bf(float f) {  // round to nearest even
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float host_bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+// enumerates the elements of one split-bf16 segment: emit(element index within the segment = ((s*NOB+ob)*64+lane)*8+e,
+// plain-layout weight index or -1)
+template <class FMap, class Emit>
+void walk_hsegment(int hseg, size_t w_off, int out_dim, int in_dim, FMap feat, Emit emit) {
+    const int KS = kpn_hseg_shapes[hseg].ks16, NOB = kpn_hseg_shapes[hseg].nob;
+    for (int s = 0; s < KS; ++s)
+        for (int ob = 0; ob < NOB; ++ob)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5, orow = ob * 32 + i;
+                for (int e = 0; e < 8; ++e) {
+                    const int f = feat(s, h, e);
+                    const bool real = orow < out_dim && f >= 0 && f < in_dim;
+                    emit((((size_t)s * NOB + ob) * 64 + lane) * 8 + e, real ? (int64_t)(w_off + (size_t)orow * in_dim + f) : (int64_t)-1);
+                }
+            }
+}
+// the five layers1 segments with their K maps; w_off[layer] = offset of the layer's W in the plain layout
+template <class Emit>
+void walk_hsegments(const size_t (&w_off)[4], Emit emit) {
+    auto chain16 = [](int s, int h, int e) { return 32 * (s / 2) + KPN_ROWMAP(8 * (s % 2) + e, h); };
+    walk_hsegment(HSEG_G1_0A, w_off[0], 128, 232, [](int s, int h, int e) { return e < 7 ? e * 24 + s + 12 * h : -1; },
+                  [&](size_t el, int64_t src) { emit(HSEG_G1_0A, el, src); });
+    walk_hsegment(HSEG_G1_0B, w_off[0], 128, 232, [](int s, int h, int e) { return 168 + 32 * h + 8 * s + e; },
+                  [&](size_t el, int64_t src) { emit(HSEG_G1_0B, el, src); });
+    walk_hsegment(HSEG_G1_1, w_off[1], 128, 128, chain16, [&](size_t el, int64_t src) { emit(HSEG_G1_1, el, src); });
+    walk_hsegment(HSEG_G1_2, w_off[2], 120, 136,
+                  [&](int s, int h, int e) { return s < 8 ? chain16(s, h, e) : (e < 4 ? 128 + 4 * h + e : -1); },
+                  [&](size_t el, int64_t src) { emit(HSEG_G1_2, el, src); });
+    walk_hsegment(HSEG_G1_3, w_off[3], 64, 120, chain16, [&](size_t el, int64_t src) { emit(HSEG_G1_3, el, src); });
+}
+// u16 slot of piece pc of element el of a segment, relative to the packed buffer viewed as uint16
+inline size_t hseg_slot(int hseg, size_t el, int pc) {
+    const int NOB = kpn_hseg_shapes[hseg].nob;
+    const size_t e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, s = el / (512 * (size_t)NOB);
+    return (size_t)kpn_hseg_off(hseg) * 2 + ((((s * 3 + pc) * NOB + ob) * 64 + lane) * 8 + e);
+}
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
 }  // namespace
 
@@ -206,6 +251,19 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r)
                     P[kpn_brow_off(BROW_G2_2_SDF + o) + (2 * b + h) * 16 + r] = pl.w[P_G2_2][o * 64 + 32 * b + KPN_ROWMAP(r, h)];
+    // split-bf16 streams of layers1 (k_geo_rows_h)
+    {
+        size_t w_off[4];
+        for (int l = 0; l < 4; ++l) w_off[l] = (size_t)(pl.w[P_G1_0 + l] - plain_host);
+        uint16_t* P16 = reinterpret_cast<uint16_t*>(P);
+        walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
+            const float w = src >= 0 ? plain_host[src] : 0.0f;
+            const uint16_t ph = host_f2bf(w);
+            const float r1 = w - host_bf2f(ph);
+            const uint16_t pm = host_f2bf(r1);
+            P16[hseg_slot(hseg, el, 0)] = ph; P16[hseg_slot(hseg, el, 1)] = pm; P16[hseg_slot(hseg, el, 2)] = host_f2bf(r1 - host_bf2f(pm));
+        });
+    }
     // scalars: |ani_al| (model.py:1287) and layers2(0), the query() result of a fully masked point
     float* sc = P + kpn_scalar_off();
     sc[0] = fabsf(pl.ani_al);
@@ -231,6 +289,19 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
 // ---------------------------------------------------------------------------------------------
 // device-side packing: the host packer above is a pure gather apart from four derived scalars, so its index map is
 // taken once (by packing a ramp) and applied on the device — a training loop re-packs after every optimizer step
+// split-bf16 region: element t of the concatenated segments -> three bf16 pieces at their slots
+__global__ void k_pack_hseg(const float* __restrict__ plain, const int32_t* __restrict__ src, const int32_t* __restrict__ slot0,
+                            const int32_t* __restrict__ pstride, int n, uint16_t* __restrict__ packed16) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float w = src[t] >= 0 ? plain[src[t]] : 0.0f;
+    float one[8] = {w, 0, 0, 0, 0, 0, 0, 0};
+    kpn_bf16x8 h, m, l;
+    kpn_split3(one, h, m, l);
+    uint16_t ph, pm, plo;
+    { const auto hv = h[0]; const auto mv = m[0]; const auto lv = l[0]; memcpy(&ph, &hv, 2); memcpy(&pm, &mv, 2); memcpy(&plo, &lv, 2); }
+    packed16[slot0[t]] = ph; packed16[slot0[t] + pstride[t]] = pm; packed16[slot0[t] + 2 * pstride[t]] = plo;
+}
 __global__ void k_pack_gather(const float* __restrict__ plain, const int32_t* __restrict__ map, int n, float* __restrict__ packed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -265,6 +336,8 @@ __global__ void k_pack_scalars(const float* __restrict__ plain, size_t w0, size_
 extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev, void* stream) {
     KPN_REQUIRE(plain_dev && packed_dev, "null pointer");
     static int32_t* map_dev = nullptr;
+    static int32_t *hsrc_dev = nullptr, *hslot_dev = nullptr, *hstride_dev = nullptr;
+    static int n_helem = 0;
     static std::mutex mtx;
     static bool built = false;
     static int rc = KPN_OK;
@@ -281,9 +354,27 @@ extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev
         for (int i = 0; i < 4; ++i) map[kpn_scalar_off() + i] = -1;
         if (hipMalloc((void**)&map_dev, nk * sizeof(int32_t)) != hipSuccess ||
             hipMemcpy(map_dev, map.data(), nk * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = KPN_ELAUNCH;
+        // split-bf16 region: per element its source weight, the u16 slot of its first piece and the piece stride
+        std::vector<int32_t> hsrc, hslot, hstride;
+        size_t w_off[4];
+        for (int l = 0; l < 4; ++l) { size_t o = 0; for (int k = 0; k < P_G1_0 + l; ++k) o += (size_t)plain_dims[k][0] * plain_dims[k][1] + plain_dims[k][0]; w_off[l] = o; }
+        walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
+            hsrc.push_back((int32_t)src);
+            hslot.push_back((int32_t)hseg_slot(hseg, el, 0));
+            hstride.push_back((int32_t)(hseg_slot(hseg, el, 1) - hseg_slot(hseg, el, 0)));
+        });
+        n_helem = (int)hsrc.size();
+        auto up = [&](int32_t** d, const std::vector<int32_t>& h) {
+            if (hipMalloc((void**)d, h.size() * sizeof(int32_t)) != hipSuccess ||
+                hipMemcpy(*d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = KPN_ELAUNCH;
+        };
+        up(&hsrc_dev, hsrc); up(&hslot_dev, hslot); up(&hstride_dev, hstride);
     }();
     if (rc != KPN_OK || !map_dev) return fail(KPN_ELAUNCH, "could not build the device pack map");
-    KPN_LAUNCH(k_pack_gather, grid1d((int64_t)nk, 256), dim3(256), stream, plain_dev, (const int32_t*)map_dev, (int)nk, packed_dev);
+    const int n_gather = kpn_bwd_end();  // everything before the split-bf16 region is a gather
+    KPN_LAUNCH(k_pack_gather, grid1d((int64_t)n_gather, 256), dim3(256), stream, plain_dev, (const int32_t*)map_dev, n_gather, packed_dev);
+    KPN_LAUNCH(k_pack_hseg, grid1d((int64_t)n_helem, 256), dim3(256), stream, plain_dev, (const int32_t*)hsrc_dev,
+               (const int32_t*)hslot_dev, (const int32_t*)hstride_dev, n_helem, reinterpret_cast<uint16_t*>(packed_dev));
     auto woff = [](int layer) { size_t o = 0; for (int l = 0; l < layer; ++l) o += (size_t)plain_dims[l][0] * plain_dims[l][1] + plain_dims[l][0]; return o; };
     auto boff = [&](int layer) { return woff(layer) + (size_t)plain_dims[layer][0] * plain_dims[layer][1]; };
     KPN_LAUNCH(k_pack_scalars, dim3(1), dim3(64), stream, plain_dev, woff(P_G2_0), boff(P_G2_0), woff(P_G2_1), boff(P_G2_1),
@@ -439,6 +530,12 @@ struct ProfState {
 static ProfState g_prof;
 #endif
 
+// 0: fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy)
+int g_geo_rows_mode = -1;
+int geo_rows_mode() {
+    if (g_geo_rows_mode < 0) { const char* e = getenv("KPN_GEO_ROWS_MODE"); g_geo_rows_mode = e ? atoi(e) : 0; }
+    return g_geo_rows_mode;
+}
 int fuse_grid_blocks() {
 #ifdef KPN_SIMT_EMU
     return 4;
@@ -460,7 +557,10 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     const bool prof = g_prof.on && g_prof.used < g_prof.cap;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
 #endif
-    KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
+    if (geo_rows_mode() == 1)
+        KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
+    else
+        KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
 #ifndef KPN_SIMT_EMU
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
@@ -476,6 +576,13 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     return check_launch("field query");
 }
 }  // namespace
+
+extern "C" int kpn_set_geo_rows_mode(int32_t mode) {
+    KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
+    g_geo_rows_mode = mode;
+    return KPN_OK;
+}
+extern "C" int kpn_get_geo_rows_mode(void) { return geo_rows_mode(); }
 
 extern "C" size_t kpn_query_workspace_bytes(int64_t N, int32_t V) {
     if (N <= 0 || V <= 0) return 0;

@@ -57,6 +57,45 @@ static inline void kpn_atomic_add(float* p, float v) {
 #endif
 __device__ __forceinline__ float kpn_fast_exp(float x) { return kpn_exp2(x * 1.44269504088896341f); }
 
+// ---- split-bf16 operands for v_mfma_f32_32x32x16_bf16 (k_geo_rows_h) ----
+// An fp32 value x is carried as three bf16 pieces h + m + l (|x - (h+m+l)| <= 2^-24 |x|: the residuals are exact in
+// fp32); a product term set  w*x ~= wh*xh + wh*xm + wm*xh + wm*xm + wh*xl + wl*xh  (everything above 2^-24 relative)
+// is six MFMAs at 16x the fp32-MFMA rate.  Operand layout (verified on the MI355X with asymmetric operands):
+//   A: lane l holds A[i = l&31][k = 8(l>>5) + e], e = 0..7;  B: lane l holds B[k = 8(l>>5) + e][j = l&31];  D as 32x32x2.
+#ifndef KPN_SIMT_EMU
+typedef __bf16 kpn_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void kpn_split3(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 a = (__bf16)x[i];
+        const float r1 = x[i] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        h[i] = a; m[i] = b; l[i] = (__bf16)(r1 - (float)b);
+    }
+}
+__device__ __forceinline__ kpn_bf16x8 kpn_as_bf16x8(kpn_f32x4 v) { return __builtin_bit_cast(kpn_bf16x8, v); }
+#define KPN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#else
+typedef uint16_t kpn_bf16x8 __attribute__((ext_vector_type(8)));
+static inline uint16_t kpn_f2bf(float f) {  // round to nearest even, as v_cvt_pk_bf16_f32
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float kpn_bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline void kpn_split3(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) {
+    for (int i = 0; i < 8; ++i) {
+        const uint16_t a = kpn_f2bf(x[i]);
+        const float r1 = x[i] - kpn_bf2f(a);
+        const uint16_t b = kpn_f2bf(r1);
+        h[i] = a; m[i] = b; l[i] = kpn_f2bf(r1 - kpn_bf2f(b));
+    }
+}
+static inline kpn_bf16x8 kpn_as_bf16x8(kpn_f32x4 v) { kpn_bf16x8 r; memcpy(&r, &v, 16); return r; }
+#define KPN_MFMA16(a, b, c) simt_mfma_f32_32x32x16_bf16((a), (b), (c))
+#endif
+
 #define KPN_NKPT 24
 #define KPN_MAXV 16
 #define KPN_WAVE 64
@@ -163,7 +202,24 @@ constexpr int kpn_bseg_woff(int seg) {
 // [2 blocks][2 halves][16 regs]: d in[32b + rowmap(r,h)] = row[(2b+h)*16 + r] * d out   (a rank-1 VALU update)
 enum { BROW_G2_2_SDF, BROW_G2_2_RAD, BROW_COUNT };  // layers2.2 rows 0 (sdf_raw) and 1 (rad)
 constexpr int kpn_brow_off(int row) { return kpn_bseg_woff(BSEG_COUNT) + row * 64; }
-constexpr int kpn_packed_floats() { return kpn_brow_off(BROW_COUNT); }
+constexpr int kpn_bwd_end() { return kpn_brow_off(BROW_COUNT); }
+// Split-bf16 segments of layers1 (k_geo_rows_h), after the backward region.  K runs in steps of 16: the h = 0 lanes of
+// the B operand supply 8 values, the h = 1 lanes 8 — for chained inputs a lane's registers 8j..8j+7 of block b (step
+// 2b + j), i.e. features 32b + rowmap(8j + e, h).  Stream per step: [piece h,m,l][ob][64 lanes] x 16 B (8 bf16 =
+// A[i = lane&31][k = 8(lane>>5) + e]); the fp32 bias blocks of the forward segments are reused.
+//   HSEG_G1_0A: step j = keypoints j (h=0) and j+12 (h=1): 7 encoding values + 1 pad;  HSEG_G1_0B: 8 geometry channels per half
+//   HSEG_G1_2 : 8 chained steps + 1 step with the 4+4 hd channels (+ pads)
+enum { HSEG_G1_0A, HSEG_G1_0B, HSEG_G1_1, HSEG_G1_2, HSEG_G1_3, HSEG_COUNT };
+struct kpn_hseg_shape { int ks16, nob; };
+#define KPN_HSEG_SHAPES {12, 4}, {4, 4}, {8, 4}, {9, 4}, {8, 2}
+static constexpr kpn_hseg_shape kpn_hseg_shapes[HSEG_COUNT] = {KPN_HSEG_SHAPES};
+constexpr int kpn_hseg_step_floats(int seg) { return 3 * kpn_hseg_shapes[seg].nob * 64 * 4; }
+constexpr int kpn_hseg_off(int seg) {
+    int o = kpn_bwd_end();
+    for (int i = 0; i < seg; ++i) o += kpn_hseg_shapes[i].ks16 * kpn_hseg_step_floats(i);
+    return o;
+}
+constexpr int kpn_packed_floats() { return kpn_hseg_off(HSEG_COUNT); }
 
 // Row scratch written by k_geo_rows and read by k_fuse_color: per work item (tile, view) KPN_ROW_SLABS
 // slabs of [64 lanes] float4.  Slabs 0..7: the lane's 32 registers of the 64-vector (block b = slab/4);

@@ -240,6 +240,94 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
     }, acc);
 }
 
+// One Linear layer on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (kpn_common.h HSEG_*): KS16 steps of 16 k.
+// in_fn(kpn_ic<s>, float (&x)[8]) produces the 8 fp32 values this lane supplies in step s; they are split into three
+// bf16 pieces on the fly; the weights arrive pre-split.  Six products per (step, output block) keep every term above
+// 2^-24 relative: fp32-class accuracy at (measured, clean loop) about twice the fp32-MFMA rate.
+#ifndef KPN_GUARD_NOPS
+#define KPN_GUARD_NOPS "s_nop 7"
+#endif
+__device__ __forceinline__ void kpn_mfma16_guard(kpn_f32x16& acc0, kpn_f32x16& acc1, const kpn_bf16x8& a0, const kpn_bf16x8& a1,
+                                                 const kpn_bf16x8& a2, const kpn_bf16x8& a3, const kpn_bf16x8& a4, const kpn_bf16x8& a5,
+                                                 const kpn_bf16x8& b0, const kpn_bf16x8& b1, const kpn_bf16x8& b2) {
+#ifndef KPN_SIMT_EMU
+    asm volatile(KPN_GUARD_NOPS : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(b0), "v"(b1), "v"(b2));
+#else
+    (void)acc0; (void)acc1; (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5; (void)b0; (void)b1; (void)b2;
+#endif
+}
+template <int KS16, int NOB, class InFn>
+__device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
+    // software pipeline: the B pieces of step s+1 are produced (VALU: activation + split) while the MFMAs of step s
+    // issue; the A pieces are fetched in two halves of the output blocks so that the loads of one half fly while the
+    // other half's MFMAs issue (a full double buffer of 3*NOB dwordx4 does not fit the register file)
+    static_assert(NOB <= 4, "two halves of at most two output blocks");
+    constexpr int H0 = (NOB + 1) / 2, H1 = NOB - H0;
+    kpn_bf16x8 xp[2][3];
+    kpn_bf16x8 wa[3][H0], wb[3][H1 > 0 ? H1 : 1];
+    auto load_half = [&](int s, int ob0, int n, auto& w) {
+        const float* gp = hseg + (size_t)s * (3 * NOB * 64 * 4);
+        KPN_PIN_POINTER(gp);
+        const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int k = 0; k < n; ++k) w[pc][k] = kpn_as_bf16x8(src[(pc * NOB + ob0 + k) * 64]);
+    };
+    auto mfma_half = [&](int ob0, int n, const auto& w, const kpn_bf16x8 (&x)[3]) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            acc[ob0 + k] = KPN_MFMA16(w[0][k], x[0], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[0][k], x[1], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[1][k], x[0], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[1][k], x[1], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[0][k], x[2], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[2][k], x[0], acc[ob0 + k]);
+        }
+    };
+    // The guard keeps a half's A and B operand registers live up to its last MFMA and then idles 8 cycles before any of
+    // them can be recycled (the compiler otherwise lets a VALU instruction overwrite a 4-VGPR MFMA source in the very
+    // next issue slot; cheap insurance: 16 of ~770 cycles per step).
+    auto guard_half = [&](int ob0, auto nn, const auto& w, const kpn_bf16x8 (&x)[3]) {
+        if constexpr (decltype(nn)::value == 2)
+            kpn_mfma16_guard(acc[ob0], acc[ob0 + 1], w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
+        else
+            kpn_mfma16_guard(acc[ob0], acc[ob0], w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0], x[0], x[1], x[2]);
+    };
+    {
+        float x[8];
+        in_fn(kpn_ic<0>{}, x);
+        kpn_split3(x, xp[0][0], xp[0][1], xp[0][2]);
+    }
+    load_half(0, 0, H0, wa);
+    if constexpr (H1 > 0) load_half(0, H0, H1, wb);
+    kpn_static_for<0, KS16>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int cur = s & 1, nxt = cur ^ 1;
+        if constexpr (s + 1 < KS16) {
+            float x[8];
+            in_fn(kpn_ic<s + 1>{}, x);
+            kpn_split3(x, xp[nxt][0], xp[nxt][1], xp[nxt][2]);
+        }
+        // Phase separation.  With the activation / split VALU code of step s+1 interleaved among the MFMAs of step s
+        // (what the scheduler does when left alone) this kernel produced NONDETERMINISTIC, wrong tiles on the MI355X
+        // whenever two waves shared a SIMD (hipcc 7.2; one wave per SIMD, or the phases kept apart as here, is
+        // bit-reproducible and within 5e-5 of the fp32 kernel on sigma ~ 40).  The cause was not found — not an
+        // operand-read WAR hazard (192 cycles of s_nop after each half did not help); see DESIGN.md section 9.
+        // The other wave of the SIMD fills the matrix pipe during this wave's VALU phase.
+        KPN_SCHED_BARRIER();
+        mfma_half(0, H0, wa, xp[cur]);
+        guard_half(0, kpn_ic<H0>{}, wa, xp[cur]);
+        if constexpr (s + 1 < KS16) load_half(s + 1, 0, H0, wa);
+        if constexpr (H1 > 0) {
+            mfma_half(H0, H1, wb, xp[cur]);
+            guard_half(H0, kpn_ic<H1>{}, wb, xp[cur]);
+            if constexpr (s + 1 < KS16) load_half(s + 1, H0, H1, wb);
+        }
+        KPN_SCHED_BARRIER();
+    });
+}
+
 // A single-output Linear over a lane's 16 chained features: both halves of a point add their partial
 // dot products (lanes p and p+32) and every lane gets  W[row,:].x + b.
 __device__ __forceinline__ float kpn_row_dot(const float* __restrict__ rowvec, int h, const float (&x)[16]) {

@@ -445,6 +445,17 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
     return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2), d_tx.permute(0, 3, 1, 2)
 
 
+def set_geo_rows_mode(mode):
+    """Arithmetic of the dominant kernel (kpn_set_geo_rows_mode): 0 = fp32 MFMA (default), 1 = split-bf16 operands on
+    the bf16 MFMA (three bf16 pieces per fp32 operand, six products: fp32-class results, faster).  Process-wide."""
+    L = kl.get_library()
+    L.check(L.kpn_set_geo_rows_mode(int(mode)))
+
+
+def get_geo_rows_mode():
+    return int(kl.get_library().kpn_get_geo_rows_mode())
+
+
 def frame_to_rgb8(img, bgr=False):
     """(3,H,W) or (1,3,H,W) fp32 -> (H,W,3) uint8 on the device: clamp to [0,1] (_arrange_nerf_images, reference
     src/model.py:427-430), x255 and truncate (`.astype(np.uint8)`, :496), optional B,G,R order for cv2.imwrite (:222)."""

@@ -60,6 +60,7 @@ struct Fiber {
     unsigned tid = 0;
 };
 struct WaveShared {
+    float a8[WAVE][8], b8[WAVE][8];
     float a[WAVE], b[WAVE];
     uint32_t u[WAVE];
     unsigned arrived = 0, gen = 0;
@@ -168,6 +169,28 @@ static inline kpn_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
         int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = std::fmaf(w.a[i], w.b[j], c[r]);         // k = 0
         acc = std::fmaf(w.a[i + 32], w.b[j + 32], acc);      // k = 1
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
+}
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8(l>>5)+e], B[k=8(l>>5)+e][j=l&31], D as the 32x32x2 form; bf16 carried as uint16
+typedef uint16_t simt_bf16x8 __attribute__((ext_vector_type(8)));
+static inline kpn_f32x16 simt_mfma_f32_32x32x16_bf16(simt_bf16x8 a, simt_bf16x8 b, kpn_f32x16 c) {
+    auto& w = simt::wave_shared();
+    int l = simt::lane_id();
+    for (int e = 0; e < 8; ++e) {
+        uint32_t ua = (uint32_t)a[e] << 16, ub = (uint32_t)b[e] << 16;
+        memcpy(&w.a8[l][e], &ua, 4); memcpy(&w.b8[l][e], &ub, 4);
+    }
+    simt::wave_sync();
+    kpn_f32x16 d;
+    int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kh = 0; kh < 2; ++kh)
+            for (int e = 0; e < 8; ++e) acc = std::fmaf(w.a8[i + 32 * kh][e], w.b8[j + 32 * kh][e], acc);
         d[r] = acc;
     }
     simt::wave_sync();

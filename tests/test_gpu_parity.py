@@ -453,3 +453,43 @@ def test_device_weight_packer(ops, golden_weights):
     a, va = ops.query(ps, w, pts, view)
     b, vb = ops.query(ps, wd, pts, view)
     assert torch.equal(va, vb) and (a - b).abs().max() <= 1e-6
+
+
+def test_split_bf16_mode(ops, golden_weights):
+    """kpn_set_geo_rows_mode(1): the dominant kernel on the bf16 MFMA with split operands.  Same parity bar against the
+    reference goldens (query and rendered images), bit-reproducible run to run at two waves per SIMD (an earlier
+    schedule of this kernel was not: see kpn_mfma16_layer), and fp32-class against mode 0."""
+    sd, w = golden_weights
+    try:
+        ops.set_geo_rows_mode(1)
+        assert ops.get_geo_rows_mode() == 1
+        for case in CASES:
+            scene, cfg, g = load_case(case)
+            s, ps = _prep(ops, scene)
+            out, valid = ops.query(ps, w, torch.from_numpy(g["query.0.pts"]).cuda(), torch.from_numpy(g["query.0.view"]).cuda())
+            v = g["query.0.valid"][0].reshape(-1)
+            assert (valid.cpu().numpy() == g["query.0.valid"]).all()
+            assert np.abs(out.cpu().numpy()[0] - g["query.0.out"][0])[v].max() < 2e-5
+            pix, (ny, nx) = pixel_list(cfg, scene["cam_tar"])
+            step = 2 ** (cfg["level"] - 1)
+            res = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny),
+                                  n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+            for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+                assert np.abs(res[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, (case, k)
+        from keypointnerf_amd.synthetic import make_scene
+        big = make_scene(n_views=3, src_hw=(256, 256), tar_hw=(64, 64), mask="dense", seed=1)
+        sb, pb = _prep(ops, big)
+        N = 400_000
+        gen = torch.Generator(device="cuda").manual_seed(4)
+        lo, hi = sb["bounds"].reshape(2, 3)[0], sb["bounds"].reshape(2, 3)[1]
+        P = (lo + (hi - lo) * (0.2 + 0.6 * torch.rand(N, 3, device="cuda", generator=gen)))[None]
+        V = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=gen), dim=-1)[None]
+        runs = [ops.query(pb, w, P, V, mode=1)[0].clone() for _ in range(6)]
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0])
+        ops.set_geo_rows_mode(0)
+        ref = ops.query(pb, w, P, V, mode=1)[0]
+        scale = ref.abs().amax(dim=(0, 1))
+        assert ((runs[0] - ref).abs().amax(dim=(0, 1)) <= 2e-5 * scale + 1e-6).all()
+    finally:
+        ops.set_geo_rows_mode(0)

@@ -361,3 +361,25 @@ def test_device_weight_packer(env):
     assert np.abs(dev - host).max() <= 1e-6 and np.isfinite(dev).all()
     nz = host != 0
     assert np.array_equal(dev[nz][np.abs(host[nz]) > 1e-3] != 0, np.ones((np.abs(host[nz]) > 1e-3).sum(), bool))
+
+
+def test_split_bf16_geo_rows(env):
+    """k_geo_rows_h (split-bf16 operands on the emulated v_mfma_f32_32x32x16_bf16) vs the reference's recorded query
+    outputs and vs the fp32-MFMA kernel: fp32-class (three bf16 pieces, six products)."""
+    lib, packed, wflat = env
+    scene, cfg, g = load_case(CASES[0])
+    hs = sh.HostScene(lib, scene)
+    valid = g["query.0.valid"][0].reshape(-1)
+    idx = np.concatenate([np.where(valid)[0][:700], np.where(~valid)[0][:60]])
+    pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
+    try:
+        lib.check(lib.kpn_set_geo_rows_mode(1))
+        assert lib.kpn_get_geo_rows_mode() == 1
+        o1, v1 = sh.query(lib, hs, packed, pts, view)
+    finally:
+        lib.check(lib.kpn_set_geo_rows_mode(0))
+    o0, v0 = sh.query(lib, hs, packed, pts, view)
+    assert np.array_equal(v0, v1) and v1.sum() == 700
+    assert np.abs(o1 - ref)[v1].max() < 1e-5
+    assert np.abs(o1 - o0)[v1].max() < 5e-6
+    assert lib.kpn_set_geo_rows_mode(2) != 0
