@@ -247,6 +247,19 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
 #ifndef KPN_GUARD_NOPS
 #define KPN_GUARD_NOPS "s_nop 7"
 #endif
+// Explicit arrival of a half's weight registers ("s_waitcnt vmcnt(0)" tied to them) before its MFMAs: belt and braces
+// next to the compiler's own waitcnt insertion (see the note on phase separation in kpn_mfma16_layer).
+__device__ __forceinline__ void kpn_mfma16_arrive(kpn_bf16x8& a0, kpn_bf16x8& a1, kpn_bf16x8& a2, kpn_bf16x8& a3, kpn_bf16x8& a4,
+                                                  kpn_bf16x8& a5) {
+#ifndef KPN_SIMT_EMU
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+#else
+    (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5;
+#endif
+}
+#ifndef KPN_GUARD_NOPS
+#define KPN_GUARD_NOPS "s_nop 7"
+#endif
 __device__ __forceinline__ void kpn_mfma16_guard(kpn_f32x16& acc0, kpn_f32x16& acc1, const kpn_bf16x8& a0, const kpn_bf16x8& a1,
                                                  const kpn_bf16x8& a2, const kpn_bf16x8& a3, const kpn_bf16x8& a4, const kpn_bf16x8& a5,
                                                  const kpn_bf16x8& b0, const kpn_bf16x8& b1, const kpn_bf16x8& b2) {
@@ -256,7 +269,7 @@ __device__ __forceinline__ void kpn_mfma16_guard(kpn_f32x16& acc0, kpn_f32x16& a
     (void)acc0; (void)acc1; (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5; (void)b0; (void)b1; (void)b2;
 #endif
 }
-template <int KS16, int NOB, class InFn>
+template <int KS16, int NOB, bool SEPARATE = true, class InFn>
 __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
     // software pipeline: the B pieces of step s+1 are produced (VALU: activation + split) while the MFMAs of step s
     // issue; the A pieces are fetched in two halves of the output blocks so that the loads of one half fly while the
@@ -274,7 +287,7 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
 #pragma unroll
             for (int k = 0; k < n; ++k) w[pc][k] = kpn_as_bf16x8(src[(pc * NOB + ob0 + k) * 64]);
     };
-    auto mfma_half = [&](int ob0, int n, const auto& w, const kpn_bf16x8 (&x)[3]) {
+    auto mfma_half = [&](int ob0, int n, auto& w, const kpn_bf16x8 (&x)[3]) {
 #pragma unroll
         for (int k = 0; k < n; ++k) {
             acc[ob0 + k] = KPN_MFMA16(w[0][k], x[0], acc[ob0 + k]);
@@ -288,6 +301,10 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
     // The guard keeps a half's A and B operand registers live up to its last MFMA and then idles 8 cycles before any of
     // them can be recycled (the compiler otherwise lets a VALU instruction overwrite a 4-VGPR MFMA source in the very
     // next issue slot; cheap insurance: 16 of ~770 cycles per step).
+    auto arrive_half = [&](auto nn, auto& w) {
+        if constexpr (decltype(nn)::value == 2) kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1]);
+        else kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0]);
+    };
     auto guard_half = [&](int ob0, auto nn, const auto& w, const kpn_bf16x8 (&x)[3]) {
         if constexpr (decltype(nn)::value == 2)
             kpn_mfma16_guard(acc[ob0], acc[ob0 + 1], w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
@@ -310,21 +327,24 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
             kpn_split3(x, xp[nxt][0], xp[nxt][1], xp[nxt][2]);
         }
         // Phase separation.  With the activation / split VALU code of step s+1 interleaved among the MFMAs of step s
-        // (what the scheduler does when left alone) this kernel produced NONDETERMINISTIC, wrong tiles on the MI355X
-        // whenever two waves shared a SIMD (hipcc 7.2; one wave per SIMD, or the phases kept apart as here, is
-        // bit-reproducible and within 5e-5 of the fp32 kernel on sigma ~ 40).  The cause was not found — not an
-        // operand-read WAR hazard (192 cycles of s_nop after each half did not help); see DESIGN.md section 9.
-        // The other wave of the SIMD fills the matrix pipe during this wave's VALU phase.
-        KPN_SCHED_BARRIER();
+        // in EVERY layer (what the scheduler does when left alone: one scheduling region per tile) this kernel
+        // produced NONDETERMINISTIC, wrong tiles on the MI355X whenever two waves shared a SIMD (hipcc 7.2; ~0.1 % of
+        // the points per run).  One wave per SIMD, interleaving in any single layer, or the phases kept apart as here
+        // are bit-reproducible and within 5e-5 of the fp32 kernel on sigma ~ 40.  Not an operand-read WAR hazard
+        // (192 idle cycles after each half did not help); explicit vmcnt(0) arrivals reduced but did not remove it;
+        // cause not found.  The other wave of the SIMD fills the matrix pipe meanwhile.
+        if constexpr (SEPARATE) KPN_SCHED_BARRIER();
+        arrive_half(kpn_ic<H0>{}, wa);
         mfma_half(0, H0, wa, xp[cur]);
         guard_half(0, kpn_ic<H0>{}, wa, xp[cur]);
         if constexpr (s + 1 < KS16) load_half(s + 1, 0, H0, wa);
         if constexpr (H1 > 0) {
+            arrive_half(kpn_ic<H1>{}, wb);
             mfma_half(H0, H1, wb, xp[cur]);
             guard_half(H0, kpn_ic<H1>{}, wb, xp[cur]);
             if constexpr (s + 1 < KS16) load_half(s + 1, H0, H1, wb);
         }
-        KPN_SCHED_BARRIER();
+        if constexpr (SEPARATE) KPN_SCHED_BARRIER();
     });
 }
 
