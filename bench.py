@@ -28,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# --geo-rows-mode 1: six bf16 MFMAs (2.5 PFLOP/s dense peak) per fp32 product term set -> fp32-equivalent roof
+BF16_SPLIT_PEAK_TFLOPS = 2500.0 / 6.0
 
 
 def parse():
@@ -41,6 +43,8 @@ def parse():
     ap.add_argument("--mask", default="ellipsoid", choices=["ellipsoid", "dense"])
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
+    ap.add_argument("--geo-rows-mode", type=int, default=0, choices=[0, 1],
+                    help="0 = fp32 MFMA (default); 1 = split-bf16 operands on the bf16 MFMA (opt-in, fp32-class results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo + all ranks on cuda:0 only to exercise the N>1 flow on a 1-GPU box")
@@ -102,6 +106,7 @@ def main():
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
 
     L = kl.get_library()
+    L.check(L.kpn_set_geo_rows_mode(args.geo_rows_mode))
     sd = random_hotpath_state_dict(seed=3)
     res = args.res
     scene_cpu = make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), mask=args.mask, seed=1)
@@ -162,11 +167,13 @@ def main():
         if os.path.exists(tj) and launches.value > 0:
             traffic = json.load(open(tj))["hbm_bytes_per_row"] * rows.value / launches.value
         alpha_mean = float(out["alpha_fine" if fine else "alpha"].mean())
+        peak = BF16_SPLIT_PEAK_TFLOPS if args.geo_rows_mode == 1 else FP32_MFMA_PEAK_TFLOPS
         line = {
             "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray = {evals_per_ray} field evaluations/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.geo_rows_mode == 0 else "f32 (three bf16 pieces per operand, bf16 MFMA)",
+            "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if (fine and args.views == 3 and args.samples == 64 and res == 512) else 'custom'}: "
                                    f"{res}x{res} novel view, {args.views} source views {res}x{res}, "
                                    f"{args.samples} coarse" + (f" + {args.samples} fine" if fine else "") + f" samples/ray, {args.mask} fg mask, "
@@ -175,8 +182,8 @@ def main():
                        "sampled_points_per_sec": value * evals_per_ray,
                        "valid_rows_per_step": rows.value / max(1, args.steps),
                        "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},
-            "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"kernel": "k_geo_rows" if args.geo_rows_mode == 0 else "k_geo_rows_h", "bound": "mfma", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "algorithmic_flop_per_row": flops_row,
