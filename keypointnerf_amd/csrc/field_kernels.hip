@@ -44,7 +44,11 @@ __device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, f
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_points ps, int64_t N, int mode,
+// lean != 0 (the render passes): the colour of a masked point is never looked at — its density is exactly 0, so it
+// contributes 0 * rgb to the composited ray — hence the projection loop stops at the first view that rejects the point
+// and the masked result carries rgb = 0.  lean == 0 (kpn_query): the reference's full result, incl. the plain average of
+// the sampled source colours.
+__global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_points ps, int64_t N, int mode, int lean,
                                                       const float* __restrict__ wscalars, float* __restrict__ out,
                                                       uint8_t* __restrict__ valid, int* __restrict__ list,
                                                       int* __restrict__ count) {
@@ -62,9 +66,11 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
             const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
             const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
             all_in &= q.in;
+            if (lean && !all_in) break;
             const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
             const float4 s = kpn_tap4(sc.rgbm + (size_t)v * HW * 4, 4, 0, tp);
             if (!sc.disable_fg_mask) all_fg &= (s.w > 0.1f);  // model.py:737-739
+            if (lean && !all_fg) break;
             acc[0] = KADD(acc[0], KMUL(s.x, pu)); acc[1] = KADD(acc[1], KMUL(s.y, pu)); acc[2] = KADD(acc[2], KMUL(s.z, pu));
         }
         // a_v = in_v * all(fg) * all(in) * dropout_v (model.py:739,748); valid = sum_v a_v > 0 (utils.py:643-646)
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
             float* o = out + n * 5;
             if (mode == 1) { o[0] = 0.0f; o[1] = 0.1f / sc.nml_scale; }  // eval_func, model.py:981-996
             else { o[0] = wscalars[1]; o[1] = wscalars[2]; }
-            o[2] = acc[0]; o[3] = acc[1]; o[4] = acc[2];
+            o[2] = lean ? 0.0f : acc[0]; o[3] = lean ? 0.0f : acc[1]; o[4] = lean ? 0.0f : acc[2];
         }
     }
     const unsigned long long m = __ballot(is_valid);

@@ -544,14 +544,14 @@ int fuse_grid_blocks() {
 #endif
 }
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
-              uint8_t* valid, void* ws, void* stream) {
+              uint8_t* valid, void* ws, void* stream, int lean = 0) {
     const QueryLayout L = query_layout(N, sc.V);
     char* base = static_cast<char*>(ws);
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
     hipMemsetAsync(count, 0, 4 * sizeof(int), (hipStream_t)stream);  // [0] valid count, [1] k_geo_rows tickets, [2] k_fuse_color tickets
-    KPN_LAUNCH(k_mask_compact, grid1d(N, 256), dim3(256), stream, sc, ps, N, mode, wp + kpn_scalar_off(), out, valid, list, count);
+    KPN_LAUNCH(k_mask_compact, grid1d(N, 256), dim3(256), stream, sc, ps, N, mode, lean, wp + kpn_scalar_off(), out, valid, list, count);
     const int blocks = field_grid_blocks();
 #ifndef KPN_SIMT_EMU
     const bool prof = g_prof.on && g_prof.used < g_prof.cap;
@@ -765,7 +765,7 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
             list = reinterpret_cast<int*>(qb + Q.list);
             xscr = reinterpret_cast<float*>(qb + Q.xscr);
         } else {
-            KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, wp + kpn_scalar_off(), (float*)nullptr,
+            KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, 1, wp + kpn_scalar_off(), (float*)nullptr,
                        (uint8_t*)nullptr, list, count);
         }
         KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, vcount, V, rows_dev);
@@ -963,7 +963,7 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
         kpn_points ps{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc,
                       (t && t->rand_noise_std != 0.0f) ? t->noise_coarse + r0 * Sc : nullptr, t ? t->rand_noise_std : 0.0f};
         sc.keep = t ? t->keep_coarse : 0xFFFFFFFFu;
-        if (int e = run_field(sc, ps, wp, n * Sc, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;   // model.py:1062
+        if (int e = run_field(sc, ps, wp, n * Sc, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;   // model.py:1062
         if (int e = kpn_rgba2out(F(L.rgba), F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
@@ -977,7 +977,7 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
             kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
                           (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
             sc.keep = t ? t->keep_fine : 0xFFFFFFFFu;
-            if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream)) return e;  // :1082
+            if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;  // :1082
             if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);
             if (a->depth_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth_fine);
@@ -1075,7 +1075,7 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
                    (const float*)(F(L.farv) + r0), t->u_coarse + r0 * Sc, F(L.zc));
         kpn_points pc{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc, std_ != 0.0f ? t->noise_coarse + r0 * Sc : nullptr, std_};
         sc.keep = t->keep_coarse;
-        if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream)) return e;
+        if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream, 1)) return e;
         if (int e = kpn_rgba2out(F(L.rgba_c), F(L.zc), n, Sc, sc4, sc4 + 3 * n, sc4 + 4 * n, F(L.contrib), sc4 + 5 * n, stream)) return e;
         // ---- coarse pass reverse (before the fine forward overwrites the query workspace whose valid list and row
         //      scratch it reuses); sample positions carry no gradient (model.py:1038,1118) ----
@@ -1095,7 +1095,7 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
                        (const float*)F(L.contrib), t->u_fine + r0 * Sf, F(L.zf));
         kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
         sc.keep = t->keep_fine;
-        if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream)) return e;
+        if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream, 1)) return e;
         KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg_fine, F(L.g3));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth_fine, F(L.g1a));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha_fine, F(L.g1b));
