@@ -247,6 +247,36 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
 #ifndef KPN_GUARD_NOPS
 #define KPN_GUARD_NOPS "s_nop 7"
 #endif
+// hipcc 7.2 under-protects v_mfma_f32_32x32x16_bf16: the software wait states it inserts between the instruction and
+// its neighbours are too few on the MI355X when two waves share a SIMD.  Established by experiment (scripts/
+// soak_determinism.py): (1) with the accumulators read by VALU code right after a layer's last MFMAs, about one tile in
+// 10^5 came out wrong, nondeterministically — an idle tail of 64 cycles before the accumulators are touched removes
+// it completely (result RAW); (2) with the scheduler free to interleave the activation / split VALU code among the
+// MFMAs, ~0.1 % of the points were wrong even with that tail (VALU-written operand registers feeding the next MFMAs,
+// dead operand registers recycled by a VALU write in the next slot).  kpn_mfma16_layer therefore fences every such
+// boundary by hand: phases kept apart by scheduling barriers, an arrival statement before the MFMAs (weights landed,
+// a few idle cycles after the last operand write), a guard after them (operands stay live, 8 idle cycles), and the tail.
+__device__ __forceinline__ void kpn_mfma16_arrive(kpn_bf16x8& a0, kpn_bf16x8& a1, kpn_bf16x8& a2, kpn_bf16x8& a3, kpn_bf16x8& a4,
+                                                  kpn_bf16x8& a5, kpn_bf16x8& b0, kpn_bf16x8& b1, kpn_bf16x8& b2) {
+#ifndef KPN_SIMT_EMU
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(b0), "+v"(b1), "+v"(b2));
+#else
+    (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5; (void)b0; (void)b1; (void)b2;
+#endif
+}
+// idle tail after a layer's last MFMAs, before anything reads the accumulators
+template <int NOB>
+__device__ __forceinline__ void kpn_mfma16_tail(kpn_f32x16 (&acc)[NOB]) {
+#ifndef KPN_SIMT_EMU
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[ob]));
+#else
+    (void)acc;
+#endif
+}
+#ifndef KPN_GUARD_NOPS
+#define KPN_GUARD_NOPS "s_nop 7"
+#endif
 // Explicit arrival of a half's weight registers ("s_waitcnt vmcnt(0)" tied to them) before its MFMAs: belt and braces
 // next to the compiler's own waitcnt insertion (see the note on phase separation in kpn_mfma16_layer).
 __device__ __forceinline__ void kpn_mfma16_arrive(kpn_bf16x8& a0, kpn_bf16x8& a1, kpn_bf16x8& a2, kpn_bf16x8& a3, kpn_bf16x8& a4,
@@ -301,9 +331,9 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
     // The guard keeps a half's A and B operand registers live up to its last MFMA and then idles 8 cycles before any of
     // them can be recycled (the compiler otherwise lets a VALU instruction overwrite a 4-VGPR MFMA source in the very
     // next issue slot; cheap insurance: 16 of ~770 cycles per step).
-    auto arrive_half = [&](auto nn, auto& w) {
-        if constexpr (decltype(nn)::value == 2) kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1]);
-        else kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0]);
+    auto arrive_half = [&](auto nn, auto& w, kpn_bf16x8 (&x)[3]) {
+        if constexpr (decltype(nn)::value == 2) kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
+        else kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0], x[0], x[1], x[2]);
     };
     auto guard_half = [&](int ob0, auto nn, const auto& w, const kpn_bf16x8 (&x)[3]) {
         if constexpr (decltype(nn)::value == 2)
@@ -326,26 +356,22 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
             in_fn(kpn_ic<s + 1>{}, x);
             kpn_split3(x, xp[nxt][0], xp[nxt][1], xp[nxt][2]);
         }
-        // Phase separation.  With the activation / split VALU code of step s+1 interleaved among the MFMAs of step s
-        // in EVERY layer (what the scheduler does when left alone: one scheduling region per tile) this kernel
-        // produced NONDETERMINISTIC, wrong tiles on the MI355X whenever two waves shared a SIMD (hipcc 7.2; ~0.1 % of
-        // the points per run).  One wave per SIMD, interleaving in any single layer, or the phases kept apart as here
-        // are bit-reproducible and within 5e-5 of the fp32 kernel on sigma ~ 40.  Not an operand-read WAR hazard
-        // (192 idle cycles after each half did not help); explicit vmcnt(0) arrivals reduced but did not remove it;
-        // cause not found.  The other wave of the SIMD fills the matrix pipe meanwhile.
+        // VALU phase (above) and MFMA phase (below) are kept apart: see the note at kpn_mfma16_arrive.  The other wave
+        // of the SIMD fills the matrix pipe meanwhile.
         if constexpr (SEPARATE) KPN_SCHED_BARRIER();
-        arrive_half(kpn_ic<H0>{}, wa);
+        arrive_half(kpn_ic<H0>{}, wa, xp[cur]);
         mfma_half(0, H0, wa, xp[cur]);
         guard_half(0, kpn_ic<H0>{}, wa, xp[cur]);
         if constexpr (s + 1 < KS16) load_half(s + 1, 0, H0, wa);
         if constexpr (H1 > 0) {
-            arrive_half(kpn_ic<H1>{}, wb);
+            arrive_half(kpn_ic<H1>{}, wb, xp[cur]);
             mfma_half(H0, H1, wb, xp[cur]);
             guard_half(H0, kpn_ic<H1>{}, wb, xp[cur]);
             if constexpr (s + 1 < KS16) load_half(s + 1, H0, H1, wb);
         }
         if constexpr (SEPARATE) KPN_SCHED_BARRIER();
     });
+    kpn_mfma16_tail<NOB>(acc);
 }
 
 // A single-output Linear over a lane's 16 chained features: both halves of a point add their partial
