@@ -149,7 +149,7 @@ int kpn_query_backward_geometry(const kpn_scene_desc* desc, const void* scene_ws
                                 float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of the WHOLE field evaluation, colour head included (<= 3 source views): everything above plus
+/* Backward of the WHOLE field evaluation, colour head included: everything above plus
  * ibr_compress_gfeat, IBRRenderingHead (src/model.py:784-843, 1267-1302: ray_encoder, the ani_al blend weights,
  * weighted mean/var over views, base / vis / out layers, softmax blend of the source colours) and the feat_tex gather.
  * view (N,3): the query rays' directions.  d_out (N,5): all five columns are propagated.
@@ -248,7 +248,7 @@ int kpn_render_rays_train(const kpn_scene_desc* desc, const void* scene_ws, cons
  * gradients of every hot-path parameter (d_plain, flat layout of kpn_pack_weights' input, raw ani_al last) and of the
  * three feature maps (channels-last, like kpn_query_backward).  Same `args` / `train` as the forward call (outputs in
  * `args` are ignored).  Nothing is kept from the forward pass: z, rgba and the field activations are recomputed per
- * pass; the sample positions carry no gradient (drawn under no_grad, src/model.py:1038,1118).  <= 3 source views. */
+ * pass; the sample positions carry no gradient (drawn under no_grad, src/model.py:1038,1118). */
 typedef struct kpn_render_grads {
     const float* d_tex_fg; const float* d_depth; const float* d_alpha;
     const float* d_tex_fg_fine; const float* d_depth_fine; const float* d_alpha_fine; const float* d_sdf;

@@ -232,6 +232,9 @@ __device__ __forceinline__ float kpn_elu_grad_from_out(float y) { return y > 0.0
 // sum over the two halves of a point (lanes p and p + 32)
 __device__ __forceinline__ float kpn_pair_sum(float x) { return x + __shfl_xor(x, 32); }
 
+// VMAX = 3: the per-view scalars (dot, source colour, logit, ...) stay in registers; VMAX = KPN_MAXV: any view count, the
+// small per-view arrays are indexed dynamically (private memory).
+template <int VMAX>
 __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                       int* __restrict__ tickets, const float* __restrict__ xscr,
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
     const int p = lane & 31, h = lane >> 5;
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
-    const int V = sc.V;  // <= 3 (checked by the launcher)
+    const int V = sc.V;  // <= VMAX (the launcher picks the instantiation)
     const uint32_t keep = sc.keep;
     const float ani = wp[kpn_scalar_off() + 0];  // |ani_al|
     __shared__ __attribute__((aligned(16))) float scat_s[4][KPN_TILE][8];
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }
         // ---------------- forward: per-view x' = [lat|rgb|tex] + ray_encoder(ray_diff) ----------------
-        float dotv[3], rgbv[3][3], logit[3];
+        float dotv[VMAX], rgbv[VMAX][3], logit[VMAX];
         float emin = 3.0e38f, esum = 0.0f;
         for (int v = 0; v < V; ++v) {
             kpn_view_gather g;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
         const float dr = go[2] * live, dg = go[3] * live, db = go[4] * live;
         float lmax = -3.0e38f;
         for (int v = 0; v < V; ++v) lmax = fmaxf(lmax, logit[v]);
-        float den = 0.0f, sm[3], rdot[3], rtot = 0.0f;
+        float den = 0.0f, sm[VMAX], rdot[VMAX], rtot = 0.0f;
         for (int v = 0; v < V; ++v) { sm[v] = ((keep >> v) & 1u) ? kpn_fast_exp(logit[v] - lmax) : 0.0f; den += sm[v]; }
         for (int v = 0; v < V; ++v) {
             sm[v] /= den;
@@ -423,7 +426,9 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dasum[b][r] = 0.0f;
-        float dwv[3] = {0.0f, 0.0f, 0.0f};
+        float dwv[VMAX];
+#pragma unroll
+        for (int v = 0; v < VMAX; ++v) dwv[v] = 0.0f;
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
             const size_t hr = hrow(v);
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
         // ---------------- reverse: blend weights -> |ani_al| (model.py:1287-1289) ----------------
         {
             const float S = KADD(esum, 1e-8f);
-            float ev[3], dot_du = 0.0f;
+            float ev[VMAX], dot_du = 0.0f;
             int imin = 0;
             for (int v = 0; v < V; ++v) {
                 ev[v] = kpn_fast_exp(KMUL(ani, KSUB(dotv[v], 1.0f)));
@@ -671,7 +676,9 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             }
             // d e_v first (the argmin view collects -sum of the others: a difference of nearly equal numbers when one
             // kept view carries almost all the weight), then the common factor — the reference's association
-            float de[3] = {0.0f, 0.0f, 0.0f}, demin = 0.0f;
+            float de[VMAX], demin = 0.0f;
+#pragma unroll
+            for (int v = 0; v < VMAX; ++v) de[v] = 0.0f;
             for (int v = 0; v < V; ++v) {
                 if (!((keep >> v) & 1u)) continue;
                 const float du = dwv[v] / S - dot_du / (S * S);

@@ -775,8 +775,12 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
             if (full == 2) {
                 // rows of dropped views are skipped by k_color_bwd: their dumps must read as zeros in k_weight_grad
                 if (views_dropped) hipMemsetAsync(fp(L.color), 0, L.color_bytes, (hipStream_t)stream);
-                KPN_LAUNCH(k_color_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
-                           (const float*)xscr, d_out + c0 * 5, C);
+                if (V <= 3)
+                    KPN_LAUNCH(k_color_bwd<3>, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
+                               (const float*)xscr, d_out + c0 * 5, C);
+                else
+                    KPN_LAUNCH(k_color_bwd<KPN_MAXV>, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
+                               (const float*)xscr, d_out + c0 * 5, C);
                 wgrad(1, 0, C.Do2, 2, 1, C.Xo2, 8, 8, 8, P_O_2, 0, 0);
                 wgrad(1, 0, C.Do1, 8, 8, C.Xo1, 16, 16, 16, P_O_1, 0, 0);
                 wgrad(1, 0, C.Do0, 16, 16, C.Xo0, KPN_LD_XO0, KPN_LD_XO0, 37, P_O_0, 0, 0);
@@ -855,7 +859,6 @@ extern "C" int kpn_query_backward(const kpn_scene_desc* d, const void* scene_ws,
     if (int e = check_desc(d)) return e;
     KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (raw query) or 1 (eval_func)");
     KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
-    KPN_REQUIRE(d->n_views <= 3, "the colour-head reverse is built for <= 3 source views (use kpn_query_backward_geometry beyond)");
     if (N == 0) return KPN_OK;
     KPN_REQUIRE(scene_ws && wp && pts && view && d_out && d_plain && d_geo0 && d_geo1 && d_tex && ws, "null pointer");
     return run_backward(d, scene_ws, wp, N, pts, view, mode, keep_mask, noise, noise_std, nullptr, d_out, d_plain, d_geo0, d_geo1,
@@ -1050,7 +1053,6 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
     if (int e = check_render(a)) return e;
     KPN_REQUIRE(t && g, "train args / gradients null");
     KPN_REQUIRE(a->fine, "the train branch renders coarse + fine (dr_kwargs.fine)");
-    KPN_REQUIRE(d->n_views <= 3, "the colour-head reverse is built for <= 3 source views");
     KPN_REQUIRE(scene_ws && wp && ws && d_plain && d_geo0 && d_geo1 && d_tex, "null pointer");
     KPN_REQUIRE(t->pix && t->u_coarse && t->u_fine, "train args: pix, u_coarse, u_fine are required");
     KPN_REQUIRE(t->rand_noise_std == 0.0f || (t->noise_coarse && t->noise_fine), "train args: noise tensors missing");

@@ -10,7 +10,7 @@ weights are read from ``net.state_dict()`` and re-packed whenever a parameter ch
 
 Eval path (``net.training == False``, ``uniform=True`` sampling as used by render_full_nerf_image,
 src/model.py:453-473): ``kpn_render_rays``.  Training path (``net.training == True``, batch size 1 as
-configs/zju.json:12, <= 3 source views): ``batch_render_pifu_nerf`` draws the patch centre, the stratified jitter, the
+configs/zju.json:12): ``batch_render_pifu_nerf`` draws the patch centre, the stratified jitter, the
 view-dropout masks, the density noise and the importance ``u`` with the same calls, shapes and order as the reference
 (src/model.py:1008-1017, 1049-1053, 742-748, 993-994, 1129), renders with ``kpn_render_rays_train`` and is
 differentiable: ``loss.backward()`` runs ``kpn_render_rays_train_backward`` and reaches ``weight_g`` / ``weight_v`` /
@@ -169,7 +169,7 @@ def install(net):
     def batch_render_pifu_nerf(net_, img_in, cam_in, n_views, cam_tar, level=2, stride=0, tar_img=None, feat_geo=None,
                                feat_tex=None, sp_data={}, objcenter=None, **config):
         if net_.training:
-            if (img_in.shape[0] // n_views == 1 and n_views <= 3 and config.get("fine", False) and not config.get("uniform", False)
+            if (img_in.shape[0] // n_views == 1 and n_views <= 16 and config.get("fine", False) and not config.get("uniform", False)
                     and not config.get("separate_cf", False) and "msk" in config):
                 return train_render(net_, img_in, cam_in, n_views, cam_tar, tar_img, feat_geo, feat_tex, sp_data, **config)
             return ref["batch_render_pifu_nerf"](net_, img_in, cam_in, n_views, cam_tar, level, stride, tar_img, feat_geo,

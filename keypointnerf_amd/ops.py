@@ -286,7 +286,7 @@ def query_backward_geometry(scene, weights, pts, d_out, mode=1, keep_mask=0xFFFF
 
 
 def query_backward(scene, weights, pts, view, d_out, mode=1, keep_mask=0xFFFFFFFF, noise=None, noise_std=0.0):
-    """Reverse pass of the whole field evaluation incl. the colour head (kpn_query_backward, <= 3 source views):
+    """Reverse pass of the whole field evaluation incl. the colour head (kpn_query_backward):
     what loss.backward() does for KeypointNeRF.query + eval_func in training_step (reference src/model.py:128-155).
     pts, view (N,3)/(1,N,3); d_out (N,5) = d loss / d [sigma, sdf, r, g, b] (mode 1) or d [sdf_raw, rad, r, g, b] (mode 0).
     Returns (d_plain, d_geo0, d_geo1, d_tex): flat effective-parameter gradient (weights.plain_grads_to_state_dict maps it

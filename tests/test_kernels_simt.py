@@ -309,10 +309,10 @@ def test_train_render_backward_kernels(env, case):
     assert_train_grads_vs_golden(got, g, load_weights(), 1e-4)
 
 
-@pytest.mark.parametrize("n_views", [1, 2])
-def test_query_backward_fewer_views(env, n_views):
-    """The colour-head reverse is built for <= 3 views: V = 1 (softmax over one view: no colour gradient at all) and
-    V = 2, synthetic scene + random weights, against the oracle; ragged point count (not a multiple of the 32-point tile)."""
+@pytest.mark.parametrize("n_views", [1, 2, 4])
+def test_query_backward_other_view_counts(env, n_views):
+    """View counts other than 3: V = 1 (softmax over one view: no colour gradient at all), V = 2, and V = 4 (the generic
+    instantiation of k_color_bwd); synthetic scene + random weights, against the oracle; ragged point count."""
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
     from tests.test_oracle_vs_golden import assert_flat_grads_close
     lib = env[0]
