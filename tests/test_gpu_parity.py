@@ -493,3 +493,28 @@ def test_split_bf16_mode(ops, golden_weights):
         assert ((runs[0] - ref).abs().amax(dim=(0, 1)) <= 2e-5 * scale + 1e-6).all()
     finally:
         ops.set_geo_rows_mode(0)
+
+
+def test_query_backward_four_views(ops):
+    """V = 4 (the generic instantiation of the colour-head reverse) on the MI355X against the oracle, one view dropped."""
+    from oracle import oracle
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    from tests.test_oracle_vs_golden import assert_flat_grads_close
+    sd = random_hotpath_state_dict(seed=11)
+    scene = make_scene(n_views=4, src_hw=(48, 64), tar_hw=(16, 16), mask="dense", seed=31)
+    s, ps = _prep(ops, scene)
+    w = ops.PackedWeights(sd)
+    rng = np.random.default_rng(6)
+    lo, hi = scene["bounds"].reshape(2, 3).numpy()
+    N = 1500
+    pts = (lo + (hi - lo) * rng.random((N, 3))).astype(np.float32)
+    view = rng.standard_normal((N, 3)).astype(np.float32)
+    view /= np.linalg.norm(view, axis=1, keepdims=True)
+    G = rng.standard_normal((N, 5)).astype(np.float32)
+    got = ops.query_backward(ps, w, torch.from_numpy(pts).cuda(), torch.from_numpy(view).cuda(), torch.from_numpy(G).cuda(), mode=1,
+                             keep_mask=0b1011)
+    ref = oracle.query_backward(oracle.OracleScene(scene), oracle.flat_weights(sd), pts, view, G, apply_eval_func=True, keep=0b1011)
+    assert np.abs(ref[0]).max() > 0
+    assert_flat_grads_close(got[0].cpu().numpy(), ref[0], 3e-5, "V4", ani_rtol=2e-3, ani_atol=1e-5)
+    for k in (1, 2, 3):
+        assert np.abs(got[k].cpu().numpy() - ref[k]).max() <= 3e-5 * np.abs(ref[k]).max() + 1e-9, k
