@@ -215,6 +215,15 @@ int kpn_render_rays(const kpn_scene_desc* desc, const void* scene_ws, const floa
  * partial sums are accumulated in fp64.  scratch: 2048 doubles + 1 int (device, 16,392 bytes). */
 int kpn_frame_to_rgb8(const float* chw, int32_t height, int32_t width, int32_t bgr, uint8_t* hwc_out, void* stream);
 int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2, void* scratch, void* stream);
+/* kpn_ssim: ZJUEvaluator._compute_ssim (src/zju_evaluator.py:21-45) = skimage 0.19 (environment.yml:135)
+ * structural_similarity(pred, gt, multichannel=True) on the crop [y0, y0+h) x [x0, x0+w) (cv2.boundingRect of
+ * mask_at_box, computed by the caller) of two (3,H,W) fp32 images: 7x7 uniform window, sample covariance, data_range 2
+ * (skimage's default for float images), mean over the interior and the channels.  out (device, 1 double).
+ * skimage is not installed here: the oracle restates its published algorithm with scipy.ndimage.uniform_filter (the
+ * filter skimage itself calls); parity against skimage proper is unpinned. */
+size_t kpn_ssim_scratch_bytes(int32_t crop_w, int32_t crop_h);
+int kpn_ssim(const float* pred_chw, const float* gt_chw, int32_t height, int32_t width, int32_t x0, int32_t y0, int32_t crop_w,
+             int32_t crop_h, double* out, void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py).  When enabled, every launch of the dominant kernel (k_geo_rows) is

@@ -1127,6 +1127,27 @@ extern "C" int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, doubl
     return check_launch("kpn_mse_psnr");
 }
 
+extern "C" size_t kpn_ssim_scratch_bytes(int32_t w, int32_t h) {
+    if (w < 7 || h < 7) return 0;
+    return align_up((size_t)5 * 3 * (h - 6) * w * sizeof(float), 256) + 2048 * sizeof(double) + 256;
+}
+extern "C" int kpn_ssim(const float* pred_chw, const float* gt_chw, int32_t H, int32_t W, int32_t x0, int32_t y0, int32_t w,
+                        int32_t h, double* out, void* scratch, void* stream) {
+    KPN_REQUIRE(pred_chw && gt_chw && out && scratch, "null pointer");
+    KPN_REQUIRE(x0 >= 0 && y0 >= 0 && w >= 7 && h >= 7 && x0 + w <= W && y0 + h <= H, "crop must lie inside the image and be at least 7x7 (win_size)");
+    char* base = static_cast<char*>(scratch);
+    float* tmp = reinterpret_cast<float*>(base);
+    double* partial = reinterpret_cast<double*>(base + align_up((size_t)5 * 3 * (h - 6) * w * sizeof(float), 256));
+    int* ticket = reinterpret_cast<int*>(partial + 2048);
+    (void)hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream);
+    KPN_LAUNCH(k_ssim_vertical, grid1d((int64_t)3 * (h - 6) * w, 256), dim3(256), stream, pred_chw, gt_chw, (int)H, (int)W, (int)x0, (int)y0,
+               (int)w, (int)h, tmp);
+    int64_t blocks = ((int64_t)3 * (h - 6) * (w - 6) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    KPN_LAUNCH(k_ssim_map, dim3((unsigned)blocks), dim3(256), stream, (const float*)tmp, (int)w, (int)h, partial, ticket, out);
+    return check_launch("kpn_ssim");
+}
+
 extern "C" int kpn_profile_enable(int32_t on) {
 #ifndef KPN_SIMT_EMU
     if (on && g_prof.cap == 0) {

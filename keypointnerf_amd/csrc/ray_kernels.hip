@@ -434,3 +434,74 @@ __global__ __launch_bounds__(256) void k_mse_psnr(int64_t n, const float* __rest
         out2[1] = -10.0 * log(mse) / log(10.0);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// SSIM as ZJUEvaluator._compute_ssim computes it (reference src/zju_evaluator.py:21-45): skimage 0.19's
+// structural_similarity(pred, gt, multichannel=True) on the crop [y0, y0+h) x [x0, x0+w) of two float32 images —
+// 7x7 uniform window (scipy.ndimage.uniform_filter: separable, fp64 accumulation, fp32 result per axis), sample
+// covariance (49/48), data_range 2 (skimage's default for float images), K1 = 0.01, K2 = 0.03, mean over the interior
+// (3-pixel border cropped) and the 3 channels.
+// pass 1: vertical 7-tap means of x, y, xx, yy, xy per channel -> tmp[5][3][h-6][w]
+__global__ __launch_bounds__(256) void k_ssim_vertical(const float* __restrict__ pred, const float* __restrict__ gt, int H, int W,
+                                                       int x0, int y0, int w, int h, float* __restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hv = h - 6;
+    if (i >= (int64_t)3 * hv * w) return;
+    const int x = (int)(i % w), y = (int)((i / w) % hv), c = (int)(i / ((int64_t)w * hv));
+    const float* a = pred + ((size_t)c * H + y0 + y) * W + x0 + x;
+    const float* b = gt + ((size_t)c * H + y0 + y) * W + x0 + x;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 7; ++k) {
+        const float u = a[(size_t)k * W], v = b[(size_t)k * W];
+        s[0] += (double)u; s[1] += (double)v;
+        s[2] += (double)KMUL(u, u); s[3] += (double)KMUL(v, v); s[4] += (double)KMUL(u, v);  // im1*im1 etc. are fp32 arrays
+    }
+    const size_t plane = (size_t)3 * hv * w;
+    for (int q = 0; q < 5; ++q) tmp[q * plane + i] = (float)(s[q] / 7.0);
+}
+// pass 2: horizontal 7-tap means, the SSIM map, its sum in fp64 (last workgroup folds the partials)
+__global__ __launch_bounds__(256) void k_ssim_map(const float* __restrict__ tmp, int w, int h, double* __restrict__ partial,
+                                                  int* __restrict__ ticket, double* __restrict__ out) {
+    __shared__ double red[256];
+    __shared__ int last;
+    const int hv = h - 6, wv = w - 6;
+    const int64_t n = (int64_t)3 * hv * wv;
+    const size_t plane = (size_t)3 * hv * w;
+    const float C1 = KMUL(KMUL(0.01f, 2.0f), KMUL(0.01f, 2.0f)), C2 = KMUL(KMUL(0.03f, 2.0f), KMUL(0.03f, 2.0f));
+    const float cov_norm = 49.0f / 48.0f;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wv), y = (int)((i / wv) % hv), c = (int)(i / ((int64_t)wv * hv));
+        float m[5];
+        for (int q = 0; q < 5; ++q) {
+            const float* t = tmp + q * plane + ((size_t)c * hv + y) * w + x;
+            double s = 0.0;
+            for (int k = 0; k < 7; ++k) s += (double)t[k];
+            m[q] = (float)(s / 7.0);
+        }
+        const float ux = m[0], uy = m[1];
+        const float vx = KMUL(cov_norm, KSUB(m[2], KMUL(ux, ux))), vy = KMUL(cov_norm, KSUB(m[3], KMUL(uy, uy)));
+        const float vxy = KMUL(cov_norm, KSUB(m[4], KMUL(ux, uy)));
+        const float A1 = KADD(KMUL(KMUL(2.0f, ux), uy), C1), A2 = KADD(KMUL(2.0f, vxy), C2);
+        const float B1 = KADD(KADD(KMUL(ux, ux), KMUL(uy, uy)), C1), B2 = KADD(KADD(vx, vy), C2);
+        acc += (double)(KMUL(A1, A2) / KMUL(B1, B2));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0];
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double tot = 0.0;
+        for (unsigned k = 0; k < gridDim.x; ++k) tot += ((volatile double*)partial)[k];
+        out[0] = tot / (double)n;
+    }
+}

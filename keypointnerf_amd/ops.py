@@ -481,6 +481,28 @@ def mse_psnr(pred, gt):
     return out
 
 
+def ssim(pred, gt, mask_at_box=None):
+    """SSIM of ZJUEvaluator._compute_ssim (reference src/zju_evaluator.py:21-45): pred, gt (3,H,W) or (1,3,H,W) in [0,1];
+    mask_at_box (H,W): the images are cropped to its bounding rectangle (cv2.boundingRect) first.  Returns a float."""
+    L = kl.get_library()
+    a, b = _dev(pred, "pred").reshape(3, *pred.shape[-2:]), _dev(gt, "gt").reshape(3, *gt.shape[-2:])
+    H, W = a.shape[-2:]
+    x0, y0, w, h = 0, 0, W, H
+    if mask_at_box is not None:
+        ys, xs = torch.nonzero(mask_at_box.reshape(H, W) != 0, as_tuple=True)
+        if ys.numel() == 0:
+            raise ValueError("empty mask")
+        x0, y0 = int(xs.min()), int(ys.min())
+        w, h = int(xs.max()) - x0 + 1, int(ys.max()) - y0 + 1
+    nb = L.kpn_ssim_scratch_bytes(w, h)
+    if nb == 0:
+        raise ValueError("crop smaller than the 7x7 SSIM window")
+    scratch = torch.empty(nb, dtype=torch.uint8, device=a.device)
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    L.check(L.kpn_ssim(_p(a), _p(b), H, W, x0, y0, w, h, _p(out), _p(scratch), _stream()))
+    return float(out.item())
+
+
 def selftest_mfma():
     """Checks on the device that v_mfma_f32_32x32x2_f32 has the operand/result lane maps the kernels assume."""
     L = kl.get_library()

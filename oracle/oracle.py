@@ -249,3 +249,28 @@ def query_backward(oscene, wflat, pts, view, d_out, apply_eval_func=False, keep=
                              ctypes.c_int(int(apply_eval_func)), ctypes.c_uint32(keep), None if nz is None else _ptr(nz),
                              ctypes.c_float(noise_std), _ptr(d_out), _ptr(d_w), _ptr(d_g0), _ptr(d_g1), _ptr(d_tx))
     return d_w, d_g0, d_g1, d_tx
+
+
+def ssim(pred_chw, gt_chw, box=None):
+    """skimage 0.19 structural_similarity(pred, gt, multichannel=True) restated (reference src/zju_evaluator.py:44 calls
+    it on float32 HWC crops): per channel 7x7 scipy.ndimage.uniform_filter (the filter skimage calls), fp32 arithmetic,
+    sample covariance NP/(NP-1), data_range = 2 for float inputs, C1 = (0.01 R)^2, C2 = (0.03 R)^2, 3-pixel border
+    cropped, fp64 mean over pixels and channels.  skimage itself is not installed here: parity with it is unpinned."""
+    from scipy.ndimage import uniform_filter
+    a, b = _f32(pred_chw), _f32(gt_chw)
+    if box is not None:
+        x0, y0, w, h = box
+        a, b = a[:, y0:y0 + h, x0:x0 + w], b[:, y0:y0 + h, x0:x0 + w]
+    R = np.float32(2.0)
+    C1, C2 = (np.float32(0.01) * R) ** 2, (np.float32(0.03) * R) ** 2
+    cov_norm = np.float32(49.0 / 48.0)
+    vals = []
+    for c in range(a.shape[0]):
+        x, y = a[c], b[c]
+        ux, uy = uniform_filter(x, size=7), uniform_filter(y, size=7)
+        uxx, uyy, uxy = uniform_filter(x * x, size=7), uniform_filter(y * y, size=7), uniform_filter(x * y, size=7)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        A1, A2, B1, B2 = 2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2
+        S = (A1 * A2) / (B1 * B2)
+        vals.append(S[3:-3, 3:-3].mean(dtype=np.float64))
+    return float(np.mean(vals))

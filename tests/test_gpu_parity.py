@@ -518,3 +518,19 @@ def test_query_backward_four_views(ops):
     assert_flat_grads_close(got[0].cpu().numpy(), ref[0], 3e-5, "V4", ani_rtol=2e-3, ani_atol=1e-5)
     for k in (1, 2, 3):
         assert np.abs(got[k].cpu().numpy() - ref[k]).max() <= 3e-5 * np.abs(ref[k]).max() + 1e-9, k
+
+
+def test_ssim(ops):
+    """ops.ssim (ZJUEvaluator._compute_ssim on device) vs the scipy restatement of skimage 0.19's structural_similarity,
+    with the evaluator's bounding-box crop of mask_at_box, at 512x512."""
+    from oracle import oracle
+    gen = torch.Generator().manual_seed(3)
+    gt = torch.rand(3, 512, 512, generator=gen)
+    pred = (gt + 0.05 * torch.randn(3, 512, 512, generator=gen)).clamp(0, 1)
+    mask = torch.zeros(512, 512, dtype=torch.bool)
+    mask[100:431, 77:400] = True
+    mask[120, 60] = True                                           # bounding box x0 = 60
+    got = ops.ssim(pred.cuda(), gt.cuda(), mask.cuda())
+    ref = oracle.ssim(pred.numpy(), gt.numpy(), (60, 100, 340, 331))
+    assert abs(got - ref) < 2e-6, (got, ref)
+    assert abs(ops.ssim(gt.cuda(), gt.cuda()) - 1.0) < 1e-7

@@ -383,3 +383,25 @@ def test_split_bf16_geo_rows(env):
     assert np.abs(o1 - ref)[v1].max() < 1e-5
     assert np.abs(o1 - o0)[v1].max() < 5e-6
     assert lib.kpn_set_geo_rows_mode(2) != 0
+
+
+def test_ssim_kernel(env):
+    """kpn_ssim (emulated) against the scipy restatement of skimage 0.19's structural_similarity (the oracle; skimage
+    itself is not installed: unpinned), full image and a bounding-box crop; identical images give exactly 1."""
+    import ctypes
+    lib = env[0]
+    rng = np.random.default_rng(8)
+    H, W = 40, 52
+    gt = rng.random((3, H, W)).astype(np.float32)
+    pred = np.clip(gt + 0.1 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    for box in ((0, 0, W, H), (5, 9, 31, 22), (10, 3, 7, 7)):
+        x0, y0, w, h = box
+        nb = lib.kpn_ssim_scratch_bytes(w, h)
+        scratch, out = np.zeros(nb, np.uint8), np.zeros(1, np.float64)
+        lib.check(lib.kpn_ssim(sh.ptr(pred), sh.ptr(gt), H, W, x0, y0, w, h, sh.ptr(out), sh.ptr(scratch), None))
+        assert abs(out[0] - oracle.ssim(pred, gt, box)) < 2e-6, box
+    scratch = np.zeros(lib.kpn_ssim_scratch_bytes(W, H), np.uint8)
+    lib.check(lib.kpn_ssim(sh.ptr(gt), sh.ptr(gt), H, W, 0, 0, W, H, sh.ptr(out), sh.ptr(scratch), None))
+    assert abs(out[0] - 1.0) < 1e-7
+    assert lib.kpn_ssim_scratch_bytes(6, 20) == 0
+    assert lib.kpn_ssim(sh.ptr(pred), sh.ptr(gt), H, W, 0, 0, W + 1, H, sh.ptr(out), sh.ptr(scratch), None) != 0
