@@ -483,7 +483,7 @@ __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows,
 __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                       float* __restrict__ out) {
+                                                       int park_x, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -595,12 +595,38 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                 else { const float d = KSUB(x, mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
             }
         };
+        // x' of a view is needed three times (two statistics passes, the head).  With park_x the first pass parks it
+        // in slabs 0..4 of the view's row block — the 64-vector stored there is dead once it has been pooled — and the
+        // later passes read it back (5 dwordx4 per lane) instead of re-running the gather and the ray encoder.
+        float4* const park = const_cast<float4*>(rows) + lane;
+        auto park_store = [&](int v, const kpn_ibr_view& x) {
+            float4* d = park + (size_t)v * KPN_ROW_SLABS * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k * 64] = make_float4(x.xb0[4 * k], x.xb0[4 * k + 1], x.xb0[4 * k + 2], x.xb0[4 * k + 3]);
+            d[4 * 64] = make_float4(x.xb1[0], x.xb1[1], x.xb1[2], 0.0f);
+        };
+        auto park_load = [&](int v, kpn_ibr_view& x) {
+            const float4* d = park + (size_t)v * KPN_ROW_SLABS * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 f = d[k * 64];
+                x.xb0[4 * k] = f.x; x.xb0[4 * k + 1] = f.y; x.xb0[4 * k + 2] = f.z; x.xb0[4 * k + 3] = f.w;
+            }
+            const float4 f = d[4 * 64];
+            x.xb1[0] = f.x; x.xb1[1] = f.y; x.xb1[2] = f.z;
+        };
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
                 if (!((keep >> v) & 1u)) continue;
-                kpn_gather_view(xscr, t, V, v, lane, h, gv);
-                kpn_encode_view(wl, lane, h, gv, lat0, iv);
-                stats(pass, gv.rd[3], iv);
+                if (pass == 0 || !park_x) {
+                    kpn_gather_view(xscr, t, V, v, lane, h, gv);
+                    kpn_encode_view(wl, lane, h, gv, lat0, iv);
+                    if (park_x) park_store(v, iv);
+                    stats(pass, gv.rd[3], iv);
+                } else {
+                    park_load(v, iv);
+                    stats(pass, rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w, iv);
+                }
             }
         // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
         kpn_f32x16 base[2];
@@ -670,7 +696,8 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
             kpn_gather_view(xscr, t, V, v, lane, h, gv);
-            kpn_encode_view(wl, lane, h, gv, lat0, iv);
+            if (park_x) park_load(v, iv);
+            else kpn_encode_view(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }
         if (h == 0 && ci_raw < count) {

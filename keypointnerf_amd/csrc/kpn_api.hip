@@ -544,7 +544,7 @@ int fuse_grid_blocks() {
 #endif
 }
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
-              uint8_t* valid, void* ws, void* stream, int lean = 0) {
+              uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0) {
     const QueryLayout L = query_layout(N, sc.V);
     char* base = static_cast<char*>(ws);
     int* count = reinterpret_cast<int*>(base + L.count);
@@ -571,8 +571,10 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 #endif
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
     static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
+    // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going to
+    // read them again (keep_rows)
     KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1,
-               (const float*)xscr, mode, out);
+               (const float*)xscr, mode, keep_rows ? 0 : 1, out);
     return check_launch("field query");
 }
 }  // namespace
@@ -1077,7 +1079,7 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
                    (const float*)(F(L.farv) + r0), t->u_coarse + r0 * Sc, F(L.zc));
         kpn_points pc{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc, std_ != 0.0f ? t->noise_coarse + r0 * Sc : nullptr, std_};
         sc.keep = t->keep_coarse;
-        if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream, 1)) return e;
+        if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream, 1, 1)) return e;
         if (int e = kpn_rgba2out(F(L.rgba_c), F(L.zc), n, Sc, sc4, sc4 + 3 * n, sc4 + 4 * n, F(L.contrib), sc4 + 5 * n, stream)) return e;
         // ---- coarse pass reverse (before the fine forward overwrites the query workspace whose valid list and row
         //      scratch it reuses); sample positions carry no gradient (model.py:1038,1118) ----
@@ -1097,7 +1099,7 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
                        (const float*)F(L.contrib), t->u_fine + r0 * Sf, F(L.zf));
         kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
         sc.keep = t->keep_fine;
-        if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream, 1)) return e;
+        if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream, 1, 1)) return e;
         KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg_fine, F(L.g3));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth_fine, F(L.g1a));
         KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha_fine, F(L.g1b));
