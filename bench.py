@@ -3,7 +3,8 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input = ONE full novel-view frame of
 BASELINE.json configs[1]: 512x512 target, 3 source views (512x512), 64 coarse + 64 fine samples per
-ray (192 field evaluations per ray), synthetic seeded scene + random-init hot-path weights.  Inside a
+ray (the reference evaluates the field 192 times per ray; here 128: the fine pass takes the coarse samples' values from the
+coarse pass, bit-identical outputs), synthetic seeded scene + random-init hot-path weights.  Inside a
 step: scene preparation (NCHW -> channels-last), ray set-up, coarse field pass, compositing, importance
 resampling, fine field pass, compositing, planar image write.  Inputs are resident in HBM before the
 timed region.  With --gpus N every rank renders its own target camera per step (frames of a render job
@@ -45,6 +46,10 @@ def parse():
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
     ap.add_argument("--geo-rows-mode", type=int, default=0, choices=[0, 1],
                     help="0 = fp32 MFMA (default); 1 = split-bf16 operands on the bf16 MFMA (opt-in, fp32-class results)")
+    ap.add_argument("--no-coarse-reuse", action="store_true",
+                    help="evaluate the field at all Sc+Sf merged samples in the fine pass, as the reference does (default: the "
+                         "coarse samples' values are taken from the coarse pass: bit-identical outputs, Sc+Sf instead of "
+                         "2*Sc+Sf evaluations per ray)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo + all ranks on cuda:0 only to exercise the N>1 flow on a 1-GPU box")
@@ -105,6 +110,10 @@ def main():
     from keypointnerf_amd.parallel import orbit_target_camera
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
 
+    if args.no_coarse_reuse:
+        os.environ["KPN_NO_COARSE_REUSE"] = "1"
+    else:
+        os.environ.pop("KPN_NO_COARSE_REUSE", None)
     L = kl.get_library()
     L.check(L.kpn_set_geo_rows_mode(args.geo_rows_mode))
     sd = random_hotpath_state_dict(seed=3)
@@ -115,7 +124,8 @@ def main():
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
                            scene["src_foreground_mask"])
     fine = not args.no_fine
-    evals_per_ray = args.samples * (3 if fine else 1)
+    ref_evals_per_ray = args.samples * (3 if fine else 1)          # the reference: Sc coarse + (Sc + Sf) fine
+    evals_per_ray = args.samples * (2 if fine and not args.no_coarse_reuse else (3 if fine else 1))   # performed here
     plan = ops.RenderPlan(ps, (0, 0, 1, res, res), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
     gather_buf = torch.empty(world, 3, res, res, device=dev) if world > 1 else None
 
@@ -169,7 +179,7 @@ def main():
         alpha_mean = float(out["alpha_fine" if fine else "alpha"].mean())
         peak = BF16_SPLIT_PEAK_TFLOPS if args.geo_rows_mode == 1 else FP32_MFMA_PEAK_TFLOPS
         line = {
-            "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray = {evals_per_ray} field evaluations/ray)" if fine else " samples/ray, flat)"),
+            "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.geo_rows_mode == 0 else "f32 (three bf16 pieces per operand, bf16 MFMA)",
@@ -179,6 +189,10 @@ def main():
                                    f"{args.samples} coarse" + (f" + {args.samples} fine" if fine else "") + f" samples/ray, {args.mask} fg mask, "
                                    f"seeded synthetic scene, random-init hot-path weights",
                        "rays_per_step": rays_per_step, "field_evals_per_ray": evals_per_ray,
+                       "reference_field_evals_per_ray": ref_evals_per_ray,
+                       "note": ("fine pass re-uses the coarse samples' field values (same points, bit-identical outputs; "
+                                "tests/test_gpu_parity.py::test_fine_pass_reuses_coarse_values_bit_exactly); "
+                                "--no-coarse-reuse evaluates them again like the reference") if evals_per_ray != ref_evals_per_ray else "",
                        "sampled_points_per_sec": value * evals_per_ray,
                        "valid_rows_per_step": rows.value / max(1, args.steps),
                        "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},

@@ -870,7 +870,7 @@ extern "C" int kpn_query_backward(const kpn_scene_desc* d, const void* scene_ws,
 // ---------------------------------------------------------------------------------------------
 // hierarchical render
 namespace {
-struct RenderLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, rgba, contrib, color, depth, alpha, sdf, query, total; int64_t chunk; };
+struct RenderLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, zn, src, rgba, rgba_c, rgba_n, contrib, color, depth, alpha, sdf, query, total; int64_t chunk; };
 int64_t pick_chunk(const kpn_scene_desc* d, const kpn_render_args* a) {
     // default: as few, as equal passes as keep the row scratch (points x views x 320 B) under 12 GiB and a pass
     // under 131072 rays — large passes amortise launch ramps and the per-workgroup weight staging of the
@@ -902,6 +902,10 @@ RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
     L.zc = take((size_t)C * a->n_coarse * 4);
     L.zf = take((size_t)C * Sfull * 4);
     L.rgba = take((size_t)C * Sfull * 5 * 4);
+    L.rgba_c = take((size_t)C * a->n_coarse * 5 * 4);                 // coarse values kept for the fine pass (eval)
+    L.rgba_n = take((size_t)C * (a->fine ? a->n_fine : 0) * 5 * 4);   // values at the new samples
+    L.zn = take((size_t)C * (a->fine ? a->n_fine : 0) * 4);
+    L.src = take((size_t)C * Sfull * sizeof(int16_t));
     L.contrib = take((size_t)C * Sfull * 4);
     L.color = take((size_t)C * 3 * 4);
     L.depth = take((size_t)C * 4);
@@ -968,21 +972,37 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
         kpn_points ps{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc,
                       (t && t->rand_noise_std != 0.0f) ? t->noise_coarse + r0 * Sc : nullptr, t ? t->rand_noise_std : 0.0f};
         sc.keep = t ? t->keep_coarse : 0xFFFFFFFFu;
-        if (int e = run_field(sc, ps, wp, n * Sc, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;   // model.py:1062
-        if (int e = kpn_rgba2out(F(L.rgba), F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
+        // eval: the fine pass re-uses the coarse samples' field values (identical points, no dropout, no noise: identical
+        // deterministic results) and evaluates the field at the new samples only — 128 instead of 192 evaluations per ray
+        // at 64 + 64 samples.  The train branch draws fresh dropout masks and noise for the fine query and cannot.
+        const char* nr = getenv("KPN_NO_COARSE_REUSE");  // A/B knob (read per call: tests flip it)
+        const bool no_reuse = nr && atoi(nr);
+        const bool reuse = (t == nullptr) && a->fine && !no_reuse;
+        float* rgba_coarse = reuse ? F(L.rgba_c) : F(L.rgba);
+        if (int e = run_field(sc, ps, wp, n * Sc, 1, rgba_coarse, nullptr, base + L.query, stream, 1)) return e;   // model.py:1062
+        if (int e = kpn_rgba2out(rgba_coarse, F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
         if (a->alpha) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha);
         if (a->fine) {
             const float* uf = t ? t->u_fine + r0 * Sf : (const float*)nullptr;
+            float* zn = reuse ? F(L.zn) : nullptr;
+            int16_t* src = reuse ? reinterpret_cast<int16_t*>(base + L.src) : nullptr;
             if (Sc <= 64 && Sf <= 64)
-                KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf));
+                KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf), zn, src);
             else
-                KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf));
-            kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
-                          (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
+                KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf), zn, src);
             sc.keep = t ? t->keep_fine : 0xFFFFFFFFu;
-            if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;  // :1082
+            if (reuse) {
+                kpn_points pn{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zn), Sf, nullptr, 0.0f};
+                if (int e = run_field(sc, pn, wp, n * Sf, 1, F(L.rgba_n), nullptr, base + L.query, stream, 1)) return e;  // :1082, new samples
+                KPN_LAUNCH(k_merge_rgba, grid1d(n * Sfull, 256), dim3(256), stream, n, Sc, Sf, (const int16_t*)src, (const float*)F(L.rgba_c),
+                           (const float*)F(L.rgba_n), F(L.rgba));
+            } else {
+                kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
+                              (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
+                if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;  // :1082
+            }
             if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);
             if (a->depth_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth_fine);
@@ -1093,10 +1113,10 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
         // ---- fine pass: samples, forward, reverse ----
         if (Sc <= 64 && Sf <= 64)
             KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib),
-                       t->u_fine + r0 * Sf, F(L.zf));
+                       t->u_fine + r0 * Sf, F(L.zf), (float*)nullptr, (int16_t*)nullptr);
         else
             KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc),
-                       (const float*)F(L.contrib), t->u_fine + r0 * Sf, F(L.zf));
+                       (const float*)F(L.contrib), t->u_fine + r0 * Sf, F(L.zf), (float*)nullptr, (int16_t*)nullptr);
         kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
         sc.keep = t->keep_fine;
         if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream, 1, 1)) return e;

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(64) void k_importance(int64_t R, int Dm2, int n, co
 template <int MAXD>
 __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, const float* __restrict__ zc,
                                                      const float* __restrict__ contrib, const float* __restrict__ u,
-                                                     float* __restrict__ zf) {
+                                                     float* __restrict__ zf, float* __restrict__ znew,
+                                                     int16_t* __restrict__ src) {
     __shared__ float cdf_s[64][MAXD];
     __shared__ float zn_s[64][MAXD];
     const int t = threadIdx.x;
@@ -376,18 +377,40 @@ __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, 
     }
     // merge two ascending lists; a descending coarse list (near > far after the AABB clip) is handled
     // by the final insertion pass, which is a no-op on sorted data
+    // znew / src (optional): the sorted new samples and, per merged position, where it came from (coarse index, or
+    // Sc + index into znew) — the eval render evaluates the field at the new samples only and takes the coarse samples'
+    // values from the coarse pass (same points, same deterministic result)
     float* o = zf + r * (Sc + Sf);
+    int16_t* so = src ? src + r * (Sc + Sf) : nullptr;
+    if (znew)
+        for (int k = 0; k < Sf; ++k) znew[r * Sf + k] = zn_s[t][k];
     int a = 0, b = 0;
     for (int k = 0; k < Sc + Sf; ++k) {
         const bool take_a = (b >= Sf) || (a < Sc && z[a] <= zn_s[t][b]);
+        if (so) so[k] = (int16_t)(take_a ? a : Sc + b);
         o[k] = take_a ? z[a++] : zn_s[t][b++];
     }
     for (int k = 1; k < Sc + Sf; ++k) {
         const float v = o[k];
+        const int16_t sv = so ? so[k] : (int16_t)0;
         int j = k;
-        while (j > 0 && o[j - 1] > v) { o[j] = o[j - 1]; --j; }
-        if (j != k) o[j] = v;
+        while (j > 0 && o[j - 1] > v) { o[j] = o[j - 1]; if (so) so[j] = so[j - 1]; --j; }
+        if (j != k) { o[j] = v; if (so) so[j] = sv; }
     }
+}
+
+// rgba of the merged sample list from the coarse pass's values and the new samples' values
+__global__ void k_merge_rgba(int64_t n, int Sc, int Sf, const int16_t* __restrict__ src, const float* __restrict__ rgba_c,
+                             const float* __restrict__ rgba_n, float* __restrict__ rgba_f) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Sfull = Sc + Sf;
+    if (i >= n * Sfull) return;
+    const int64_t r = i / Sfull;
+    const int sidx = src[i];
+    const float* from = sidx < Sc ? rgba_c + (r * Sc + sidx) * 5 : rgba_n + (r * Sf + (sidx - Sc)) * 5;
+    float* to = rgba_f + i * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) to[c] = from[c];
 }
 
 // ---------------------------------------------------------------------------------------------

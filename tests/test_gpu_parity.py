@@ -534,3 +534,24 @@ def test_ssim(ops):
     ref = oracle.ssim(pred.numpy(), gt.numpy(), (60, 100, 340, 331))
     assert abs(got - ref) < 2e-6, (got, ref)
     assert abs(ops.ssim(gt.cuda(), gt.cuda()) - 1.0) < 1e-7
+
+
+def test_fine_pass_reuses_coarse_values_bit_exactly(ops, monkeypatch):
+    """The eval render evaluates the field only at the NEW samples of the fine pass and takes the coarse samples' values
+    from the coarse pass: every output is bit-identical to evaluating all Sc+Sf merged samples again (what the reference
+    does), incl. rays whose near/far are swapped by the AABB clip and dead rays."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    sd = random_hotpath_state_dict(seed=3)
+    for mask, tar_angle in (("ellipsoid", None), ("dense", 95.0)):
+        scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(96, 96), mask=mask, seed=5, tar_angle=tar_angle)
+        s, ps = _prep(ops, scene)
+        w = ops.PackedWeights(sd)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("KPN_NO_COARSE_REUSE", flag)
+            o = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 96, 96), n_coarse=24, n_fine=40)
+            outs.append({k: v.clone() for k, v in o.items()})
+        monkeypatch.delenv("KPN_NO_COARSE_REUSE")
+        assert float(outs[0]["alpha_fine"].max()) > 0.05
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (mask, k)
