@@ -872,16 +872,16 @@ extern "C" int kpn_query_backward(const kpn_scene_desc* d, const void* scene_ws,
 namespace {
 struct RenderLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, zn, src, rgba, rgba_c, rgba_n, contrib, color, depth, alpha, sdf, query, total; int64_t chunk; };
 int64_t pick_chunk(const kpn_scene_desc* d, const kpn_render_args* a) {
-    // default: as few, as equal passes as keep the row scratch (points x views x 320 B) under 12 GiB and a pass
-    // under 131072 rays — large passes amortise launch ramps and the per-workgroup weight staging of the
-    // persistent field kernels (measured: 4096 rays/pass 71 ms, 16384 53 ms, 65536 48 ms per 512^2 frame)
+    // default: as few, as equal passes as keep the row scratch (points x views x 320 B) under 40 GiB (of 288) and a pass under
+    // 262144 rays — large passes amortise launch ramps and the per-workgroup weight staging of the persistent field
+    // kernels (measured per 512^2 frame: 65536 rays/pass 33.6 ms, 131072 33.3 ms, 262144 32.2 ms)
     const int64_t R = (int64_t)a->nx * a->ny;
     int64_t c = a->chunk_rays;
     if (c <= 0) {
         const int64_t Sfull = a->n_coarse + (a->fine ? a->n_fine : 0);
-        int64_t cmax = (12ll << 30) / (Sfull * d->n_views * (int64_t)(KPN_ROW_SLABS * 32)) / 4096 * 4096;
+        int64_t cmax = (40ll << 30) / (Sfull * d->n_views * (int64_t)(KPN_ROW_SLABS * 32)) / 4096 * 4096;
         if (cmax < 4096) cmax = 4096;
-        if (cmax > 131072) cmax = 131072;
+        if (cmax > 262144) cmax = 262144;
         const int64_t npass = (R + cmax - 1) / cmax;
         c = ((R + npass - 1) / npass + 63) / 64 * 64;
     }
