@@ -198,6 +198,10 @@ typedef struct kpn_render_args {
     float* tex_fg_fine; float* depth_fine; float* alpha_fine; float* sdf;
 } kpn_render_args;
 
+/* Note on the fine pass: z_fine = sort(cat(z_coarse, z_new)) (src/model.py:1076) repeats the coarse samples; their field
+ * values are taken from the coarse pass and the field is evaluated at the new samples only — identical points, identical
+ * deterministic values, outputs bit-identical to evaluating all of them again (environment variable
+ * KPN_NO_COARSE_REUSE=1 does that, for comparison).  kpn_render_rays_train evaluates everything (fresh dropout / noise). */
 size_t kpn_render_workspace_bytes(const kpn_scene_desc* desc, const kpn_render_args* args);
 int kpn_render_rays(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
                     const kpn_render_args* args, void* workspace, size_t workspace_bytes, void* stream);
