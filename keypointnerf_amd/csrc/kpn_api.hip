@@ -942,6 +942,16 @@ extern "C" size_t kpn_render_workspace_bytes(const kpn_scene_desc* d, const kpn_
 
 // shared implementation: t == nullptr -> eval branch (model.py:1019-1022, uniform=True); otherwise the train
 // branch with explicit random draws
+// importance samples of the fine pass + the merged depth list (k_fine_samples_w), Sc, Sf <= 128
+static void launch_fine_samples(void* stream, int64_t n, int Sc, int Sf, const float* zc, const float* contrib,
+                                const float* u, float* zf, float* znew, int16_t* src) {
+    const dim3 grid((unsigned)(n + 3 < 4 * 8192 ? (n + 3) / 4 : 8192));
+    if (Sc <= 64 && Sf <= 64)
+        KPN_LAUNCH(k_fine_samples_w<true>, grid, dim3(256), stream, n, Sc, Sf, zc, contrib, u, zf, znew, src);
+    else
+        KPN_LAUNCH(k_fine_samples_w<false>, grid, dim3(256), stream, n, Sc, Sf, zc, contrib, u, zf, znew, src);
+}
+
 static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
                        const kpn_train_args* t, void* ws, size_t ws_bytes, void* stream) {
     if (int e = check_desc(d)) return e;
@@ -988,10 +998,7 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
             const float* uf = t ? t->u_fine + r0 * Sf : (const float*)nullptr;
             float* zn = reuse ? F(L.zn) : nullptr;
             int16_t* src = reuse ? reinterpret_cast<int16_t*>(base + L.src) : nullptr;
-            if (Sc <= 64 && Sf <= 64)
-                KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf), zn, src);
-            else
-                KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib), uf, F(L.zf), zn, src);
+            launch_fine_samples(stream, n, Sc, Sf, F(L.zc), F(L.contrib), uf, F(L.zf), zn, src);
             sc.keep = t ? t->keep_fine : 0xFFFFFFFFu;
             if (reuse) {
                 kpn_points pn{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zn), Sf, nullptr, 0.0f};
@@ -1111,12 +1118,7 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
         if (int e = run_backward(d, scene_ws, wp, n * Sc, nullptr, nullptr, 1, t->keep_coarse, nullptr, 0.0f, nullptr, F(L.drgba_c),
                                  d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pc, base + L.query)) return e;
         // ---- fine pass: samples, forward, reverse ----
-        if (Sc <= 64 && Sf <= 64)
-            KPN_LAUNCH(k_fine_samples<65>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc), (const float*)F(L.contrib),
-                       t->u_fine + r0 * Sf, F(L.zf), (float*)nullptr, (int16_t*)nullptr);
-        else
-            KPN_LAUNCH(k_fine_samples<KPN_IS_MAXD>, grid1d(n, 64), dim3(64), stream, n, Sc, Sf, (const float*)F(L.zc),
-                       (const float*)F(L.contrib), t->u_fine + r0 * Sf, F(L.zf), (float*)nullptr, (int16_t*)nullptr);
+        launch_fine_samples(stream, n, Sc, Sf, F(L.zc), F(L.contrib), t->u_fine + r0 * Sf, F(L.zf), nullptr, nullptr);
         kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
         sc.keep = t->keep_fine;
         if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream, 1, 1)) return e;

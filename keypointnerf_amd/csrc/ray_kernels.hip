@@ -399,6 +399,139 @@ __global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, 
     }
 }
 
+// Wave-per-ray version of k_fine_samples (same results: every value is produced by the same fp32 operations; ties
+// between equal depths may be ordered differently, which changes nothing — equal depths on a ray are the same point).
+// Lane k draws sample k.  The two cumsums of the reference stay sequential (torch.cumsum order on the CPU, which the
+// oracle is pinned to): with SMALL (Sc, Sf <= 64) lane i holds element i and the running value walks the lanes through
+// v_readlane; otherwise lane 0 walks LDS.  The new samples are ordered by rank counting unless they already are
+// (uniform u: nearly always); the merged order of two sorted lists is two binary searches per element, with rank
+// counting over the whole list as the fall-back when the coarse depths are not sorted.  Sc, Sf <= 128.
+// One workgroup = 4 wavefronts = 4 rays per iteration.
+#ifndef KPN_SIMT_EMU
+#define KPN_READLANE_F(v, i) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (i)))
+#else
+#define KPN_READLANE_F(v, i) __shfl((v), (i))
+#endif
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_fine_samples_w(int64_t R, int Sc, int Sf, const float* __restrict__ zc,
+                                                        const float* __restrict__ contrib, const float* __restrict__ u,
+                                                        float* __restrict__ zf, float* __restrict__ znew,
+                                                        int16_t* __restrict__ src) {
+    constexpr int NE = SMALL ? 1 : 2;   // elements of one list per lane
+    constexpr int W = 64 * NE;
+    __shared__ float q_s[SMALL ? 1 : 4][SMALL ? 1 : W];   // (c_i + 1e-5), then / sum (LDS walk only)
+    __shared__ float cdf_s[4][W + 1];
+    __shared__ float zn_s[4][W];       // new samples as drawn
+    __shared__ float ev_s[4][2 * W];   // all Sc + Sf depths: coarse, then new (sorted)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int Dm2 = Sc - 2, C = Sc - 1, Sfull = Sc + Sf;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < R; r += (int64_t)gridDim.x * 4) {
+        const float* c = contrib + r * Sc + 1;
+        const float* z = zc + r * Sc;
+        for (int i = lane; i < Sc; i += 64) ev_s[w][i] = z[i];
+        if constexpr (SMALL) {
+            float q = lane < Dm2 ? KADD(c[lane], 1e-5f) : 0.0f;
+            float sum = 0.0f;
+            for (int i = 0; i < Dm2; ++i) sum = KADD(sum, KPN_READLANE_F(q, i));   // :1120-1121, sequential
+            q = q / sum;
+            float run = 0.0f, mine = 0.0f;
+            for (int i = 0; i < Dm2; ++i) {                                        // :1122-1123, sequential
+                run = KADD(run, KPN_READLANE_F(q, i));
+                mine = lane == i + 1 ? run : mine;
+            }
+            if (lane < C) cdf_s[w][lane] = mine;
+        } else {
+            for (int i = lane; i < Dm2; i += 64) q_s[w][i] = KADD(c[i], 1e-5f);
+            KPN_WAVE_SYNC();
+            float sum = 0.0f;
+            if (lane == 0)
+                for (int i = 0; i < Dm2; ++i) sum = KADD(sum, q_s[w][i]);
+            sum = __shfl(sum, 0);
+            for (int i = lane; i < Dm2; i += 64) q_s[w][i] = q_s[w][i] / sum;
+            KPN_WAVE_SYNC();
+            if (lane == 0) {
+                float run = 0.0f;
+                cdf_s[w][0] = 0.0f;
+                for (int i = 0; i < Dm2; ++i) { run = KADD(run, q_s[w][i]); cdf_s[w][i + 1] = run; }
+            }
+        }
+        KPN_WAVE_SYNC();
+        // inverse-CDF samples (:1125-1147)
+        float v[NE];
+        for (int e = 0; e < NE; ++e) {
+            const int k = lane + 64 * e;
+            v[e] = 0.0f;
+            if (k < Sf) {
+                const float sv = u ? u[r * Sf + k] : kpn_linspace01(k, Sf);
+                int lo = 0, hi = C;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cdf_s[w][mid] <= sv) lo = mid + 1; else hi = mid;
+                }
+                const int ip = lo - 1 < 0 ? 0 : lo - 1;
+                const int in = lo > C - 1 ? C - 1 : lo;
+                const float num = KSUB(sv, cdf_s[w][ip]);
+                float den = KSUB(cdf_s[w][in], cdf_s[w][ip]);
+                if (den < 1e-5f) den = 1.0f;
+                const float zp = KMUL(0.5f, KADD(ev_s[w][ip + 1], ev_s[w][ip]));
+                const float zq = KMUL(0.5f, KADD(ev_s[w][in + 1], ev_s[w][in]));
+                v[e] = KADD(zp, KMUL(num / den, KSUB(zq, zp)));
+                zn_s[w][k] = v[e];
+            }
+        }
+        KPN_WAVE_SYNC();
+        // order the new samples
+        int rk[NE];
+        int unsorted = 0;
+        for (int e = 0; e < NE; ++e) {
+            const int k = lane + 64 * e;
+            rk[e] = k;
+            unsorted |= (k + 1 < Sf) && !(v[e] <= zn_s[w][k + 1 < W ? k + 1 : k]);
+        }
+        if (__any(unsorted)) {
+            for (int e = 0; e < NE; ++e) rk[e] = 0;
+            for (int j = 0; j < Sf; ++j) {
+                const float o = zn_s[w][j];
+                for (int e = 0; e < NE; ++e) rk[e] += (o < v[e]) || (o == v[e] && j < lane + 64 * e);
+            }
+        }
+        for (int e = 0; e < NE; ++e)
+            if (lane + 64 * e < Sf) ev_s[w][Sc + rk[e]] = v[e];
+        KPN_WAVE_SYNC();
+        if (znew)
+            for (int k = lane; k < Sf; k += 64) znew[r * Sf + k] = ev_s[w][Sc + k];
+        // merged order
+        int csorted = 1;
+        for (int i = lane; i + 1 < Sc; i += 64) csorted &= ev_s[w][i] <= ev_s[w][i + 1];
+        if (__all(csorted)) {
+            // coarse i goes to i + #{new < it}, new k (sorted position) to k + #{coarse <= it}: a permutation of 0..Sfull-1
+            for (int i = lane; i < Sc; i += 64) {
+                const float a = ev_s[w][i];
+                int lo = 0, hi = Sf;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ev_s[w][Sc + mid] < a) lo = mid + 1; else hi = mid; }
+                zf[r * Sfull + i + lo] = a;
+                if (src) src[r * Sfull + i + lo] = (int16_t)i;
+            }
+            for (int k = lane; k < Sf; k += 64) {
+                const float b = ev_s[w][Sc + k];
+                int lo = 0, hi = Sc;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ev_s[w][mid] <= b) lo = mid + 1; else hi = mid; }
+                zf[r * Sfull + k + lo] = b;
+                if (src) src[r * Sfull + k + lo] = (int16_t)(Sc + k);
+            }
+        } else {
+            for (int id = lane; id < Sfull; id += 64) {
+                const float a = ev_s[w][id];
+                int rank = 0;
+                for (int j = 0; j < Sfull; ++j) { const float o = ev_s[w][j]; rank += (o < a) || (o == a && j < id); }
+                zf[r * Sfull + rank] = a;
+                if (src) src[r * Sfull + rank] = (int16_t)id;
+            }
+        }
+        KPN_WAVE_SYNC();
+    }
+}
+
 // rgba of the merged sample list from the coarse pass's values and the new samples' values
 __global__ void k_merge_rgba(int64_t n, int Sc, int Sf, const int16_t* __restrict__ src, const float* __restrict__ rgba_c,
                              const float* __restrict__ rgba_n, float* __restrict__ rgba_f) {

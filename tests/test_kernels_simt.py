@@ -92,6 +92,25 @@ def test_render_pipeline_vs_golden(env):
         np.testing.assert_allclose(o[k], g["out." + k][0], rtol=2e-4, atol=2e-4)
 
 
+def test_render_more_than_64_samples_per_pass(env):
+    """Sc, Sf > 64 take the sampler's two-elements-per-lane path (k_fine_samples_w<false>); checked against the oracle on a
+    coarse pixel lattice of the smallest golden scene."""
+    lib, packed, wflat = env
+    scene, cfg, g = load_case("case_c_v3_offaxis")
+    hs = sh.HostScene(lib, scene)
+    H, W = scene["cam_tar"]["height"], scene["cam_tar"]["width"]
+    step, Sc, Sf = 8, 70, 66
+    ny, nx = H // step, W // step
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, step, nx, ny), Sc, Sf, chunk_rays=1000)
+    ys, xs = np.meshgrid(np.arange(ny) * step, np.arange(nx) * step, indexing="ij")
+    pix = np.stack([xs.reshape(-1), ys.reshape(-1)], 1).astype(np.float32)
+    ref = oracle.render_rays(oracle.OracleScene(scene), wflat, scene["cam_tar"], scene["bounds"], pix, Sc, Sf)
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(o[k].reshape(3, -1).T - ref[k]).max() < 1e-5, k
+    for k in ("alpha", "alpha_fine", "depth_fine"):
+        assert np.abs(o[k].reshape(-1) - ref[k]).max() < 2e-5, k
+
+
 def test_output_kernels(env):
     import ctypes
     import os
