@@ -543,6 +543,17 @@ int fuse_grid_blocks() {
     return 256;
 #endif
 }
+// points per k_mask_compact thread: as many as keep >= 8 workgroups per CU in flight
+static inline int mask_points_per_thread(int64_t N) {
+#ifndef KPN_SIMT_EMU
+    const int64_t min_groups = 2048;
+#else
+    const int64_t min_groups = 2;  // so that the emulator tests walk the multi-point loop
+#endif
+    int ppt = KPN_MASK_PPT;
+    while (ppt > 1 && N / (256 * (int64_t)ppt) < min_groups) ppt >>= 1;
+    return ppt;
+}
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
               uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0) {
     const QueryLayout L = query_layout(N, sc.V);
@@ -551,7 +562,8 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     int* list = reinterpret_cast<int*>(base + L.list);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
     hipMemsetAsync(count, 0, 4 * sizeof(int), (hipStream_t)stream);  // [0] valid count, [1] k_geo_rows tickets, [2] k_fuse_color tickets
-    KPN_LAUNCH(k_mask_compact, grid1d(N, 256), dim3(256), stream, sc, ps, N, mode, lean, wp + kpn_scalar_off(), out, valid, list, count);
+    const int ppt = mask_points_per_thread(N);
+    KPN_LAUNCH(k_mask_compact, grid1d(N, 256 * ppt), dim3(256), stream, sc, ps, N, mode, lean, ppt, wp + kpn_scalar_off(), out, valid, list, count);
     const int blocks = field_grid_blocks();
 #ifndef KPN_SIMT_EMU
     const bool prof = g_prof.on && g_prof.used < g_prof.cap;
@@ -767,7 +779,8 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
             list = reinterpret_cast<int*>(qb + Q.list);
             xscr = reinterpret_cast<float*>(qb + Q.xscr);
         } else {
-            KPN_LAUNCH(k_mask_compact, grid1d(n, 256), dim3(256), stream, sc, ps, n, 0, 1, wp + kpn_scalar_off(), (float*)nullptr,
+            const int ppt = mask_points_per_thread(n);
+            KPN_LAUNCH(k_mask_compact, grid1d(n, 256 * ppt), dim3(256), stream, sc, ps, n, 0, 1, ppt, wp + kpn_scalar_off(), (float*)nullptr,
                        (uint8_t*)nullptr, list, count);
         }
         KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, vcount, V, rows_dev);
