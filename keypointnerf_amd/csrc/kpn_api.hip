@@ -482,8 +482,16 @@ extern "C" int kpn_rgba2out(const float* rgba, const float* z, int64_t R, int32_
     if (R <= 0) return R == 0 ? KPN_OK : fail(KPN_EINVAL, "negative ray count");
     const int64_t blocks = (R + 3) / 4;  // 4 waves per block, one ray per wave per iteration
     KPN_LAUNCH(k_rgba2out, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), stream, R, (int)S, rgba, z, color,
-               depth, alpha, contrib, sdf);
+               depth, alpha, contrib, sdf, (const int16_t*)nullptr, (const float*)nullptr, 0);
     return check_launch("kpn_rgba2out");
+}
+// compositor over the merged list of the fine pass, read in place from the coarse and the new samples' records
+static int rgba2out_merged(const float* rgba_c, const float* rgba_n, const int16_t* src, const float* z, int64_t R, int Sc, int Sf,
+                           float* color, float* depth, float* alpha, float* sdf, void* stream) {
+    const int64_t blocks = (R + 3) / 4;
+    KPN_LAUNCH(k_rgba2out, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), stream, R, Sc + Sf, rgba_c, z, color,
+               depth, alpha, (float*)nullptr, sdf, src, rgba_n, Sc);
+    return check_launch("kpn_render_rays");
 }
 
 extern "C" int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t R, int32_t S, const float* d_color,
@@ -1016,14 +1024,13 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
             if (reuse) {
                 kpn_points pn{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zn), Sf, nullptr, 0.0f};
                 if (int e = run_field(sc, pn, wp, n * Sf, 1, F(L.rgba_n), nullptr, base + L.query, stream, 1)) return e;  // :1082, new samples
-                KPN_LAUNCH(k_merge_rgba, grid1d(n * Sfull, 256), dim3(256), stream, n, Sc, Sf, (const int16_t*)src, (const float*)F(L.rgba_c),
-                           (const float*)F(L.rgba_n), F(L.rgba));
+                if (int e = rgba2out_merged(F(L.rgba_c), F(L.rgba_n), src, F(L.zf), n, Sc, Sf, F(L.color), F(L.depth), F(L.alpha), F(L.sdf), stream)) return e;
             } else {
                 kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
                               (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
                 if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;  // :1082
+                if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             }
-            if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);
             if (a->depth_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth_fine);
             if (a->alpha_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha_fine);

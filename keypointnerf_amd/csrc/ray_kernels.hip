@@ -199,23 +199,33 @@ __global__ void k_coarse_z(int64_t R, int S, const float* __restrict__ near_i, c
 __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float* __restrict__ rgba,
                                                   const float* __restrict__ z, float* __restrict__ color,
                                                   float* __restrict__ depth, float* __restrict__ alpha,
-                                                  float* __restrict__ contrib, float* __restrict__ sdf) {
+                                                  float* __restrict__ contrib, float* __restrict__ sdf,
+                                                  const int16_t* __restrict__ src, const float* __restrict__ rgba_new, int Sc) {
+    // src != NULL: sample i of ray r is record src[r*S+i] of the ray's coarse records (rgba, Sc per ray) when < Sc, else of
+    // its new-sample records (rgba_new, S - Sc per ray) — the merged list of the fine pass without materialising it
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int per = (S + 63) / 64;
     for (int64_t r = wave; r < R; r += nwaves) {
-        const float* q = rgba + r * S * 5;
         const float* zz = z + r * S;
+        auto record = [&](int i) -> const float* {
+            if (!src) return rgba + (r * S + i) * 5;
+            const int id = src[r * S + i];
+            return id < Sc ? rgba + (r * Sc + id) * 5 : rgba_new + (r * (S - Sc) + (id - Sc)) * 5;
+        };
         float c[KPN_MAX_PER_LANE];
+        const float* qk[KPN_MAX_PER_LANE];
         float tl = 1.0f;  // product of (1-c) over this lane's samples
 #pragma unroll
         for (int k = 0; k < KPN_MAX_PER_LANE; ++k) {
             c[k] = 0.0f;
+            qk[k] = rgba;
             const int i = lane * per + k;
             if (k < per && i < S) {
+                qk[k] = record(i);
                 const float dist = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;  // :1166
-                c[k] = 1.0f - expf(-q[i * 5 + 0] * dist);                       // :1167
+                c[k] = 1.0f - expf(-qk[k][0] * dist);                           // :1167
                 tl *= (1.0f - c[k]);
             }
         }
@@ -236,8 +246,9 @@ __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float*
                 const float cw = c[k] * T;  // :1168-1169
                 T *= (1.0f - c[k]);
                 if (contrib) contrib[r * S + i] = cw;
-                s_r += q[i * 5 + 2] * cw; s_g += q[i * 5 + 3] * cw; s_b += q[i * 5 + 4] * cw;
-                s_a += cw; s_s += q[i * 5 + 1] * cw; s_d += zz[i] * cw;
+                const float* q = qk[k];
+                s_r += q[2] * cw; s_g += q[3] * cw; s_b += q[4] * cw;
+                s_a += cw; s_s += q[1] * cw; s_d += zz[i] * cw;
             }
         }
 #pragma unroll
@@ -530,20 +541,6 @@ __global__ __launch_bounds__(256) void k_fine_samples_w(int64_t R, int Sc, int S
         }
         KPN_WAVE_SYNC();
     }
-}
-
-// rgba of the merged sample list from the coarse pass's values and the new samples' values
-__global__ void k_merge_rgba(int64_t n, int Sc, int Sf, const int16_t* __restrict__ src, const float* __restrict__ rgba_c,
-                             const float* __restrict__ rgba_n, float* __restrict__ rgba_f) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int Sfull = Sc + Sf;
-    if (i >= n * Sfull) return;
-    const int64_t r = i / Sfull;
-    const int sidx = src[i];
-    const float* from = sidx < Sc ? rgba_c + (r * Sc + sidx) * 5 : rgba_n + (r * Sf + (sidx - Sc)) * 5;
-    float* to = rgba_f + i * 5;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) to[c] = from[c];
 }
 
 // ---------------------------------------------------------------------------------------------
