@@ -6,7 +6,7 @@
 //   k_coarse_z                                 : src/model.py:1045-1055 (uniform=True)
 //   k_rgba2out                                 : src/model.py:1150-1176, one wavefront per ray,
 //                                                transmittance by a 64-lane exclusive product scan
-//   k_importance_merge                         : src/model.py:1110-1148 + sort(cat) :1076
+//   k_importance / k_fine_samples_w            : src/model.py:1110-1148 (+ sort(cat) :1076)
 #include "kpn_device.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -342,77 +342,9 @@ __global__ __launch_bounds__(64) void k_importance(int64_t R, int Dm2, int n, co
     }
 }
 
-// z_mid (:1074) and contrib[...,1:-1] (:1075) followed by importance sampling and
-// z_fine = sort(cat[z, z_new]) (:1076).  One thread per ray; z_new is staged in LDS, insertion-sorted
-// (already ascending when u is the uniform linspace), then merged with the coarse z.
-// MAXD: LDS row length (odd: conflict-free column access); 65 serves Sc,Sf <= 64 at 4x the occupancy of 129
-template <int MAXD>
-__global__ __launch_bounds__(64) void k_fine_samples(int64_t R, int Sc, int Sf, const float* __restrict__ zc,
-                                                     const float* __restrict__ contrib, const float* __restrict__ u,
-                                                     float* __restrict__ zf, float* __restrict__ znew,
-                                                     int16_t* __restrict__ src) {
-    __shared__ float cdf_s[64][MAXD];
-    __shared__ float zn_s[64][MAXD];
-    const int t = threadIdx.x;
-    const int64_t r = (int64_t)blockIdx.x * 64 + t;
-    if (r >= R) return;
-    const int Dm2 = Sc - 2, C = Sc - 1;
-    const float* c = contrib + r * Sc + 1;
-    const float* z = zc + r * Sc;
-    float sum = 0.0f;
-    for (int i = 0; i < Dm2; ++i) sum = KADD(sum, KADD(c[i], 1e-5f));
-    float run = 0.0f;
-    cdf_s[t][0] = 0.0f;
-    for (int i = 0; i < Dm2; ++i) {
-        run = KADD(run, KADD(c[i], 1e-5f) / sum);
-        cdf_s[t][i + 1] = run;
-    }
-    for (int k = 0; k < Sf; ++k) {
-        const float s = u ? u[r * Sf + k] : kpn_linspace01(k, Sf);  // train: th.rand (:1129); eval: linspace (:1126)
-        int lo = 0, hi = C;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf_s[t][mid] <= s) lo = mid + 1; else hi = mid;
-        }
-        const int ip = lo - 1 < 0 ? 0 : lo - 1;
-        const int in = lo > C - 1 ? C - 1 : lo;
-        const float num = KSUB(s, cdf_s[t][ip]);
-        float den = KSUB(cdf_s[t][in], cdf_s[t][ip]);
-        if (den < 1e-5f) den = 1.0f;
-        const float zp = KMUL(0.5f, KADD(z[ip + 1], z[ip]));  // z_mid[ip]
-        const float zq = KMUL(0.5f, KADD(z[in + 1], z[in]));  // z_mid[in]
-        float v = KADD(zp, KMUL(num / den, KSUB(zq, zp)));
-        int j = k;  // insertion sort step
-        while (j > 0 && zn_s[t][j - 1] > v) { zn_s[t][j] = zn_s[t][j - 1]; --j; }
-        zn_s[t][j] = v;
-    }
-    // merge two ascending lists; a descending coarse list (near > far after the AABB clip) is handled
-    // by the final insertion pass, which is a no-op on sorted data
-    // znew / src (optional): the sorted new samples and, per merged position, where it came from (coarse index, or
-    // Sc + index into znew) — the eval render evaluates the field at the new samples only and takes the coarse samples'
-    // values from the coarse pass (same points, same deterministic result)
-    float* o = zf + r * (Sc + Sf);
-    int16_t* so = src ? src + r * (Sc + Sf) : nullptr;
-    if (znew)
-        for (int k = 0; k < Sf; ++k) znew[r * Sf + k] = zn_s[t][k];
-    int a = 0, b = 0;
-    for (int k = 0; k < Sc + Sf; ++k) {
-        const bool take_a = (b >= Sf) || (a < Sc && z[a] <= zn_s[t][b]);
-        if (so) so[k] = (int16_t)(take_a ? a : Sc + b);
-        o[k] = take_a ? z[a++] : zn_s[t][b++];
-    }
-    for (int k = 1; k < Sc + Sf; ++k) {
-        const float v = o[k];
-        const int16_t sv = so ? so[k] : (int16_t)0;
-        int j = k;
-        while (j > 0 && o[j - 1] > v) { o[j] = o[j - 1]; if (so) so[j] = so[j - 1]; --j; }
-        if (j != k) { o[j] = v; if (so) so[j] = sv; }
-    }
-}
-
-// Wave-per-ray version of k_fine_samples (same results: every value is produced by the same fp32 operations; ties
-// between equal depths may be ordered differently, which changes nothing — equal depths on a ray are the same point).
-// Lane k draws sample k.  The two cumsums of the reference stay sequential (torch.cumsum order on the CPU, which the
+// z_mid (:1074) and contrib[...,1:-1] (:1075) followed by importance sampling and z_fine = sort(cat[z, z_new]) (:1076),
+// one wavefront per ray (ties between equal depths are ordered coarse-first, which changes nothing — equal depths on a
+// ray are the same point).  Lane k draws sample k.  The two cumsums of the reference stay sequential (torch.cumsum order on the CPU, which the
 // oracle is pinned to): with SMALL (Sc, Sf <= 64) lane i holds element i and the running value walks the lanes through
 // v_readlane; otherwise lane 0 walks LDS.  The new samples are ordered by rank counting unless they already are
 // (uniform u: nearly always); the merged order of two sorted lists is two binary searches per element, with rank
