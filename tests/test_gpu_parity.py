@@ -556,3 +556,30 @@ def test_fine_pass_reuses_coarse_values_bit_exactly(ops, monkeypatch):
         assert float(outs[0]["alpha_fine"].max()) > 0.05
         for k in outs[0]:
             assert torch.equal(outs[0][k], outs[1][k]), (mask, k)
+
+
+def test_render_is_graph_capturable(ops):
+    """kpn_render_rays makes no synchronising call: a frame can be captured into a HIP graph on the caller's stream and
+    replayed (same outputs, also after the target camera tensors were overwritten in place)."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(64, 64), mask="ellipsoid", seed=7)
+    s, ps = _prep(ops, scene)
+    w = ops.PackedWeights(random_hotpath_state_dict(seed=3))
+    plan = ops.RenderPlan(ps, (0, 0, 1, 64, 64), 32, 32, fine=True)
+    eager = {k: v.clone() for k, v in ops.render_rays(ps, w, s["cam_tar"], s["bounds"], plan=plan).items()}
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ops.render_rays(ps, w, s["cam_tar"], s["bounds"], plan=plan)  # warm-up on the capture stream
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            ops.render_rays(ps, w, s["cam_tar"], s["bounds"], plan=plan)
+    for v in plan.out.values():
+        v.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float(eager["alpha_fine"].max()) > 0.05
+    for k in eager:
+        assert torch.equal(plan.out[k], eager[k]), k
