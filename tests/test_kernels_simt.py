@@ -92,14 +92,15 @@ def test_render_pipeline_vs_golden(env):
         np.testing.assert_allclose(o[k], g["out." + k][0], rtol=2e-4, atol=2e-4)
 
 
-def test_render_more_than_64_samples_per_pass(env):
-    """Sc, Sf > 64 take the sampler's two-elements-per-lane path (k_fine_samples_w<false>); checked against the oracle on a
-    coarse pixel lattice of the smallest golden scene."""
+@pytest.mark.parametrize("step,Sc,Sf", [(8, 70, 66), (12, 128, 128), (6, 3, 1)])
+def test_render_sample_count_extremes(env, step, Sc, Sf):
+    """Sc, Sf > 64 take the sampler's two-elements-per-lane path (k_fine_samples_w<false>); the largest (128 + 128) and the
+    smallest (3 + 1) sample counts the entry point accepts; checked against the oracle on a coarse pixel lattice of the
+    smallest golden scene."""
     lib, packed, wflat = env
     scene, cfg, g = load_case("case_c_v3_offaxis")
     hs = sh.HostScene(lib, scene)
     H, W = scene["cam_tar"]["height"], scene["cam_tar"]["width"]
-    step, Sc, Sf = 8, 70, 66
     ny, nx = H // step, W // step
     o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, step, nx, ny), Sc, Sf, chunk_rays=1000)
     ys, xs = np.meshgrid(np.arange(ny) * step, np.arange(nx) * step, indexing="ij")
