@@ -475,22 +475,31 @@ extern "C" int kpn_importance_sample(const float* contrib, const float* z, const
     return check_launch("kpn_importance_sample");
 }
 
+// compositor launch: the kernel is specialised by samples per lane (ceil(S / 64)) so that the double-buffered ray
+// state stays in few registers
+static void launch_rgba2out(void* stream, int64_t R, int S, const float* rgba, const float* z, float* color, float* depth,
+                            float* alpha, float* contrib, float* sdf, const int16_t* src, const float* rgba_new, int Sc) {
+    const int64_t blocks = (R + 3) / 4;  // 4 waves per block, one ray per wave per iteration
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
+    const int per = (S + 63) / 64;
+    if (per <= 1) KPN_LAUNCH(k_rgba2out<1>, grid, dim3(256), stream, R, S, rgba, z, color, depth, alpha, contrib, sdf, src, rgba_new, Sc);
+    else if (per <= 2) KPN_LAUNCH(k_rgba2out<2>, grid, dim3(256), stream, R, S, rgba, z, color, depth, alpha, contrib, sdf, src, rgba_new, Sc);
+    else if (per <= 4) KPN_LAUNCH(k_rgba2out<4>, grid, dim3(256), stream, R, S, rgba, z, color, depth, alpha, contrib, sdf, src, rgba_new, Sc);
+    else KPN_LAUNCH(k_rgba2out<KPN_MAX_PER_LANE>, grid, dim3(256), stream, R, S, rgba, z, color, depth, alpha, contrib, sdf, src, rgba_new, Sc);
+}
+
 extern "C" int kpn_rgba2out(const float* rgba, const float* z, int64_t R, int32_t S, float* color, float* depth,
                             float* alpha, float* contrib, float* sdf, void* stream) {
     KPN_REQUIRE(rgba && z && color && depth && alpha && sdf, "null pointer");
     KPN_REQUIRE(S >= 1 && S <= 64 * KPN_MAX_PER_LANE, "samples per ray out of range (<= 512)");
     if (R <= 0) return R == 0 ? KPN_OK : fail(KPN_EINVAL, "negative ray count");
-    const int64_t blocks = (R + 3) / 4;  // 4 waves per block, one ray per wave per iteration
-    KPN_LAUNCH(k_rgba2out, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), stream, R, (int)S, rgba, z, color,
-               depth, alpha, contrib, sdf, (const int16_t*)nullptr, (const float*)nullptr, 0);
+    launch_rgba2out(stream, R, (int)S, rgba, z, color, depth, alpha, contrib, sdf, nullptr, nullptr, 0);
     return check_launch("kpn_rgba2out");
 }
 // compositor over the merged list of the fine pass, read in place from the coarse and the new samples' records
 static int rgba2out_merged(const float* rgba_c, const float* rgba_n, const int16_t* src, const float* z, int64_t R, int Sc, int Sf,
                            float* color, float* depth, float* alpha, float* sdf, void* stream) {
-    const int64_t blocks = (R + 3) / 4;
-    KPN_LAUNCH(k_rgba2out, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), stream, R, Sc + Sf, rgba_c, z, color,
-               depth, alpha, (float*)nullptr, sdf, src, rgba_n, Sc);
+    launch_rgba2out(stream, R, Sc + Sf, rgba_c, z, color, depth, alpha, nullptr, sdf, src, rgba_n, Sc);
     return check_launch("kpn_render_rays");
 }
 

@@ -195,7 +195,12 @@ __global__ void k_coarse_z(int64_t R, int S, const float* __restrict__ near_i, c
 // rgba2out (model.py:1150-1176): one wavefront per ray.  Lane l owns the contiguous samples
 // [l*per, (l+1)*per); the exclusive transmittance prod_{j<i}(1-c_j) is a 64-lane product scan of the
 // per-lane products, the four weighted sums are butterfly reductions.
+// A ray's loads (records, depths) are issued one ray ahead of its arithmetic: the kernel is latency-bound (a dependent
+// chain of loads, a 6-step scan and 6-step reductions per ray), so the next ray's memory latency hides under them.
 #define KPN_MAX_PER_LANE 8  // supports S <= 512
+template <int PER>
+struct kpn_ray_samples { float sig[PER], sd[PER], cr[PER], cg[PER], cb[PER], z[PER], dist[PER]; };
+template <int PER>
 __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float* __restrict__ rgba,
                                                   const float* __restrict__ z, float* __restrict__ color,
                                                   float* __restrict__ depth, float* __restrict__ alpha,
@@ -206,26 +211,38 @@ __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float*
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int per = (S + 63) / 64;
-    for (int64_t r = wave; r < R; r += nwaves) {
+    const int per = (S + 63) / 64;   // <= PER
+    auto load = [&](int64_t r, kpn_ray_samples<PER>& o) {
         const float* zz = z + r * S;
-        auto record = [&](int i) -> const float* {
-            if (!src) return rgba + (r * S + i) * 5;
-            const int id = src[r * S + i];
-            return id < Sc ? rgba + (r * Sc + id) * 5 : rgba_new + (r * (S - Sc) + (id - Sc)) * 5;
-        };
-        float c[KPN_MAX_PER_LANE];
-        const float* qk[KPN_MAX_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = lane * per + k;
+            o.sig[k] = 0.0f; o.sd[k] = 0.0f; o.cr[k] = 0.0f; o.cg[k] = 0.0f; o.cb[k] = 0.0f; o.z[k] = 0.0f; o.dist[k] = 0.0f;
+            if (k < per && i < S) {
+                const float* q;
+                if (!src) q = rgba + (r * S + i) * 5;
+                else {
+                    const int id = src[r * S + i];
+                    q = id < Sc ? rgba + (r * Sc + id) * 5 : rgba_new + (r * (S - Sc) + (id - Sc)) * 5;
+                }
+                o.sig[k] = q[0]; o.sd[k] = q[1]; o.cr[k] = q[2]; o.cg[k] = q[3]; o.cb[k] = q[4];
+                o.z[k] = zz[i];
+                o.dist[k] = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;  // :1166
+            }
+        }
+    };
+    kpn_ray_samples<PER> cur{}, nxt{};
+    if (wave < R) load(wave, cur);
+    for (int64_t r = wave; r < R; r += nwaves) {
+        if (r + nwaves < R) load(r + nwaves, nxt);
+        float c[PER];
         float tl = 1.0f;  // product of (1-c) over this lane's samples
 #pragma unroll
-        for (int k = 0; k < KPN_MAX_PER_LANE; ++k) {
+        for (int k = 0; k < PER; ++k) {
             c[k] = 0.0f;
-            qk[k] = rgba;
             const int i = lane * per + k;
             if (k < per && i < S) {
-                qk[k] = record(i);
-                const float dist = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;  // :1166
-                c[k] = 1.0f - expf(-qk[k][0] * dist);                           // :1167
+                c[k] = 1.0f - expf(-cur.sig[k] * cur.dist[k]);  // :1167
                 tl *= (1.0f - c[k]);
             }
         }
@@ -240,15 +257,14 @@ __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float*
         if (lane == 0) T = 1.0f;
         float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_a = 0.f, s_s = 0.f, s_d = 0.f;
 #pragma unroll
-        for (int k = 0; k < KPN_MAX_PER_LANE; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int i = lane * per + k;
             if (k < per && i < S) {
                 const float cw = c[k] * T;  // :1168-1169
                 T *= (1.0f - c[k]);
                 if (contrib) contrib[r * S + i] = cw;
-                const float* q = qk[k];
-                s_r += q[2] * cw; s_g += q[3] * cw; s_b += q[4] * cw;
-                s_a += cw; s_s += q[1] * cw; s_d += zz[i] * cw;
+                s_r += cur.cr[k] * cw; s_g += cur.cg[k] * cw; s_b += cur.cb[k] * cw;
+                s_a += cw; s_s += cur.sd[k] * cw; s_d += cur.z[k] * cw;
             }
         }
 #pragma unroll
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float*
             sdf[r] = s_s / (s_a + 1e-8f);    // :1173
             depth[r] = s_d / (s_a + 1e-8f);  // :1174
         }
+        cur = nxt;
     }
 }
 
