@@ -39,7 +39,12 @@ __device__ __forceinline__ void kpn_sincos(float y, float& s, float& c) {
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
 }
-__device__ __forceinline__ float kpn_elu(float x) { return x > 0.0f ? x : (kpn_fast_exp(x) - 1.0f); }
+__device__ __forceinline__ float kpn_elu(float x) {
+#ifdef KPN_ABLATE_ELU  // timing experiment only: wrong results
+    return x;
+#endif
+    return x > 0.0f ? x : (kpn_fast_exp(x) - 1.0f);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Projection of a world point into source view `tb` (per-view table): reference src/model.py:713-729.
