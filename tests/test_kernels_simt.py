@@ -112,6 +112,23 @@ def test_render_sample_count_extremes(env, step, Sc, Sf):
         assert np.abs(o[k].reshape(-1) - ref[k]).max() < 2e-5, k
 
 
+@pytest.mark.parametrize("S", [1, 7, 65, 130, 257, 512])
+def test_rgba2out_sample_counts(env, S):
+    """Every samples-per-lane specialisation of the compositor (1, 2, 4, 8 per lane; ragged last lanes) vs the oracle."""
+    lib = env[0]
+    rng = np.random.default_rng(S)
+    R = 11
+    rgba = rng.random((R, S, 5), dtype=np.float32)
+    rgba[..., 0] *= rng.random((R, 1), dtype=np.float32) * 40.0
+    rgba[rng.random((R, S)) < 0.3, 0] = 0.0
+    z = np.ascontiguousarray(np.sort(2.0 + 3.0 * rng.random((R, S), dtype=np.float32), axis=-1))
+    color, depth, alpha, contrib, sdf = (np.zeros(s, np.float32) for s in ((R, 3), R, R, (R, S), R))
+    lib.check(lib.kpn_rgba2out(sh.ptr(rgba), sh.ptr(z), R, S, sh.ptr(color), sh.ptr(depth), sh.ptr(alpha), sh.ptr(contrib), sh.ptr(sdf), None))
+    ref = oracle.rgba2out(rgba, z)
+    for name, a, b, tol in zip(("color", "depth", "alpha", "contrib", "sdf"), (color, depth, alpha, contrib, sdf), ref, (5e-6, 3e-5, 5e-6, 3e-6, 3e-5)):
+        assert np.abs(a - b).max() <= tol, name
+
+
 def test_output_kernels(env):
     import ctypes
     import os
