@@ -118,7 +118,8 @@ def test_full_frame_equals_reference_tiles(ops, golden_weights):
                                                             (2, "ellipsoid", (64, 64), (16, 16), 72, 96),   # > 64 samples per pass
                                                             (3, "dense", (64, 64), (9, 7), 128, 128),        # maximum sample counts
                                                             (3, "dense", (64, 64), (9, 7), 3, 1),            # minimum sample counts
-                                                            (3, "ellipsoid", (64, 64), (13, 11), 64, 7)])    # odd ray count, few new samples
+                                                            (3, "ellipsoid", (64, 64), (13, 11), 64, 7),     # odd ray count, few new samples
+                                                            (16, "dense", (48, 48), (10, 10), 8, 8)])         # the largest view count
 def test_render_vs_oracle(ops, n_views, mask, src_hw, tar_hw, Sc, Sf):
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
     from oracle import oracle
