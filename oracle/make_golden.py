@@ -432,6 +432,9 @@ def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     net = ref_shim.build_reference_net(seed=0)
     perturb_reference_net(net, seed=7)
+    if "--only-nofgmask" in sys.argv:  # add case M without rewriting the other (unchanged) files
+        run_nofgmask_case(net)
+        return
     sd = {k: _np(v) for k, v in net.state_dict().items() if k.startswith(HOT_PREFIXES)}
     np.savez_compressed(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"), **sd)
     print("weights:", sum(v.size for v in sd.values()), "floats")
@@ -453,6 +456,17 @@ def main():
     # seeds chosen for informative dropout patterns: k = coarse all views / fine drops view 1; l = nothing dropped
     run_train_grad_case(net, "case_k_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=6)
     run_train_grad_case(net, "case_l_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=10)
+    run_nofgmask_case(net)
+
+
+def run_nofgmask_case(net):
+    # M: model_cfg['disable_fg_mask'] = True (src/model.py:566, 734-735) on a scene whose fg masks are NOT all ones: the
+    # masks must be ignored, only the frustum test decides validity
+    net.disable_fg_mask = True
+    try:
+        run_case(net, "case_m_v3_nofgmask", 3, (64, 64), (24, 24), "ellipsoid", 1, (0, 0), 8, 8, seed=14)
+    finally:
+        net.disable_fg_mask = False
 
 
 if __name__ == "__main__":

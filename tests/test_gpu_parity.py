@@ -611,3 +611,21 @@ def test_rgba2out_sample_counts_vs_oracle(ops, S):
     ref = oracle.rgba2out(rgba, z)
     for name, a, b, tol in zip(("color", "depth", "alpha", "contrib", "sdf"), got, ref, (5e-6, 3e-5, 5e-6, 3e-6, 3e-5)):
         assert np.abs(a.cpu().numpy().reshape(b.shape) - b).max() <= tol, name
+
+
+def test_disable_fg_mask_vs_golden(ops, golden_weights):
+    """PreparedScene(disable_fg_mask=True) = model_cfg['disable_fg_mask'] (reference src/model.py:566, 734-735): golden
+    case M, recorded from the reference with the flag set on an ellipsoid-mask scene."""
+    scene, cfg, g = load_case("case_m_v3_nofgmask")
+    s = _cuda(scene)
+    ps = ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"], disable_fg_mask=True)
+    out, valid = ops.query(ps, golden_weights[1], torch.from_numpy(g["query.0.pts"]).cuda(), torch.from_numpy(g["query.0.view"]).cuda())
+    v = g["query.0.valid"][0].reshape(-1)
+    assert (valid.cpu().numpy() == g["query.0.valid"]).all()
+    assert np.abs(out.cpu().numpy()[0] - g["query.0.out"][0])[v].max() < 2e-5
+    pix, (ny, nx) = pixel_list(cfg, scene["cam_tar"])
+    step = 2 ** (cfg["level"] - 1)
+    res = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny),
+                          n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+    for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+        assert np.abs(res[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, k

@@ -442,3 +442,22 @@ def test_ssim_kernel(env):
     assert abs(out[0] - 1.0) < 1e-7
     assert lib.kpn_ssim_scratch_bytes(6, 20) == 0
     assert lib.kpn_ssim(sh.ptr(pred), sh.ptr(gt), H, W, 0, 0, W + 1, H, sh.ptr(out), sh.ptr(scratch), None) != 0
+
+
+def test_disable_fg_mask(env):
+    """kpn_scene_desc.disable_fg_mask (reference src/model.py:734-735) on the emulator vs golden case M."""
+    lib, packed, _ = env
+    scene, cfg, g = load_case("case_m_v3_nofgmask")
+    hs = sh.HostScene(lib, scene, disable_fg_mask=True)
+    pts, view = g["query.0.pts"][0], g["query.0.view"][0]
+    rvalid = g["query.0.valid"][0].reshape(-1)
+    idx = np.sort(np.concatenate([np.nonzero(rvalid)[0][:200], np.nonzero(~rvalid)[0][:60]]))
+    out, valid = sh.query(lib, hs, packed, pts[idx], view[idx], mode=0)
+    assert (valid == rvalid[idx]).all()
+    gold = g["query.0.out"][0][idx]
+    assert (np.abs(out - gold)[valid] / np.maximum(1, np.abs(gold[valid]))).max() < 2e-5
+    step = 2 ** (cfg["level"] - 1)
+    ny, nx = scene["cam_tar"]["height"] // step, scene["cam_tar"]["width"] // step
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (cfg["stride_j"], cfg["stride_i"], step, nx, ny), cfg["Sc"], cfg["Sf"])
+    for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+        assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k

@@ -225,3 +225,23 @@ def test_query_backward_vs_reference_autograd(variant):
     for got, key in ((d_g0, "d_geo0"), (d_g1, "d_geo1"), (d_tx, "d_tex")):
         ref = g[f"{variant}.{key}"]
         assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max(), (key, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_disable_fg_mask_vs_golden(wflat):
+    """model_cfg['disable_fg_mask'] = True (reference src/model.py:566, 734-735): the source fg masks are ignored, only the
+    frustum test decides which points are valid.  Golden case M was recorded with the flag set on an ellipsoid-mask scene."""
+    scene, cfg, g = load_case("case_m_v3_nofgmask")
+    osc = oracle.OracleScene(scene, disable_fg_mask=True)
+    out, valid = oracle.query(osc, wflat, g["query.0.pts"][0], g["query.0.view"][0])
+    ref_out, ref_valid = g["query.0.out"][0], g["query.0.valid"][0].reshape(-1)
+    assert (valid == ref_valid).all() and 0 < valid.sum() < valid.size
+    _, with_mask = oracle.query(oracle.OracleScene(scene), wflat, g["query.0.pts"][0], g["query.0.view"][0])
+    assert with_mask.sum() < valid.sum()  # the flag matters on this scene
+    err = np.abs(out - ref_out) / np.maximum(1.0, np.abs(ref_out))
+    assert err[valid].max() < 1e-5 and err[:, :2].max() < 1e-5
+    pix, _ = pixel_list(cfg, scene["cam_tar"])
+    o = oracle.render_rays(osc, wflat, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=True)
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(o[k] - g["out." + k][0].transpose(1, 2, 0).reshape(-1, 3)).max() < 2e-5, k
+    for k in ("alpha", "alpha_fine"):
+        assert np.abs(o[k] - g["out." + k].reshape(-1)).max() < 2e-5, k
