@@ -82,10 +82,10 @@ class Recorder:
                 del self.net.__dict__[k]
 
 
-def run_case(net, name, n_views, src_hw, tar_hw, mask, level, stride, Sc, Sf, seed, tar_angle=None):
+def run_case(net, name, n_views, src_hw, tar_hw, mask, level, stride, Sc, Sf, seed, tar_angle=None, fine=True):
     scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=tar_hw, mask=mask, seed=seed, tar_angle=tar_angle)
     rec = Recorder(net)
-    cfg = dict(fine=True, uniform=True, sample_per_ray_c=Sc, sample_per_ray_f=Sf,
+    cfg = dict(fine=fine, uniform=True, sample_per_ray_c=Sc, sample_per_ray_f=Sf,
                src_foreground_mask=scene["src_foreground_mask"], bounds=scene["bounds"])
     strd = torch.tensor([[float(stride[0]), float(stride[1])]])  # [[j, i]] as reference src/model.py:920
     with torch.no_grad():
@@ -102,7 +102,7 @@ def run_case(net, name, n_views, src_hw, tar_hw, mask, level, stride, Sc, Sf, se
                 d[f"{stage}.{i}.{k}"] = v
     path = os.path.join(GOLDEN_DIR, name + ".npz")
     np.savez_compressed(path, **d)
-    print(f"{name}: rays={out['alpha'].numel()} alpha_fine mean={float(out['alpha_fine'].mean()):.4f} "
+    print(f"{name}: rays={out['alpha'].numel()} alpha mean={float(out['alpha_fine' if fine else 'alpha'].mean()):.4f} "
           f"valid_c={rec.calls['query'][0]['valid'].mean():.3f} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
     return scene, out
 
@@ -435,6 +435,9 @@ def main():
     if "--only-nofgmask" in sys.argv:  # add case M without rewriting the other (unchanged) files
         run_nofgmask_case(net)
         return
+    if "--only-sigma" in sys.argv:
+        run_sigma_nofine_case(net)
+        return
     sd = {k: _np(v) for k, v in net.state_dict().items() if k.startswith(HOT_PREFIXES)}
     np.savez_compressed(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"), **sd)
     print("weights:", sum(v.size for v in sd.values()), "floats")
@@ -457,6 +460,18 @@ def main():
     run_train_grad_case(net, "case_k_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=6)
     run_train_grad_case(net, "case_l_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=10)
     run_nofgmask_case(net)
+    run_sigma_nofine_case(net)
+
+
+def run_sigma_nofine_case(net):
+    # N: a different keypoint-weight width (sp_args['sigma'], src/spatial.py:112-114) and fine=False (src/model.py:1067:
+    # no importance samples, no fine keys in the out dict)
+    old = net.sp_encoder.kwargs.get("sigma")
+    net.sp_encoder.kwargs["sigma"] = 0.25
+    try:
+        run_case(net, "case_n_v3_sigma_nofine", 3, (64, 64), (24, 24), "ellipsoid", 1, (0, 0), 12, 8, seed=15, fine=False)
+    finally:
+        net.sp_encoder.kwargs["sigma"] = old
 
 
 def run_nofgmask_case(net):

@@ -629,3 +629,21 @@ def test_disable_fg_mask_vs_golden(ops, golden_weights):
                           n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
     for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
         assert np.abs(res[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, k
+
+
+def test_sigma_and_coarse_only_vs_golden(ops, golden_weights):
+    """PreparedScene(sigma=0.25) (sp_args['sigma'], reference src/spatial.py:112-114) and render_rays(fine=False)
+    (src/model.py:1067): golden case N."""
+    scene, cfg, g = load_case("case_n_v3_sigma_nofine")
+    s, ps = _prep(ops, scene, sigma=0.25)
+    out, valid = ops.query(ps, golden_weights[1], torch.from_numpy(g["query.0.pts"]).cuda(), torch.from_numpy(g["query.0.view"]).cuda())
+    v = g["query.0.valid"][0].reshape(-1)
+    assert (valid.cpu().numpy() == g["query.0.valid"]).all()
+    assert np.abs(out.cpu().numpy()[0] - g["query.0.out"][0])[v].max() < 2e-5
+    pix, (ny, nx) = pixel_list(cfg, scene["cam_tar"])
+    step = 2 ** (cfg["level"] - 1)
+    res = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny),
+                          n_coarse=cfg["Sc"], n_fine=cfg["Sf"], fine=False)
+    assert set(res) == {"tex_fg", "depth", "alpha"}
+    for k in ("tex_fg", "alpha"):
+        assert np.abs(res[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, k

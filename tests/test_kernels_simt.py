@@ -461,3 +461,17 @@ def test_disable_fg_mask(env):
     o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (cfg["stride_j"], cfg["stride_i"], step, nx, ny), cfg["Sc"], cfg["Sf"])
     for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
         assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k
+
+
+def test_sigma_and_coarse_only(env):
+    """kpn_scene_desc.sigma = 0.25 and kpn_render_args.fine = 0 on the emulator vs golden case N."""
+    lib, packed, _ = env
+    scene, cfg, g = load_case("case_n_v3_sigma_nofine")
+    hs = sh.HostScene(lib, scene, sigma=0.25)
+    step = 2 ** (cfg["level"] - 1)
+    ny, nx = scene["cam_tar"]["height"] // step, scene["cam_tar"]["width"] // step
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (cfg["stride_j"], cfg["stride_i"], step, nx, ny), cfg["Sc"], cfg["Sf"],
+                  fine=False)
+    for k in ("tex_fg", "alpha"):
+        assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k
+    np.testing.assert_allclose(o["depth"], g["out.depth"][0], rtol=2e-4, atol=2e-4)

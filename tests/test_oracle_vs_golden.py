@@ -245,3 +245,22 @@ def test_disable_fg_mask_vs_golden(wflat):
         assert np.abs(o[k] - g["out." + k][0].transpose(1, 2, 0).reshape(-1, 3)).max() < 2e-5, k
     for k in ("alpha", "alpha_fine"):
         assert np.abs(o[k] - g["out." + k].reshape(-1)).max() < 2e-5, k
+
+
+def test_sigma_and_coarse_only_vs_golden(wflat):
+    """sp_args['sigma'] = 0.25 instead of 0.1 (keypoint weights, reference src/spatial.py:112-114) and fine=False
+    (src/model.py:1067: coarse pass only).  Golden case N."""
+    scene, cfg, g = load_case("case_n_v3_sigma_nofine")
+    osc = oracle.OracleScene(scene, sigma=0.25)
+    out, valid = oracle.query(osc, wflat, g["query.0.pts"][0], g["query.0.view"][0])
+    ref_out, ref_valid = g["query.0.out"][0], g["query.0.valid"][0].reshape(-1)
+    assert (valid == ref_valid).all() and 0 < valid.sum() < valid.size
+    err = np.abs(out - ref_out) / np.maximum(1.0, np.abs(ref_out))
+    assert err[valid].max() < 1e-5
+    other, _ = oracle.query(oracle.OracleScene(scene), wflat, g["query.0.pts"][0], g["query.0.view"][0])
+    assert np.abs(other - ref_out)[valid].max() > 1e-3  # sigma matters
+    assert "out.alpha_fine" not in g and "query.1.out" not in g  # the reference ran the coarse pass only
+    pix, _ = pixel_list(cfg, scene["cam_tar"])
+    o = oracle.render_rays(osc, wflat, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=False)
+    assert np.abs(o["tex_fg"] - g["out.tex_fg"][0].transpose(1, 2, 0).reshape(-1, 3)).max() < 2e-5
+    assert np.abs(o["alpha"] - g["out.alpha"].reshape(-1)).max() < 2e-5
