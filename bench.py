@@ -8,7 +8,8 @@ coarse pass, bit-identical outputs), synthetic seeded scene + random-init hot-pa
 step: scene preparation (NCHW -> channels-last), ray set-up, coarse field pass, compositing, importance
 resampling, fine field pass, compositing, planar image write.  Inputs are resident in HBM before the
 timed region.  With --gpus N every rank renders its own target camera per step (frames of a render job
-shard over ranks, weak scaling) and the finished RGB images are all-gathered over RCCL.
+shard over ranks, weak scaling) and the finished RGB images are gathered to rank 0 over RCCL; `--gpus N` run
+directly (no launcher) starts the N ranks itself.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel k_geo_rows (fp32
 MFMA bound; duration measured live with HIP events on the launch stream, see kpn_profile_*), and
@@ -87,19 +88,45 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
                       f"samples/ray, {dt:.1f} s of wall time, C oracle with OpenMP over points on {os.cpu_count()} hardware threads"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 and hand its exit status back.  Under an external launcher (the driver's
+    `python -m torch.distributed.run ... bench.py --gpus N`) WORLD_SIZE is already set and this is skipped."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for RCCL between processes on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to report a "
+                 f"number for a different GPU count")
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
+            if torch.cuda.device_count() < world:
+                sys.exit(f"bench.py: --gpus {world} needs {world} visible GPUs (found {torch.cuda.device_count()}); "
+                         f"--dist-backend gloo runs all ranks on cuda:0 for flow tests only")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -107,7 +134,7 @@ def main():
 
     from keypointnerf_amd import lib as kl
     from keypointnerf_amd import ops
-    from keypointnerf_amd.parallel import orbit_target_camera
+    from keypointnerf_amd.parallel import gather_frames_to_root, orbit_target_camera
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
 
     if args.no_coarse_reuse:
@@ -127,7 +154,9 @@ def main():
     ref_evals_per_ray = args.samples * (3 if fine else 1)          # the reference: Sc coarse + (Sc + Sf) fine
     evals_per_ray = args.samples * (2 if fine and not args.no_coarse_reuse else (3 if fine else 1))   # performed here
     plan = ops.RenderPlan(ps, (0, 0, 1, res, res), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
-    gather_buf = torch.empty(world, 3, res, res, device=dev) if world > 1 else None
+    gather_buf = None
+    if world > 1 and rank == 0:     # destination of the job's only exchange (rank 0 receives every rank's frame)
+        gather_buf = torch.empty(world, 3, res, res, device=dev if args.dist_backend == "nccl" else "cpu")
 
     def step(i):
         # frame i of the job: rank r renders target camera (i*world + r) of the orbit
@@ -135,13 +164,9 @@ def main():
         L.check(L.kpn_scene_prepare(ctypes.byref(ps.desc), ctypes.c_void_p(ps.ws.data_ptr()),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         out = ops.render_rays(ps, w, cam_tar, scene["bounds"], plan=plan)
-        if world > 1:  # the job's only exchange: finished RGB frames (3 MB each)
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(gather_buf, out["tex_fg_fine" if fine else "tex_fg"][0])
-            else:
-                host = out["tex_fg_fine" if fine else "tex_fg"][0].cpu()
-                bucket = [torch.empty_like(host) for _ in range(world)]
-                dist.all_gather(bucket, host)
+        if world > 1:  # the job's only exchange: finished RGB frames (3 MB each) gathered to rank 0
+            img = out["tex_fg_fine" if fine else "tex_fg"][0]
+            gather_frames_to_root(img if args.dist_backend == "nccl" else img.cpu(), world, rank, into=gather_buf)
         return out
 
     for i in range(args.warmup):
@@ -195,7 +220,10 @@ def main():
                                 "--no-coarse-reuse evaluates them again like the reference") if evals_per_ray != ref_evals_per_ray else "",
                        "sampled_points_per_sec": value * evals_per_ray,
                        "valid_rows_per_step": rows.value / max(1, args.steps),
-                       "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s)"},
+                       "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s), one process per GPU"
+                                      + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
+                       "dist_world_size": (dist.get_world_size() if world > 1 else 1),
+                       "dist_backend": (args.dist_backend if world > 1 else None)},
             "roofline": {"kernel": "k_geo_rows" if args.geo_rows_mode == 0 else "k_geo_rows_h", "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),

@@ -112,8 +112,8 @@ int kpn_rgba2out(const float* rgba, const float* z, int64_t n_rays, int32_t n_sa
 
 /* Backward of rgba2out (what torch autograd derives from src/model.py:1162-1174): given the forward inputs and the
  * upstream gradients of color (R,3), depth (R), alpha (R), sdf (R) (any may be NULL = zero), writes d_rgba (R,S,5).
- * z carries no gradient in the reference (sample positions are drawn under no_grad, :1038,1118).  First piece of the
- * training backward; the field-evaluation backward is not built yet. */
+ * z carries no gradient in the reference (sample positions are drawn under no_grad, :1038,1118).  The compositor piece of
+ * the training backward; kpn_render_rays_train_backward chains it with the field reverse. */
 int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t n_rays, int32_t n_samples, const float* d_color,
                           const float* d_depth, const float* d_alpha, const float* d_sdf, float* d_rgba, void* stream);
 
@@ -129,7 +129,7 @@ int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t n_rays, int
  *   d_geo0 (V, geo0_h, geo0_w, 64), d_geo1 (V, geo1_h, geo1_w, 8): += gradient w.r.t. the feature maps,
  *        CHANNELS-LAST (permute to NCHW to hand it to the encoder's backward).
  * Accumulating: the caller zeroes the three outputs.  Float atomics: the summation order is not deterministic.
- * The second piece of the training backward after kpn_rgba2out_backward; pooling / layers2 / colour head: next. */
+ * The layers1 piece of the training backward; pooling / layers2 / colour head: kpn_query_backward. */
 size_t kpn_geo_rows_backward_workspace_bytes(int64_t n_points, int32_t n_views);
 int kpn_geo_rows_backward(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights, int64_t n_points,
                           const float* pts, uint32_t keep_mask, const float* d_x, float* d_plain, float* d_geo0,
@@ -139,7 +139,7 @@ int kpn_geo_rows_backward(const kpn_scene_desc* desc, const void* scene_ws, cons
  * [sigma = mask*relu(rad + noise), sdf] (mode 1, src/model.py:981-996) — i.e. loss.backward() of training_step
  * (src/model.py:128-155) through view pooling, MLPUNetFusion.layers2 (src/utils.py:500-518, 612-647, 722-748), and
  * then layers1 + the feat_geo gathers as kpn_geo_rows_backward.  d_out (N,5): columns 0,1 are used; the colour
- * columns 2..4 are NOT propagated yet (ibr_compress_gfeat / IBRRenderingHead / feat_tex reverse: next).
+ * columns 2..4 are ignored by THIS entry point (kpn_query_backward propagates all five).
  * Masked points contribute nothing in mode 1 (mask = 0); in mode 0 their constant layers2(0) output is not
  * differentiated either (training uses mode 1).  noise (N) / noise_std: the density noise added before the relu.
  * Outputs accumulate like kpn_geo_rows_backward's (d_plain: layers1 and layers2 blocks). */

@@ -10,14 +10,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_lib", "libkpnerf_hip.so")
-SOURCES = ["kpn_api.hip", "ray_kernels.hip", "field_kernels.hip", "kpn_device.h", "kpn_common.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "kpnerf.h")]
+    # every file under csrc/ is part of the one translation unit kpn_api.hip (it #includes the other .hip files)
+    deps = [os.path.join(CSRC, s) for s in sorted(os.listdir(CSRC)) if s.endswith((".hip", ".h"))]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "kpnerf.h"))
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 

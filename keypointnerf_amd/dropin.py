@@ -4,18 +4,26 @@ The reference has no plugin interface; its hot path is reached through attribute
 object: ``net.batch_render_pifu_nerf`` (reference src/model.py:866,922),
 ``net.query`` (:979), ``net.ray_bbox_intersection`` (:1039), ``net.rgba2out`` (:1065,1085),
 ``net.importance_sample`` (:1075) and, one level up, ``net.render_pifu_nerf`` (:453).  ``install(net)``
-rebinds exactly those attributes on a live ``KeypointNeRF`` instance — same names, same argument lists,
-same return conventions — and leaves the module tree / parameter names (checkpoint format) untouched:
-weights are read from ``net.state_dict()`` and re-packed whenever a parameter changes.
+rebinds exactly those attributes on a live ``KeypointNeRF`` instance — same names, same argument lists
+(the reference calls both render methods with ``net=`` by keyword, :454 and :866), same return
+conventions — and leaves the module tree / parameter names (checkpoint format) untouched: weights are
+read from the live parameters and re-packed whenever one changes.
 
-Eval path (``net.training == False``, ``uniform=True`` sampling as used by render_full_nerf_image,
-src/model.py:453-473): ``kpn_render_rays``.  Training path (``net.training == True``, batch size 1 as
-configs/zju.json:12): ``batch_render_pifu_nerf`` draws the patch centre, the stratified jitter, the
-view-dropout masks, the density noise and the importance ``u`` with the same calls, shapes and order as the reference
-(src/model.py:1008-1017, 1049-1053, 742-748, 993-994, 1129), renders with ``kpn_render_rays_train`` and is
-differentiable: ``loss.backward()`` runs ``kpn_render_rays_train_backward`` and reaches ``weight_g`` / ``weight_v`` /
-``bias`` / ``ani_al`` and the image encoders (through ``feat_geo`` / ``feat_tex``) by autograd.  Anything outside that
-envelope (larger batches, more views, ``separate_cf``) is forwarded to the reference's own method — that is the
+Served by the library (batch size 1, as configs/zju.json:12 and src/model.py:938,1191):
+
+* eval, ``uniform=True`` (render_full_nerf_image, src/model.py:453-473): ``kpn_render_rays``;
+* eval, ``uniform=False`` (validation_step -> KeypointNeRF.forward in eval mode, src/model.py:509-526 with
+  dr_kwargs of configs/zju.json:101-108): strided pixel grid, stratified jitter, density noise and random
+  importance samples drawn with the reference's calls in the reference's order, no view dropout
+  (src/model.py:742 is train-only): ``kpn_render_rays_train`` with every view kept;
+* train (``net.training``): patch centre, jitter, view-dropout masks, density noise and importance ``u`` drawn
+  as the reference does (src/model.py:1008-1017, 1049-1053, 742-748, 993-994, 1129); differentiable:
+  ``loss.backward()`` runs ``kpn_render_rays_train_backward`` and reaches ``weight_g`` / ``weight_v`` / ``bias`` /
+  ``ani_al`` and the image encoders (through ``feat_geo`` / ``feat_tex``) by autograd
+  (``torch.ops.kpnerf.render_rays_train``, keypointnerf_amd/torch_ops.py).
+
+Anything outside that envelope (larger batches, ``separate_cf``, a spatial encoder other than the shipped
+``rel_z_decay``) is refused at ``install`` time or forwarded to the reference's own method — that is the
 reference itself, not a fallback of this library.
 """
 import types
@@ -27,34 +35,45 @@ from . import ops
 from .weights import plain_tensor_from_module
 
 _OUT_KEYS = ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")
-
-
-class _TrainRender(torch.autograd.Function):
-    """kpn_render_rays_train / kpn_render_rays_train_backward as one differentiable op.  Differentiable inputs: the
-    flat effective-parameter vector and the three feature maps; everything else (cameras, draws) rides in `cfg`."""
-
-    @staticmethod
-    def forward(ctx, plain, geo0, geo1, tex, cfg):
-        scene = ops.PreparedScene(cfg["img"], cfg["cam"], [geo0.detach(), geo1.detach()], tex.detach(), cfg["sp_data"],
-                                  cfg["fg_mask"], disable_fg_mask=cfg["disable_fg_mask"], sigma=cfg["sigma"])
-        w = ops.PackedWeights.from_plain(plain, device=geo0.device)
-        out = ops.render_rays_train(scene, w, cfg["tar"], cfg["bounds"], cfg["pix"], cfg["u_c"], cfg["u_f"], cfg["keep_c"],
-                                    cfg["keep_f"], noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"],
-                                    rand_noise_std=cfg["noise_std"], n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
-        ctx.scene, ctx.w, ctx.cfg = scene, w, cfg
-        return tuple(out[k].clone() for k in _OUT_KEYS)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        cfg = ctx.cfg
-        g = {k: (None if gi is None else gi.contiguous()) for k, gi in zip(_OUT_KEYS, grads)}
-        d_plain, d_g0, d_g1, d_tx = ops.render_rays_train_backward(
-            ctx.scene, ctx.w, cfg["tar"], cfg["bounds"], cfg["pix"], cfg["u_c"], cfg["u_f"], cfg["keep_c"], cfg["keep_f"], g,
-            noise_coarse=cfg["noise_c"], noise_fine=cfg["noise_f"], rand_noise_std=cfg["noise_std"], n_coarse=cfg["Sc"],
-            n_fine=cfg["Sf"])
-        return d_plain, d_g0.contiguous(), d_g1.contiguous(), d_tx.contiguous(), None
-
 _SEAMS = ("batch_render_pifu_nerf", "render_pifu_nerf", "query", "rgba2out", "importance_sample", "ray_bbox_intersection")
+_HOT_PREFIXES = ("mlp_geo.", "mlp_tex.", "ibr_compress_gfeat.")
+
+
+def _version_key(tensors):
+    """(identity, version) key of a list of tensors, or None when a version counter is unavailable (inference
+    tensors — Lightning runs validate/test under torch.inference_mode — raise on ._version)."""
+    key = []
+    for t in tensors:
+        if t is None:
+            key.append(None)
+            continue
+        if t.is_inference():
+            return None
+        key.append((id(t), t.data_ptr(), t._version, tuple(t.shape)))
+    return tuple(key)
+
+
+def check_supported(net):
+    """The kernels implement the shipped configuration (reference configs/zju.json:39-45): keypoint-relative depth
+    encoding with Gaussian decay, 3 octaves, 24 keypoints, scale 1.  A model built with another SpatialEncoder
+    branch of the same feature width would pass the weight-shape check and render silently wrong: refuse it."""
+    enc = getattr(net, "sp_encoder", None)
+    if enc is None:
+        return
+    want = {"sp_type": "rel_z_decay", "sp_level": 3, "n_kpt": 24}
+    for k, v in want.items():
+        got = getattr(enc, k, v)
+        if got != v:
+            raise NotImplementedError(f"keypointnerf_amd serves sp_encoder.{k} == {v!r} only (got {got!r}; "
+                                      f"reference src/spatial.py:88-133 has other branches, configs/zju.json selects this one)")
+    if float(getattr(enc, "scale", 1.0)) != 1.0:
+        raise NotImplementedError("keypointnerf_amd serves sp_encoder.scale == 1.0 only (configs/zju.json:42)")
+
+
+def encoder_sigma(net):
+    """sp_args['sigma'] of the live module; the reference's fallback is 150.0 (src/spatial.py:112)."""
+    enc = getattr(net, "sp_encoder", None)
+    return float(getattr(enc, "kwargs", {}).get("sigma", 150.0)) if enc is not None else 150.0
 
 
 class _State:
@@ -62,35 +81,82 @@ class _State:
         self.net = net
         self.weights = None
         self.weights_key = None
-        self.scene = None
-        self.scene_key = None
         self.plans = {}
+        self.feats = None            # (key, img, feat_geo, feat_tex): encoder outputs of the last source set
 
     def packed_weights(self):
-        params = [p for n, p in self.net.named_parameters() if n.startswith(("mlp_geo.", "mlp_tex.", "ibr_compress_gfeat."))]
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if key != self.weights_key:
+        params = [p for n, p in self.net.named_parameters() if n.startswith(_HOT_PREFIXES)]
+        key = _version_key(params)
+        if key is None or key != self.weights_key:
             dev = params[0].device if params and params[0].is_cuda else "cuda"
-            self.weights = ops.PackedWeights(self.net.state_dict(), device=dev)
+            # packed on the device from the live parameters (weight-norm fold + MFMA operand order): no host round trip
+            with torch.no_grad():
+                self.weights = ops.PackedWeights.from_plain(plain_tensor_from_module(self.net).to(dev), device=dev)
             self.weights_key = key
         return self.weights
 
     def prepared_scene(self, img, cam, feat_geo, feat_tex, sp_data, fg_mask):
-        tensors = [img, cam["KRT"], feat_geo[0], feat_geo[1], feat_tex, sp_data["kpt3d"], fg_mask]
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
-        if key != self.scene_key:
-            enc = getattr(self.net, "sp_encoder", None)
-            sigma = float(getattr(enc, "kwargs", {}).get("sigma", 0.1)) if enc is not None else 0.1  # configs/zju.json:43
-            self.scene = ops.PreparedScene(img, cam, feat_geo, feat_tex, sp_data, fg_mask,
-                                           disable_fg_mask=getattr(self.net, "disable_fg_mask", False), sigma=sigma)
-            self.scene_key = key
-            self.plans = {}
-        return self.scene
+        """A fresh PreparedScene per call: kpn_scene_prepare is ~0.1 ms next to a render of tens of ms, and keying a
+        cache on data_ptr/_version is unsafe (inference tensors have no version counter; a recycled address with the
+        same shape would serve a stale workspace).  PreparedScene keeps every input tensor alive."""
+        if "transf" in cam:
+            raise NotImplementedError("cam['transf'] (src/model.py:716-718) is not produced by decode_batch and not served")
+        return ops.PreparedScene(img, cam, feat_geo, feat_tex, sp_data, fg_mask,
+                                 disable_fg_mask=getattr(self.net, "disable_fg_mask", False), sigma=encoder_sigma(self.net))
+
+    def plan(self, scene, grid, Sc, Sf, fine):
+        """Render plans (outputs + workspace) are reused across calls with the same geometry; the outputs handed to
+        the caller are clones, so the reference's "new tensors out" contract holds."""
+        d = scene.desc
+        key = (tuple(grid), Sc, Sf, fine, d.n_views, d.src_h, d.src_w, d.geo0_h, d.geo0_w, d.geo1_h, d.geo1_w, d.tex_h, d.tex_w,
+               str(scene.ws.device))
+        plan = self.plans.get(key)
+        if plan is None:
+            if len(self.plans) >= 4:
+                self.plans.clear()
+            plan = self.plans[key] = ops.RenderPlan(scene, grid, Sc, Sf, fine=fine)
+        return plan
+
+    def encoder_features(self, img_in):
+        """feat_geo / feat_tex of the source images.  render_novel_views runs both encoders once per source set
+        (attach_im_feat, src/model.py:479) and render_pifu_nerf then runs them AGAIN for every target camera
+        (:913-914) — 28 M parameters of convolutions per orbit frame for identical inputs.  In eval mode the encoders
+        are deterministic, so their outputs are kept per (source images, encoder parameters) and reused."""
+        net = self.net
+        if net.training or (torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())):
+            return net.attach_geo_feat(img_in, return_val=True), net.attach_tex_feat(img_in, return_val=True)
+        enc_params = [p for n, p in net.named_parameters() if n.startswith(("geo_encoder.", "tex_encoder."))]
+        key = _version_key([img_in] + enc_params)
+        if self.feats is not None:
+            k0, img0, g0, t0 = self.feats
+            same = (key is not None and key == k0) or (key is None and k0 is None and img0.shape == img_in.shape
+                                                       and torch.equal(img0, img_in))
+            if same:
+                return g0, t0
+        g = net.attach_geo_feat(img_in, return_val=True)
+        t = net.attach_tex_feat(img_in, return_val=True)
+        # versioned tensors: the strong reference pins identity; inference tensors: a clone pins the content
+        self.feats = (key, img_in if key is not None else img_in.clone(), g, t)
+        return g, t
+
+
+def _draw_keep_bits(n_views, dev):
+    """Per-view dropout of one query call, drawn exactly like src/model.py:742-748."""
+    if n_views == 1:
+        return 1
+    d = torch.zeros(1, n_views, 1, 1, device=dev)
+    d[:, :1] = 1.0
+    d[:, 1:] = (torch.rand_like(d[:, 1:]) > 0.5).float()
+    perm = torch.rand_like(d).argsort(dim=1)
+    k = torch.gather(d, 1, perm).reshape(-1)
+    return int(sum(1 << i for i, x in enumerate(k.tolist()) if x > 0.5))
 
 
 def install(net):
     """Rebinds the hot-path attributes of a reference ``KeypointNeRF`` instance to the HIP operators.
     Returns ``net``.  ``uninstall(net)`` restores the reference's methods."""
+    from . import torch_ops  # noqa: F401  (registers torch.ops.kpnerf.*)
+    check_supported(net)
     st = _State(net)
     cls = type(net)
     ref = {k: getattr(cls, k) for k in _SEAMS if hasattr(cls, k)}
@@ -106,85 +172,84 @@ def install(net):
         scene = st.prepared_scene(tx_data["img"], cam, feat_geo, feat_tex, sp_data, kwargs["src_foreground_mask"])
         return ops.query(scene, st.packed_weights(), pts, view, mode=0)
 
-    def train_render(net_, img_in, cam_in, n_views, cam_tar, tar_img, feat_geo, feat_tex, sp_data, **config):
-        """Train branch of batch_render_pifu_nerf (src/model.py:1008-1108), batch size 1."""
+    def tar_dict(cam_in, cam_tar):
+        return {"K": cam_tar["K"], "RT": cam_tar["RT"], "znear": cam_tar.get("znear", cam_in["znear"]),
+                "zfar": cam_tar.get("zfar", cam_in["zfar"])}
+
+    def gt_gather(out, tar_img, index, config, h, w):                 # src/model.py:1097-1107
+        if tar_img is None:
+            return
+        with torch.no_grad():
+            assert tar_img.shape[0] == index.shape[0]
+            t = tar_img.reshape(*tar_img.shape[:2], -1)
+            out["tar_img"] = torch.gather(t, 2, index[:, None].expand(-1, 3, -1)).view(*t.shape[:2], h, w)
+            if "msk" in config:
+                a = config["msk"].reshape(1, 1, -1)
+                out["tar_alpha"] = torch.gather(a, 2, index[:, None].expand(-1, 1, -1)).view(1, 1, h, w).float()
+
+    def stochastic_render(net, img_in, cam_in, n_views, cam_tar, grids, out_h, out_w, tar_img, feat_geo, feat_tex, sp_data,
+                          dropout, **config):
+        """The `uniform=False` sampling of batch_render_pifu_nerf for the pixels `grids` (R,2): train branch
+        (dropout=True, differentiable) and eval-mode validation (dropout=False)."""
         dev = img_in.device
-        if feat_geo is None:
-            feat_geo = net_.attach_geo_feat(img_in, return_val=True)
-        if feat_tex is None:
-            feat_tex = net_.attach_tex_feat(img_in, return_val=True)
-        width = cam_tar.get("width", cam_in["width"])
-        height = cam_tar.get("height", cam_in["height"])
         Sc, Sf = config.get("sample_per_ray_c", 64), config.get("sample_per_ray_f", 64)
         std = float(config.get("rand_noise_std", 0.0))
-        out_h, out_w = net_.train_out_h, net_.train_out_w
-        # patch around a random foreground pixel, src/model.py:1010-1016 (numpy RNG, as the reference)
-        msk = config["msk"].squeeze()
-        msk_coords = torch.stack(torch.where(msk)[::-1], -1)
-        center = msk_coords[np.random.randint(0, msk_coords.shape[0], 1)]
-        yg, xg = torch.meshgrid(torch.arange(0, out_h, device=dev), torch.arange(0, out_w, device=dev), indexing="ij")
-        grids = torch.stack([xg, yg], -1).view(-1, 2) + (center.to(dev) - out_h // 2)
-        grids = grids.clamp(0, min(width - 1, height - 1))
         R = grids.shape[0]
-        index = (grids[:, 0] + grids[:, 1] * width)[None]
-
-        def keep_bits():                                            # src/model.py:742-748
-            if n_views == 1:
-                return 1
-            d = torch.zeros(1, n_views, 1, 1, device=dev)
-            d[:, :1] = 1.0
-            d[:, 1:] = (torch.rand_like(d[:, 1:]) > 0.5).float()
-            perm = torch.rand_like(d).argsort(dim=1)
-            k = torch.gather(d, 1, perm).reshape(-1)
-            return int(sum(1 << i for i, x in enumerate(k.tolist()) if x > 0.5))
-
+        width = cam_tar.get("width", cam_in["width"])
+        index = (grids[:, 0] + grids[:, 1] * width)[None].long()
+        all_views = (1 << n_views) - 1
         # the reference's draws, in its order: jitter (:1052), coarse dropout (:745-746), coarse noise (:994),
         # importance u (:1129), fine dropout, fine noise
         u_c = torch.rand(1, R, Sc, device=dev)
-        keep_c = keep_bits()
+        keep_c = _draw_keep_bits(n_views, dev) if dropout else all_views
         noise_c = torch.randn(1, R * Sc, 1, device=dev) if std > 0.0 else None
         u_f = torch.rand(1, R, Sf).to(dev)                          # th.rand(...).to(device): a CPU draw, as :1129
-        keep_f = keep_bits()
+        keep_f = _draw_keep_bits(n_views, dev) if dropout else all_views
         noise_f = torch.randn(1, R * (Sc + Sf), 1, device=dev) if std > 0.0 else None
-        enc = getattr(net_, "sp_encoder", None)
-        cfg = dict(img=img_in, cam=cam_in, sp_data=sp_data, fg_mask=config["src_foreground_mask"],
-                   disable_fg_mask=getattr(net_, "disable_fg_mask", False),
-                   sigma=float(getattr(enc, "kwargs", {}).get("sigma", 0.1)) if enc is not None else 0.1,
-                   tar={"K": cam_tar["K"], "RT": cam_tar["RT"], "znear": cam_tar.get("znear", cam_in["znear"]),
-                        "zfar": cam_tar.get("zfar", cam_in["zfar"])},
-                   bounds=config["bounds"], pix=grids.to(torch.int32), u_c=u_c, u_f=u_f, keep_c=keep_c, keep_f=keep_f,
-                   noise_c=noise_c, noise_f=noise_f, noise_std=std, Sc=Sc, Sf=Sf)
-        res = _TrainRender.apply(plain_tensor_from_module(net_), feat_geo[0], feat_geo[1], feat_tex, cfg)
-        out = {}
-        for k, v in zip(_OUT_KEYS, res):                            # (1,3,R) / (1,R) in patch order
-            out[k] = v.view(1, 3, out_h, out_w) if k.startswith("tex") else v.view(1, out_h, out_w)
-        if tar_img is not None:                                     # src/model.py:1097-1107
+        tar = tar_dict(cam_in, cam_tar)
+        fg = config["src_foreground_mask"]
+        extrin = sp_data["extrin"] if "extrin" in sp_data else cam_in["extrin"]
+        if "transf" in cam_in:
+            raise NotImplementedError("cam['transf'] (src/model.py:716-718) is not served")
+        if torch.is_grad_enabled():
+            plain = plain_tensor_from_module(net)
+        else:
             with torch.no_grad():
-                t = tar_img.reshape(*tar_img.shape[:2], -1)
-                out["tar_img"] = torch.gather(t, 2, index[:, None].expand(-1, 3, -1)).view(*t.shape[:2], out_h, out_w)
-                a = config["msk"].reshape(1, 1, -1)
-                out["tar_alpha"] = torch.gather(a, 2, index[:, None].expand(-1, 1, -1)).view(1, 1, out_h, out_w).float()
+                plain = plain_tensor_from_module(net)
+        res = torch.ops.kpnerf.render_rays_train(
+            plain, feat_geo[0], feat_geo[1], feat_tex, img_in, cam_in["KRT"], extrin, sp_data["kpt3d"],
+            None if getattr(net, "disable_fg_mask", False) else fg,
+            [float(cam_in["znear"]), float(cam_in["zfar"]), float(cam_in.get("nml_scale", 100.0)), encoder_sigma(net)],
+            tar["K"], tar["RT"], config["bounds"], float(tar["znear"]), float(tar["zfar"]), grids.to(torch.int32), u_c, u_f,
+            noise_c, noise_f, int(keep_c), int(keep_f), std, int(Sc), int(Sf))
+        out = {}
+        for k, v in zip(_OUT_KEYS, res):                            # (1,3,R) / (1,R) in pixel-list order
+            out[k] = v.view(1, 3, out_h, out_w) if k.startswith("tex") else v.view(1, out_h, out_w)
+        gt_gather(out, tar_img, index, config, out_h, out_w)
         return out
 
-    def batch_render_pifu_nerf(net_, img_in, cam_in, n_views, cam_tar, level=2, stride=0, tar_img=None, feat_geo=None,
+    def batch_render_pifu_nerf(net, img_in, cam_in, n_views, cam_tar, level=2, stride=0, tar_img=None, feat_geo=None,
                                feat_tex=None, sp_data={}, objcenter=None, **config):
-        if net_.training:
-            if (img_in.shape[0] // n_views == 1 and n_views <= 16 and config.get("fine", False) and not config.get("uniform", False)
-                    and not config.get("separate_cf", False) and "msk" in config):
-                return train_render(net_, img_in, cam_in, n_views, cam_tar, tar_img, feat_geo, feat_tex, sp_data, **config)
-            return ref["batch_render_pifu_nerf"](net_, img_in, cam_in, n_views, cam_tar, level, stride, tar_img, feat_geo,
+        def reference():
+            return ref["batch_render_pifu_nerf"](net, img_in, cam_in, n_views, cam_tar, level, stride, tar_img, feat_geo,
                                                  feat_tex, sp_data, objcenter, **config)
-        if not config.get("uniform", False):
-            return ref["batch_render_pifu_nerf"](net_, img_in, cam_in, n_views, cam_tar, level, stride, tar_img, feat_geo,
-                                                 feat_tex, sp_data, objcenter, **config)
-        if img_in.shape[0] // n_views != 1:
-            raise NotImplementedError("eval requires batch size 1 (reference src/model.py:938,1191)")
-        if config.get("separate_cf", False):
-            raise NotImplementedError("separate_cf is not used by configs/zju.json")
+        batch_size = img_in.shape[0] // n_views
+        uniform, fine = bool(config.get("uniform", False)), bool(config.get("fine", False))
+        served = batch_size == 1 and n_views <= 16 and not config.get("separate_cf", False)
+        if net.training:
+            if not (served and fine and not uniform and "msk" in config):
+                return reference()
+        elif not served:
+            if batch_size != 1:
+                raise NotImplementedError("eval requires batch size 1 (reference src/model.py:938,1191)")
+            raise NotImplementedError("separate_cf / more than 16 source views are not used by configs/zju.json")
+        elif not uniform and not fine:
+            return reference()                                       # stratified coarse-only: not a shipped configuration
         if feat_geo is None:
-            feat_geo = net_.attach_geo_feat(img_in, return_val=True)
+            feat_geo = net.attach_geo_feat(img_in, return_val=True)
         if feat_tex is None:
-            feat_tex = net_.attach_tex_feat(img_in, return_val=True)
+            feat_tex = net.attach_tex_feat(img_in, return_val=True)
+        dev = img_in.device
         width = cam_tar.get("width", cam_in["width"])
         height = cam_tar.get("height", cam_in["height"])
         step = 2 ** (level - 1)
@@ -197,36 +262,44 @@ def install(net):
             x0, y0 = int(stride.reshape(-1, 2)[0, 0].item()), int(stride.reshape(-1, 2)[0, 1].item())
         else:
             raise NotImplementedError("unsupported stride type")    # reference src/model.py:1006
+        if net.training:
+            # patch around a random foreground pixel, src/model.py:1008-1017 (numpy RNG, as the reference)
+            out_h, out_w = net.train_out_h, net.train_out_w
+            msk = config["msk"].squeeze()
+            msk_coords = torch.stack(torch.where(msk)[::-1], -1)
+            center = msk_coords[np.random.randint(0, msk_coords.shape[0], 1)]
+            yg, xg = torch.meshgrid(torch.arange(0, out_h, device=dev), torch.arange(0, out_w, device=dev), indexing="ij")
+            grids = torch.stack([xg, yg], -1).view(-1, 2) + (center.to(dev) - out_h // 2)
+            grids = grids.clamp(0, min(width - 1, height - 1))
+            return stochastic_render(net, img_in, cam_in, n_views, cam_tar, grids, out_h, out_w, tar_img, feat_geo, feat_tex,
+                                     sp_data, True, **config)
         nx, ny = width // step, height // step
-        scene = st.prepared_scene(img_in, cam_in, feat_geo, feat_tex, sp_data, config["src_foreground_mask"])
-        tar = {"K": cam_tar["K"], "RT": cam_tar["RT"], "znear": cam_tar.get("znear", cam_in["znear"]),
-               "zfar": cam_tar.get("zfar", cam_in["zfar"])}
-        fine = bool(config.get("fine", False))
-        key = (x0, y0, step, nx, ny, config.get("sample_per_ray_c", 64), config.get("sample_per_ray_f", 64), fine)
-        # a fresh plan per call keeps the reference's "new tensors out" contract; geometry is cached only
-        plan = ops.RenderPlan(scene, key[:5], key[5], key[6], fine=fine)
-        res = ops.render_rays(scene, st.packed_weights(), tar, config["bounds"], plan=plan)
-        out = dict(res)
-        if tar_img is not None:                                     # reference src/model.py:1097-1107
-            ys = torch.arange(ny, device=img_in.device) * step + y0
-            xs = torch.arange(nx, device=img_in.device) * step + x0
-            index = (ys[:, None] * width + xs[None, :]).reshape(1, -1).long()
+        if not uniform:                                              # validation: src/model.py:1018-1022 + :1049-1053
+            yg, xg = torch.meshgrid(torch.arange(0, height, step, device=dev), torch.arange(0, width, step, device=dev), indexing="ij")
+            grids = torch.stack([xg, yg], -1).view(-1, 2) + torch.tensor([x0, y0], device=dev)
             with torch.no_grad():
-                t = tar_img.reshape(*tar_img.shape[:2], -1)
-                out["tar_img"] = torch.gather(t, 2, index[:, None].expand(-1, 3, -1)).view(*t.shape[:2], ny, nx)
-                if "msk" in config:
-                    a = config["msk"].reshape(1, 1, -1)
-                    out["tar_alpha"] = torch.gather(a, 2, index[:, None].expand(-1, 1, -1)).view(1, 1, ny, nx).float()
+                return stochastic_render(net, img_in, cam_in, n_views, cam_tar, grids, ny, nx, tar_img, feat_geo, feat_tex,
+                                         sp_data, False, **config)
+        scene = st.prepared_scene(img_in, cam_in, feat_geo, feat_tex, sp_data, config["src_foreground_mask"])
+        Sc, Sf = config.get("sample_per_ray_c", 64), config.get("sample_per_ray_f", 64)
+        plan = st.plan(scene, (x0, y0, step, nx, ny), Sc, Sf, fine)
+        res = ops.render_rays(scene, st.packed_weights(), tar_dict(cam_in, cam_tar), config["bounds"], plan=plan)
+        out = {k: v.clone() for k, v in res.items()}
+        if tar_img is not None:
+            ys = torch.arange(ny, device=dev) * step + y0
+            xs = torch.arange(nx, device=dev) * step + x0
+            index = (ys[:, None] * width + xs[None, :]).reshape(1, -1).long()
+            gt_gather(out, tar_img, index, config, ny, nx)
         return out
 
-    def render_pifu_nerf(net_, img_in, cam_in, cam_tar, level=5, sp_data={}, bkg_emb=None, camcenter=None, objcenter=None,
+    def render_pifu_nerf(net, img_in, cam_in, cam_tar, level=5, sp_data={}, bkg_emb=None, camcenter=None, objcenter=None,
                          tar_img=None, **config):
         """The reference renders stride^2 strided tiles and re-assembles them with pixel_shuffle
-        (src/model.py:916-938); the same rays are marched here as ONE full-frame pass (step 1)."""
+        (src/model.py:916-938); the same rays are marched here as ONE full-frame pass (step 1).  The encoders are
+        not re-run when the source images are the ones already encoded (:913-914 vs :479)."""
         n_views = img_in.shape[0]
-        feat_geo = net_.attach_geo_feat(img_in, return_val=True)
-        feat_tex = net_.attach_tex_feat(img_in, return_val=True)
-        out = batch_render_pifu_nerf(net_, img_in, cam_in, n_views, cam_tar, 1, 0, tar_img, feat_geo, feat_tex, sp_data,
+        feat_geo, feat_tex = st.encoder_features(img_in)
+        out = batch_render_pifu_nerf(net, img_in, cam_in, n_views, cam_tar, 1, 0, tar_img, feat_geo, feat_tex, sp_data,
                                      objcenter, **config)
         ret = {}
         for k, v in out.items():                                   # same filtering as src/model.py:924-938
@@ -237,12 +310,18 @@ def install(net):
             ret[k] = v.detach().cpu()[0]
         return ret
 
+    def importance_sample(contrib, z, sample_per_ray, uniform=False):
+        u = None
+        if not uniform:                                            # a CPU draw moved to the device, as src/model.py:1129
+            u = torch.rand(*contrib.shape[:-1], sample_per_ray).to(contrib.device)
+        return ops.importance_sample(contrib, z, sample_per_ray, uniform=uniform, u=u)
+
     net._kpnerf_reference_methods = {k: net.__dict__.get(k) for k in _SEAMS}
     net.query = types.MethodType(query, net)
-    net.batch_render_pifu_nerf = batch_render_pifu_nerf            # static in the reference: called as net.f(net, ...)
+    net.batch_render_pifu_nerf = batch_render_pifu_nerf            # static in the reference: called as net.f(net=net, ...)
     net.render_pifu_nerf = render_pifu_nerf
     net.rgba2out = lambda rgba, z: ops.rgba2out(rgba, z)
-    net.importance_sample = lambda contrib, z, n, uniform=False: ops.importance_sample(contrib, z, n, uniform=uniform)
+    net.importance_sample = importance_sample
     net.ray_bbox_intersection = lambda bounds, orig, direct: ops.ray_bbox_intersection(bounds, orig, direct)
     net._kpnerf_state = st
     return net

@@ -391,7 +391,8 @@ def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, ke
     t.keep_coarse, t.keep_fine, t.rand_noise_std = bits(keep_coarse), bits(keep_fine), float(rand_noise_std)
     L.check(L.kpn_render_rays_train(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
                                     _p(plan.ws), plan.nbytes, _stream()))
-    torch.cuda.current_stream().synchronize()  # the small argument tensors above must outlive the launches
+    # no host sync: every launch above is on torch's current stream, and the caching allocator hands a freed block to
+    # later work of the SAME stream only, so the argument tensors may be released as soon as this returns
     return {k: v.reshape(1, *v.shape[1:-2], R) if v.dim() == 4 else v.reshape(1, R) for k, v in plan.out.items()}
 
 
@@ -441,7 +442,7 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
     ws = torch.empty(nb, dtype=torch.uint8, device=dv)
     L.check(L.kpn_render_rays_train_backward(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
                                              ctypes.byref(g), _p(d_plain), _p(d_g0), _p(d_g1), _p(d_tx), _p(ws), nb, _stream()))
-    torch.cuda.current_stream().synchronize()  # the argument tensors above must outlive the launches
+    # no host sync (stream-ordered reuse of freed blocks, see render_rays_train)
     return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2), d_tx.permute(0, 3, 1, 2)
 
 

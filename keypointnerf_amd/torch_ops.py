@@ -11,7 +11,18 @@ calling them on CPU tensors raises NotImplementedError from the dispatcher.
     torch.ops.kpnerf.ray_bbox_intersection(bounds, orig, d)  -> (near, far, hit)
     torch.ops.kpnerf.field_query(scene_ws, scene_dims, scene_scalars, weights, pts, view, mode) -> (out, valid)
 
+    torch.ops.kpnerf.render_rays(scene_ws, scene_dims, scene_scalars, weights, K, RT, bounds, znear, zfar, grid,
+                                 n_coarse, n_fine, fine) -> (tex_fg, depth, alpha, tex_fg_fine, depth_fine, alpha_fine, sdf)
+    torch.ops.kpnerf.render_rays_train(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask?, scene_scalars, K, RT,
+                                       bounds, znear, zfar, pix, u_c, u_f, noise_c?, noise_f?, keep_c, keep_f, noise_std,
+                                       n_coarse, n_fine) -> the same seven outputs, DIFFERENTIABLE
+
 ``scene_ws / scene_dims / scene_scalars`` come from ``ops.PreparedScene.as_op_args()``.
+
+``rgba2out`` and ``render_rays_train`` carry ``register_autograd`` formulas whose backward is itself a registered op
+(``kpnerf::rgba2out_backward``, ``kpnerf::render_rays_train_backward`` = kpn_render_rays_train_backward): gradients reach
+the flat effective-parameter vector ``plain`` (and from there ``weight_g`` / ``weight_v`` / ``bias`` / ``ani_al`` through
+``weights.plain_tensor_from_module``) and the three encoder feature maps.  This is the op the training drop-in calls.
 """
 import ctypes
 from typing import List, Optional, Tuple
@@ -34,6 +45,38 @@ def _(rgba, z):
     B, R, S = z.shape
     f = lambda *s: rgba.new_empty(s)
     return f(B, R, 3), f(B, R), f(B, R), f(B, R, S), f(B, R)
+
+
+@_lib.custom_op("kpnerf::rgba2out_backward", mutates_args=(), device_types="cuda")
+def rgba2out_backward(rgba: torch.Tensor, z: torch.Tensor, d_color: Optional[torch.Tensor], d_depth: Optional[torch.Tensor],
+                      d_alpha: Optional[torch.Tensor], d_sdf: Optional[torch.Tensor]) -> torch.Tensor:
+    L = kl.get_library()
+    q, zz = ops._dev(rgba, "rgba"), ops._dev(z, "z")
+    B, R, S = zz.shape
+    g = [None if x is None else ops._dev(x, "grad") for x in (d_color, d_depth, d_alpha, d_sdf)]
+    d_rgba = torch.empty_like(q)
+    L.check(L.kpn_rgba2out_backward(ops._p(q), ops._p(zz), B * R, S, ops._p(g[0]), ops._p(g[1]), ops._p(g[2]), ops._p(g[3]),
+                                    ops._p(d_rgba), ops._stream()))
+    return d_rgba
+
+
+@rgba2out_backward.register_fake
+def _(rgba, z, d_color, d_depth, d_alpha, d_sdf):
+    return torch.empty_like(rgba)
+
+
+def _rgba2out_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+    ctx.set_materialize_grads(False)
+
+
+def _rgba2out_bwd(ctx, d_color, d_depth, d_alpha, d_contrib, d_sdf):
+    # contrib and z carry no gradient in the reference (the sampler runs under no_grad, src/model.py:1038,1118)
+    rgba, z = ctx.saved_tensors
+    return torch.ops.kpnerf.rgba2out_backward(rgba, z, d_color, d_depth, d_alpha, d_sdf), None
+
+
+rgba2out.register_autograd(_rgba2out_bwd, setup_context=_rgba2out_setup)
 
 
 @_lib.custom_op("kpnerf::importance_sample", mutates_args=(), device_types="cuda")
@@ -82,3 +125,104 @@ def field_query(scene_ws: torch.Tensor, scene_dims: List[int], scene_scalars: Li
 def _(scene_ws, scene_dims, scene_scalars, weights, pts, view, mode):
     N = pts.shape[-2]
     return pts.new_empty(1, N, 5), pts.new_empty(1, N, 1, dtype=torch.bool)
+
+
+_OUT7 = Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]
+_OUT_KEYS = ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")
+
+
+@_lib.custom_op("kpnerf::render_rays", mutates_args=(), device_types="cuda")
+def render_rays(scene_ws: torch.Tensor, scene_dims: List[int], scene_scalars: List[float], weights: torch.Tensor,
+                K: torch.Tensor, RT: torch.Tensor, bounds: torch.Tensor, znear: float, zfar: float, grid: List[int],
+                n_coarse: int, n_fine: int, fine: bool) -> _OUT7:
+    """Eval branch of batch_render_pifu_nerf (kpn_render_rays) for the pixel grid (x0, y0, step, nx, ny).  With
+    fine=False the four fine outputs are empty tensors."""
+    w = ops.PackedWeights.__new__(ops.PackedWeights)
+    w.tensor = weights
+    sv = _SceneView(scene_ws, list(scene_dims), list(scene_scalars))
+    out = ops.render_rays(sv, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, grid=tuple(grid), n_coarse=n_coarse,
+                          n_fine=n_fine, fine=fine)
+    return tuple(out[k] if k in out else scene_ws.new_empty(0) for k in _OUT_KEYS)
+
+
+@render_rays.register_fake
+def _(scene_ws, scene_dims, scene_scalars, weights, K, RT, bounds, znear, zfar, grid, n_coarse, n_fine, fine):
+    nx, ny = grid[3], grid[4]
+    f = lambda *s: scene_ws.new_empty(s)
+    e = lambda *s: f(*s) if fine else f(0)
+    return f(1, 3, ny, nx), f(1, ny, nx), f(1, ny, nx), e(1, 3, ny, nx), e(1, ny, nx), e(1, ny, nx), e(1, ny, nx)
+
+
+def _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
+    V, _, H, W = img.shape
+    cam = {"KRT": KRT, "width": W, "height": H, "znear": scal[0], "zfar": scal[1], "nml_scale": scal[2]}
+    return ops.PreparedScene(img, cam, [geo0, geo1], tex, {"kpt3d": kpt3d, "extrin": extrin}, fg_mask,
+                             disable_fg_mask=fg_mask is None, sigma=scal[3])
+
+
+@_lib.custom_op("kpnerf::render_rays_train", mutates_args=(), device_types="cuda")
+def render_rays_train(plain: torch.Tensor, geo0: torch.Tensor, geo1: torch.Tensor, tex: torch.Tensor, img: torch.Tensor,
+                      KRT: torch.Tensor, extrin: torch.Tensor, kpt3d: torch.Tensor, fg_mask: Optional[torch.Tensor],
+                      scene_scalars: List[float], K: torch.Tensor, RT: torch.Tensor, bounds: torch.Tensor, znear: float,
+                      zfar: float, pix: torch.Tensor, u_c: torch.Tensor, u_f: torch.Tensor, noise_c: Optional[torch.Tensor],
+                      noise_f: Optional[torch.Tensor], keep_c: int, keep_f: int, noise_std: float, n_coarse: int,
+                      n_fine: int) -> _OUT7:
+    """The stochastic (`uniform=False`) branch of batch_render_pifu_nerf with every draw an input (kpn_render_rays_train).
+    plain: flat effective parameters (weights.flatten_plain layout); geo0/geo1/tex: the encoders' NCHW maps; fg_mask None =
+    disable_fg_mask; scene_scalars = [znear, zfar, nml_scale, sigma] of the SOURCE cameras / spatial encoder.
+    Outputs: (1,3,R) / (1,R) tensors in the order of `pix`."""
+    scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
+    w = ops.PackedWeights.from_plain(plain, device=geo0.device)
+    out = ops.render_rays_train(scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f,
+                                noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse,
+                                n_fine=n_fine)
+    return tuple(out[k].clone() for k in _OUT_KEYS)
+
+
+@render_rays_train.register_fake
+def _(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scene_scalars, K, RT, bounds, znear, zfar, pix, u_c, u_f, noise_c,
+      noise_f, keep_c, keep_f, noise_std, n_coarse, n_fine):
+    R = pix.shape[0]
+    f = lambda *s: geo0.new_empty(s)
+    return f(1, 3, R), f(1, R), f(1, R), f(1, 3, R), f(1, R), f(1, R), f(1, R)
+
+
+@_lib.custom_op("kpnerf::render_rays_train_backward", mutates_args=(), device_types="cuda")
+def render_rays_train_backward(plain: torch.Tensor, geo0: torch.Tensor, geo1: torch.Tensor, tex: torch.Tensor, img: torch.Tensor,
+                               KRT: torch.Tensor, extrin: torch.Tensor, kpt3d: torch.Tensor, fg_mask: Optional[torch.Tensor],
+                               scene_scalars: List[float], K: torch.Tensor, RT: torch.Tensor, bounds: torch.Tensor,
+                               znear: float, zfar: float, pix: torch.Tensor, u_c: torch.Tensor, u_f: torch.Tensor,
+                               noise_c: Optional[torch.Tensor], noise_f: Optional[torch.Tensor], keep_c: int, keep_f: int,
+                               noise_std: float, n_coarse: int, n_fine: int, d_tex_fg: Optional[torch.Tensor],
+                               d_depth: Optional[torch.Tensor], d_alpha: Optional[torch.Tensor],
+                               d_tex_fg_fine: Optional[torch.Tensor], d_depth_fine: Optional[torch.Tensor],
+                               d_alpha_fine: Optional[torch.Tensor], d_sdf: Optional[torch.Tensor]
+                               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """loss.backward() through render_rays_train (kpn_render_rays_train_backward) -> (d_plain, d_geo0, d_geo1, d_tex),
+    the map gradients NCHW like the maps."""
+    scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
+    w = ops.PackedWeights.from_plain(plain, device=geo0.device)
+    grads = dict(zip(_OUT_KEYS, (d_tex_fg, d_depth, d_alpha, d_tex_fg_fine, d_depth_fine, d_alpha_fine, d_sdf)))
+    d_plain, d_g0, d_g1, d_tx = ops.render_rays_train_backward(
+        scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f, grads,
+        noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse, n_fine=n_fine)
+    return d_plain, d_g0.contiguous(), d_g1.contiguous(), d_tx.contiguous()
+
+
+@render_rays_train_backward.register_fake
+def _(plain, geo0, geo1, tex, *rest):
+    return torch.empty_like(plain), torch.empty_like(geo0), torch.empty_like(geo1), torch.empty_like(tex)
+
+
+def _train_setup(ctx, inputs, output):
+    ctx.args = inputs                      # tensors and scalars of the forward call (nothing else is kept: the backward
+    ctx.set_materialize_grads(False)       # entry point recomputes z, rgba and the field activations)
+
+
+def _train_bwd(ctx, *grads):
+    d_plain, d_g0, d_g1, d_tx = torch.ops.kpnerf.render_rays_train_backward(
+        *ctx.args, *[None if g is None else g.contiguous() for g in grads])
+    return (d_plain, d_g0, d_g1, d_tx) + (None,) * (len(ctx.args) - 4)
+
+
+render_rays_train.register_autograd(_train_bwd, setup_context=_train_setup)
