@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64, help="coarse = fine samples per ray")
     ap.add_argument("--mask", default="ellipsoid", choices=["ellipsoid", "dense"])
+    ap.add_argument("--tar-focal", type=float, default=800.0,
+                    help="target camera focal length in px at 512 (800 = the subject framed like the reference's orbit, "
+                         "31 %% of the field evaluations valid; 600 = round 1's scene, 17 %%)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (dense mask / round-1 scene / training) results")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
     ap.add_argument("--geo-rows-mode", type=int, default=0, choices=[0, 1],
@@ -86,6 +90,63 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
     return {"value": pix.shape[0] / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"{pix.shape[0]} rays ({n}x{n} lattice, step {step}) of the same frame, {args.samples}+{args.samples} "
                       f"samples/ray, {dt:.1f} s of wall time, C oracle with OpenMP over points on {os.cpu_count()} hardware threads"}
+
+
+def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1):
+    """ms per frame + valid (point, view) rows per frame of one more workload (secondary results)."""
+    ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
+                           scene["src_foreground_mask"])
+    plan = ops.RenderPlan(ps, (0, 0, 1, res, res), samples, samples, fine=fine)
+    for _ in range(warmup):
+        ops.render_rays(ps, w, scene["cam_tar"], scene["bounds"], plan=plan)
+    L.check(L.kpn_profile_enable(1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        L.check(L.kpn_scene_prepare(ctypes.byref(ps.desc), ctypes.c_void_p(ps.ws.data_ptr()),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ops.render_rays(ps, w, scene["cam_tar"], scene["bounds"], plan=plan)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.kpn_profile_collect(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows)))
+    L.check(L.kpn_profile_enable(0))
+    del plan, ps
+    return dt * 1e3, rows.value / steps
+
+
+def time_training(ops, torch, dev, sd, steps=10):
+    """BASELINE configs[3], field part: train-branch forward + backward in HIP for 1024 rays x (64 + 128) samples, V=3
+    (kpn_render_rays_train + kpn_render_rays_train_backward), inputs resident, random draws prepared outside the timed
+    region.  Returns ms per forward and per backward."""
+    from keypointnerf_amd.synthetic import make_scene, to_device
+    scene = to_device(make_scene(n_views=3, src_hw=(512, 512), tar_hw=(512, 512), mask="ellipsoid", seed=1,
+                                 tar_focal_at_512=800.0), dev)
+    ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
+                           scene["src_foreground_mask"])
+    w = ops.PackedWeights(sd, device=dev)
+    R, Sc, Sf = 1024, 64, 64
+    g = torch.Generator(device=dev).manual_seed(0)
+    yy, xx = torch.meshgrid(torch.arange(32, device=dev), torch.arange(32, device=dev), indexing="ij")
+    pix = torch.stack([xx.reshape(-1) + 240, yy.reshape(-1) + 240], -1).to(torch.int32)
+    u_c, u_f = torch.rand(R, Sc, device=dev, generator=g), torch.rand(R, Sf, device=dev, generator=g)
+    n_c, n_f = torch.randn(R * Sc, device=dev, generator=g), torch.randn(R * (Sc + Sf), device=dev, generator=g)
+    grads = {"tex_fg": torch.randn(1, 3, R, device=dev, generator=g) / R, "tex_fg_fine": torch.randn(1, 3, R, device=dev, generator=g) / R}
+    kw = dict(noise_coarse=n_c, noise_fine=n_f, rand_noise_std=0.01, n_coarse=Sc, n_fine=Sf)
+    fwd = lambda: ops.render_rays_train(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, **kw)
+    bwd = lambda: ops.render_rays_train_backward(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, grads, **kw)
+    out = {}
+    for name, fn in (("forward_ms", fwd), ("backward_ms", bwd)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / steps * 1e3
+    out["iterations_per_sec"] = 1e3 / (out["forward_ms"] + out["backward_ms"])
+    out["workload"] = "configs[3] field part: 1024 rays x (64 coarse + 128 fine-pass) evaluations, V=3, view dropout + density noise, fwd + bwd in HIP"
+    return out
 
 
 def launch_ranks(args):
@@ -145,7 +206,8 @@ def main():
     L.check(L.kpn_set_geo_rows_mode(args.geo_rows_mode))
     sd = random_hotpath_state_dict(seed=3)
     res = args.res
-    scene_cpu = make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), mask=args.mask, seed=1)
+    scene_cpu = make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), mask=args.mask, seed=1,
+                           tar_focal_at_512=args.tar_focal)
     scene = to_device(scene_cpu, dev)
     w = ops.PackedWeights(sd, device=dev)
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
@@ -202,6 +264,10 @@ def main():
         if os.path.exists(tj) and launches.value > 0:
             traffic = json.load(open(tj))["hbm_bytes_per_row"] * rows.value / launches.value
         alpha_mean = float(out["alpha_fine" if fine else "alpha"].mean())
+        rows_per_step = rows.value / max(1, args.steps)
+        valid_frac = rows_per_step / (args.views * rays_per_step * evals_per_ray)
+        torch.cuda.synchronize()
+        peak_alloc = torch.cuda.max_memory_allocated(dev)
         peak = BF16_SPLIT_PEAK_TFLOPS if args.geo_rows_mode == 1 else FP32_MFMA_PEAK_TFLOPS
         line = {
             "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray)" if fine else " samples/ray, flat)"),
@@ -219,7 +285,11 @@ def main():
                                 "tests/test_gpu_parity.py::test_fine_pass_reuses_coarse_values_bit_exactly); "
                                 "--no-coarse-reuse evaluates them again like the reference") if evals_per_ray != ref_evals_per_ray else "",
                        "sampled_points_per_sec": value * evals_per_ray,
-                       "valid_rows_per_step": rows.value / max(1, args.steps),
+                       "valid_rows_per_step": rows_per_step,
+                       "valid_fraction_of_field_evaluations": valid_frac,
+                       "fully_evaluated_points_per_sec": value * evals_per_ray * valid_frac,
+                       "render_workspace_bytes": plan.nbytes, "scene_workspace_bytes": ps.ws.numel() * 4,
+                       "peak_device_bytes_allocated": peak_alloc,
                        "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s), one process per GPU"
                                       + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
                        "dist_world_size": (dist.get_world_size() if world > 1 else 1),
@@ -231,8 +301,25 @@ def main():
                          "algorithmic_flop_per_row": flops_row,
                          "kernel_time_share": (ms.value * 1e-3) / dt},
         }
+        if world == 1 and not args.no_secondary:
+            sec = {}
+            # the other mask kind on the same cameras, and round 1's lighter framing (tar focal 600: 17 % valid)
+            other = "dense" if args.mask == "ellipsoid" else "ellipsoid"
+            for name, kw in ((f"{other}_mask", dict(mask=other, tar_focal_at_512=args.tar_focal)),
+                             ("round1_scene_ellipsoid_focal600", dict(mask="ellipsoid", tar_focal_at_512=600.0))):
+                sc2 = to_device(make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), seed=1, **kw), dev)
+                ms2, rows2 = time_frames(L, ops, torch, sc2, w, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
+                sec[name] = {"ms_per_frame": ms2, "rays_per_sec": rays_per_step / (ms2 * 1e-3),
+                             "valid_fraction_of_field_evaluations": rows2 / (args.views * rays_per_step * evals_per_ray)}
+                del sc2
+            if args.views == 3 and args.geo_rows_mode == 0:
+                sec["training_step_configs3"] = time_training(ops, torch, dev, sd)
+            line["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, scene_cpu, sd, fine=fine)
+            rj = os.path.join(ROOT, "profiles", "reference_cpu_pytorch.json")
+            if os.path.exists(rj):   # the unmodified reference (PyTorch CPU), timed where it is mounted: scripts/time_reference_cpu.py
+                line["cpu_baseline"]["reference_pytorch"] = json.load(open(rj))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

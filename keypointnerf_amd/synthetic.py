@@ -50,12 +50,17 @@ def _intrinsics(H, W, focal_at_512=600.0):
 
 
 def make_scene(n_views=3, src_hw=(512, 512), tar_hw=(512, 512), mask="ellipsoid", seed=1,
-               tar_near_far=(2.0, 8.0), tar_angle=None, device="cpu", dtype=torch.float32):
+               tar_near_far=(2.0, 8.0), tar_angle=None, device="cpu", dtype=torch.float32, tar_focal_at_512=600.0):
     """Returns a dict with the tensors/dicts the reference's hot path consumes.
 
     keys: img (V,3,H,W) in [0,1]; feat_geo [list of 2]; feat_tex; cam (source cameras dict);
     cam_tar (target camera dict); sp_data {kpt3d (1,24,3), extrin (V,4,4)}; bounds (1,2,3);
     src_foreground_mask (1,V,1,H,W) bool; n_views.
+
+    tar_focal_at_512: focal length of the TARGET camera in pixels at a 512-wide image.  600 (the sources' focal) leaves the
+    1.8 m subject 70 % of the frame height; 800 frames it like the reference's orbit does (render_video_zju: 1337.6 px at
+    5 m = 94 % of the height, src/model.py:178-187), which is what brings the fraction of valid sample points to the
+    30-40 % SURVEY.md §8(d) specifies for the ellipsoid scene.
     """
     H, W = src_hw
     Ht, Wt = tar_hw
@@ -83,7 +88,7 @@ def make_scene(n_views=3, src_hw=(512, 512), tar_hw=(512, 512), mask="ellipsoid"
     Et = np.eye(4)
     Et[:3, :3] = Rt_
     Et[:3, 3] = tt_
-    Kt = torch.tensor(_intrinsics(Ht, Wt)[None], dtype=dtype)
+    Kt = torch.tensor(_intrinsics(Ht, Wt, tar_focal_at_512)[None], dtype=dtype)
     RTt = torch.tensor(Et[None], dtype=dtype)
     cam_tar = {"K": Kt, "RT": RTt, "KRT": torch.bmm(Kt, RTt), "width": Wt, "height": Ht,
                "nml_scale": 100.0, "znear": float(tar_near_far[0]), "zfar": float(tar_near_far[1])}

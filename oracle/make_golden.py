@@ -107,6 +107,52 @@ def run_case(net, name, n_views, src_hw, tar_hw, mask, level, stride, Sc, Sf, se
     return scene, out
 
 
+def run_headline_case(net, name, n_views, src_hw, mask, level, stride, Sc, Sf, seed, fine=True, n_sub=2048):
+    """One strided tile of a 512x512 target at the sample counts of the BASELINE configs — configs[1]: level 4 (64x64 =
+    4096 rays), Sc = Sf = 64 as shipped (configs/zju.json:101-108, src/model.py:916-923); configs[4]: a 4096-ray chunk,
+    V = 10, 128 flat samples (fine=False) — rendered by the reference's batch_render_pifu_nerf.  The target camera frames
+    the subject like the reference's orbit (tar_focal_at_512=800, keypointnerf_amd/synthetic.py).  Source maps are kept
+    at reduced resolution and the per-point stage records are subsampled (n_sub points per query call) so that the
+    fixture stays small; the full out dict and the packed validity bits of every point are stored."""
+    scene = make_scene(n_views=n_views, src_hw=src_hw, tar_hw=(512, 512), mask=mask, seed=seed, tar_focal_at_512=800.0)
+    rec = Recorder(net)
+    cfg = dict(fine=fine, uniform=True, sample_per_ray_c=Sc, sample_per_ray_f=Sf,
+               src_foreground_mask=scene["src_foreground_mask"], bounds=scene["bounds"])
+    strd = torch.tensor([[float(stride[0]), float(stride[1])]])
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        out = net.batch_render_pifu_nerf(net, scene["img"], scene["cam"], n_views, scene["cam_tar"], level, strd, None,
+                                         scene["feat_geo"], scene["feat_tex"], dict(scene["sp_data"]), None, **cfg)
+    dt = time.time() - t0
+    rec.restore()
+    d = scene_to_npz(scene)
+    d["cfg"] = np.array([n_views, level, stride[0], stride[1], Sc, Sf], np.int64)
+    d["tar_focal_at_512"] = np.float64(800.0)
+    for k, v in out.items():
+        d["out." + k] = _np(v)
+    g = np.random.default_rng(seed)
+    n_eval = 0
+    for i, c in enumerate(rec.calls["query"]):
+        N = c["pts"].shape[1]
+        n_eval += N
+        d[f"query.{i}.valid_bits"] = np.packbits(c["valid"].reshape(-1).astype(np.uint8))
+        d[f"query.{i}.n"] = np.int64(N)
+        idx = np.sort(g.choice(N, size=min(n_sub, N), replace=False))
+        d[f"query.{i}.idx"] = idx
+        for k in ("pts", "view", "out", "valid"):
+            d[f"query.{i}.{k}"] = c[k][:, idx]
+    for i, c in enumerate(rec.calls["rgba2out"]):                   # z of both passes for 256 rays (bin-flip diagnostics)
+        d[f"rgba2out.{i}.z_sub"] = c["z"][:, ::16]
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    key = "alpha_fine" if fine else "alpha"
+    print(f"{name}: rays={out['alpha'].numel()} field evaluations={n_eval} ({dt:.1f} s of reference CPU time on "
+          f"{torch.get_num_threads()} threads = {n_eval / dt:.0f} pts/s) alpha mean={float(out[key].mean()):.4f} "
+          f"valid_c={rec.calls['query'][0]['valid'].mean():.3f} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+    return n_eval, dt
+
+
 def run_tiled_case(net, name, n_views, src_hw, tar_hw, mask, level, Sc, Sf, seed):
     """render_pifu_nerf's stride^2 tiles + pixel_shuffle re-assembly (reference src/model.py:897-940),
     with the image encoders bypassed (feature maps are the synthetic ones)."""
@@ -438,6 +484,9 @@ def main():
     if "--only-sigma" in sys.argv:
         run_sigma_nofine_case(net)
         return
+    if "--only-headline" in sys.argv:
+        run_headline_cases(net)
+        return
     sd = {k: _np(v) for k, v in net.state_dict().items() if k.startswith(HOT_PREFIXES)}
     np.savez_compressed(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"), **sd)
     print("weights:", sum(v.size for v in sd.values()), "floats")
@@ -461,6 +510,14 @@ def main():
     run_train_grad_case(net, "case_l_v3_train_grad", 3, (64, 64), (32, 32), "ellipsoid", 12, 12, seed=10)
     run_nofgmask_case(net)
     run_sigma_nofine_case(net)
+    run_headline_cases(net)
+
+
+def run_headline_cases(net):
+    # P: BASELINE configs[1] — one level-4 strided tile (offset j=3, i=5) of a 512^2 target, V=3, 64 + 64 samples
+    run_headline_case(net, "case_p_v3_headline_tile", 3, (128, 128), "ellipsoid", 4, (3, 5), 64, 64, seed=21)
+    # Q: BASELINE configs[4] — one 4096-ray chunk, V=10, 128 flat samples, dense mask
+    run_headline_case(net, "case_q_v10_flat128_chunk", 10, (96, 96), "dense", 4, (6, 2), 128, 128, seed=22, fine=False)
 
 
 def run_sigma_nofine_case(net):

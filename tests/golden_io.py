@@ -49,3 +49,38 @@ TRAIN_CASES = ["case_f_v3_train", "case_g_v4_train"]
 def keep_bits(vec):
     """(V,) 0/1 view-dropout vector -> bit mask (bit v = view v kept)."""
     return int(sum(1 << i for i, k in enumerate(vec) if k > 0.5))
+
+
+# Reference fixtures at the BASELINE sample counts (oracle/make_golden.py::run_headline_cases): name, fine
+HEADLINE_CASES = [("case_p_v3_headline_tile", True), ("case_q_v10_flat128_chunk", False)]
+
+
+def out_as_rays(g, key):
+    """out-dict entry of a golden file, (1,3,h,w) / (1,h,w), as (R,3) / (R,) in ray order."""
+    a = g["out." + key][0]
+    return a.transpose(1, 2, 0).reshape(-1, 3) if a.ndim == 3 else a.reshape(-1)
+
+
+def min_source_depth(scene, pts):
+    """min over the source views of a point's camera-space depth KRT[2,:] . (p,1): the projection x/z of
+    src/model.py:713-716 is ill-conditioned where this is small."""
+    KRT = scene["cam"]["KRT"].numpy()
+    return np.stack([pts @ KRT[v, 2, :3] + KRT[v, 2, 3] for v in range(KRT.shape[0])], 0).min(0)
+
+
+def check_query_against_reference(out, valid, g, i, scene, tol):
+    """Shared checker for query outputs at the points of golden stage record i: validity bit-exact; [sdf_raw, rad] of
+    EVERY point, rgb of every valid point, and rgb of every MASKED point whose projection is well-conditioned (all
+    source depths > 0.5 m) within tol (relative above 1); the ill-conditioned few (x/z with z ~ 1e-2) within 20 tol."""
+    ref, rvalid = g[f"query.{i}.out"][0], g[f"query.{i}.valid"][0].reshape(-1)
+    assert (valid == rvalid).all()
+    err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+    assert err[:, :2].max() < tol
+    assert err[valid].max() < tol
+    well = min_source_depth(scene, g[f"query.{i}.pts"][0]) > 0.5
+    m = ~valid
+    if (m & well).any():
+        assert err[m & well].max() < 2 * tol, float(err[m & well].max())
+    if (m & ~well).any():
+        assert err[m & ~well].max() < 20 * tol
+    return int((m & well).sum()), int((m & ~well).sum())

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import oracle
 from tests import simt_harness as sh
-from tests.golden_io import CASES, load_case, load_weights
+from tests.golden_io import CASES, HEADLINE_CASES, check_query_against_reference, load_case, load_weights, out_as_rays, pixel_list
 from tests.test_oracle_vs_golden import assert_samples_close
 
 
@@ -90,6 +90,27 @@ def test_render_pipeline_vs_golden(env):
         assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k
     for k in ("depth", "depth_fine", "sdf"):
         np.testing.assert_allclose(o[k], g["out." + k][0], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("case,fine", HEADLINE_CASES)
+def test_headline_configs_vs_reference(env, case, fine):
+    """Kernel sources on the emulator against the reference at the BASELINE sample counts (64 + 64, V=3; 128 flat, V=10):
+    a strided subset of the fixture's 4096 rays (rays are independent) and the field at the recorded query points."""
+    lib, packed, _ = env
+    scene, cfg, g = load_case(case)
+    hs = sh.HostScene(lib, scene)
+    step = 2 ** (cfg["level"] - 1)
+    sub = 8 if fine else 16                             # every sub-th row and column of the 64x64 tile
+    grid = (cfg["stride_j"], cfg["stride_i"], step * sub, 64 // sub, 64 // sub)
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], grid, cfg["Sc"], cfg["Sf"], fine=fine)
+    for k in ("tex_fg", "alpha") + (("tex_fg_fine", "alpha_fine") if fine else ()):
+        ref = g["out." + k][0][..., ::sub, ::sub]
+        assert np.abs(o[k] - ref).max() < 2e-5, k
+    for i in range(2 if fine else 1):
+        n = 512 if fine else 160
+        out, valid = sh.query(lib, hs, packed, g[f"query.{i}.pts"][0][:n], g[f"query.{i}.view"][0][:n])
+        gs = {k: (v[:, :n] if k.startswith(f"query.{i}.") and v.ndim >= 2 else v) for k, v in g.items()}
+        check_query_against_reference(out, valid, gs, i, scene, 2e-5)
 
 
 @pytest.mark.parametrize("step,Sc,Sf", [(8, 70, 66), (12, 128, 128), (6, 3, 1)])
