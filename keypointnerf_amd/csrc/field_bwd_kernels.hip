@@ -99,18 +99,18 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         kpn_f32x16 a0[4];
         {
             const float* E = tb + KPN_TBL_EXT;
-            const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
-            const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
-            const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
+            const float cx = RADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
+            const float cy = RADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
+            const float cz = RADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             kpn_load_bias<4>(bias_s[0], h, a0);
             kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
                 constexpr int j = decltype(gi)::value;
-                const float dx_ = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
-                const float d2 = KADD(KADD(KMUL(dx_, dx_), KMUL(dy, dy)), KMUL(dz, dz));
+                const float dx_ = RSUB(cx, kc[j * 3 + 0]), dy = RSUB(cy, kc[j * 3 + 1]), dz = RSUB(cz, kc[j * 3 + 2]);
+                const float d2 = RADD(RADD(RMUL(dx_, dx_), RMUL(dy, dy)), RMUL(dz, dz));
                 const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                kpn_sincos(KMUL(dz, pe_pi), s1, c1);
+                kpn_sincos(RMUL(dz, pe_pi), s1, c1);
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
                 const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
                 x[0] = dz * w;

@@ -28,6 +28,7 @@ struct kpn_points {
     const float* noise;
     float noise_std;
 };
+template <bool S = false>
 __device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, float (&P)[3], float (&D)[3]) {
     if (ps.pts) {
 #pragma unroll
@@ -38,7 +39,7 @@ __device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, f
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             D[k] = ps.dirs[r * 3 + k];
-            P[k] = KADD(ps.cam_pos[k], KMUL(D[k], zz));
+            P[k] = kpn_add<S>(ps.cam_pos[k], kpn_mul<S>(D[k], zz));
         }
     }
 }
@@ -65,18 +66,18 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
         int is_valid = 0;
         if (n < N) {
             float P[3], D[3];
-            kpn_get_point(ps, n, P, D);
+            kpn_get_point<true>(ps, n, P, D);
             int all_in = 1, all_fg = 1;
             float acc[3] = {0.f, 0.f, 0.f};
             const float pu = 1.0f / (float)sc.V;
             const size_t HW = (size_t)sc.H * sc.W;
             for (int v = 0; v < sc.V; ++v) {
                 const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-                const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+                const kpn_proj q = kpn_project<true>(tb, P[0], P[1], P[2], sc);
                 all_in &= q.in;
                 if (lean && !all_in) break;
-                const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
-                const float4 s = kpn_tap4(sc.rgbm + (size_t)v * HW * 4, 4, 0, tp);
+                const kpn_taps tp = kpn_make_taps<true>(q.xn, q.yn, sc.H, sc.W);
+                const float4 s = kpn_tap4<true>(sc.rgbm + (size_t)v * HW * 4, 4, 0, tp);
                 if (!sc.disable_fg_mask) all_fg &= (s.w > 0.1f);  // model.py:737-739
                 if (lean && !all_fg) break;
                 acc[0] = KADD(acc[0], KMUL(s.x, pu)); acc[1] = KADD(acc[1], KMUL(s.y, pu)); acc[2] = KADD(acc[2], KMUL(s.z, pu));
@@ -114,14 +115,14 @@ __global__ __launch_bounds__(256) void k_mask_compact(kpn_scene_dev sc, kpn_poin
 
 // Boundary-smooth pooling weight of one view (model.py:752-759, mask == 1), un-normalised
 __device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
-    const float c3[3] = {KADD(KMUL(0.5f, q.xn), 0.5f), KADD(KMUL(0.5f, q.yn), 0.5f), KADD(KMUL(0.5f, q.zn), 0.5f)};
+    const float c3[3] = {RADD(RMUL(0.5f, q.xn), 0.5f), RADD(RMUL(0.5f, q.yn), 0.5f), RADD(RMUL(0.5f, q.zn), 0.5f)};
     float w3[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float d = fminf(c3[i], KSUB(1.0f, c3[i]));
-        w3[i] = kpn_sigmoid(KMUL(5.0f, KSUB(d / 0.1f, 1.0f)));
+        const float d = fminf(c3[i], RSUB(1.0f, c3[i]));
+        w3[i] = kpn_sigmoid(RMUL(5.0f, RSUB(d / 0.1f, 1.0f)));
     }
-    return KMUL(KMUL(w3[0], w3[1]), w3[2]);
+    return RMUL(RMUL(w3[0], w3[1]), w3[2]);
 }
 
 // the colour head's per-(point,view) gather record (query_color, model.py:806-832): h=0 lanes [r,g,b, pooling
@@ -134,10 +135,10 @@ __device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const fl
         const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
         rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
         const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
-        float cr[3] = {KSUB(P[0], cp[0]), KSUB(P[1], cp[1]), KSUB(P[2], cp[2])};
+        float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
         const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
         cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
-        const float r0 = KSUB(D[0], cr[0]), r1 = KSUB(D[1], cr[1]), r2 = KSUB(D[2], cr[2]);
+        const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
         const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
         rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
     } else {
@@ -210,20 +211,20 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         kpn_f32x16 a0[4];
         {
             const float* E = tb + KPN_TBL_EXT;  // camera-space position, spatial.py:76
-            const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
-            const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
-            const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
+            const float cx = RADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
+            const float cy = RADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
+            const float cz = RADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             kpn_load_bias<4>(bias_s[0], h, a0);
             // group j = keypoint j + 12h: 7 encoding values (spatial.py:110-118), produced while the
             // previous keypoint's 28 MFMAs issue
             kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
                 constexpr int j = decltype(gi)::value;
-                const float dx = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
-                const float d2 = KADD(KADD(KMUL(dx, dx), KMUL(dy, dy)), KMUL(dz, dz));
+                const float dx = RSUB(cx, kc[j * 3 + 0]), dy = RSUB(cy, kc[j * 3 + 1]), dz = RSUB(cz, kc[j * 3 + 2]);
+                const float d2 = RADD(RADD(RMUL(dx, dx), RMUL(dy, dy)), RMUL(dz, dz));
                 const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                kpn_sincos(KMUL(dz, pe_pi), s1, c1);
+                kpn_sincos(RMUL(dz, pe_pi), s1, c1);
                 // sin/cos(2y), sin/cos(4y): the reference's arguments are exactly 2y and 4y
                 // (float32(2*pi) == 2*float32(pi)), so the double-angle identities apply to them
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
@@ -340,18 +341,18 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_h(kpn_scene_dev sc, kpn_poi
         kpn_f32x16 a0[4];
         {
             const float* E = tb + KPN_TBL_EXT;
-            const float cx = KADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
-            const float cy = KADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
-            const float cz = KADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
+            const float cx = RADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
+            const float cy = RADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
+            const float cz = RADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             kpn_load_bias<4>(bias_s[0], h, a0);
             kpn_mfma16_layer<12, 4>(wp + kpn_hseg_off(HSEG_G1_0A), lane, [&](auto gi, float (&x)[8]) {
                 constexpr int j = decltype(gi)::value;
-                const float dx = KSUB(cx, kc[j * 3 + 0]), dy = KSUB(cy, kc[j * 3 + 1]), dz = KSUB(cz, kc[j * 3 + 2]);
-                const float d2 = KADD(KADD(KMUL(dx, dx), KMUL(dy, dy)), KMUL(dz, dz));
+                const float dx = RSUB(cx, kc[j * 3 + 0]), dy = RSUB(cy, kc[j * 3 + 1]), dz = RSUB(cz, kc[j * 3 + 2]);
+                const float d2 = RADD(RADD(RMUL(dx, dx), RMUL(dy, dy)), RMUL(dz, dz));
                 const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                kpn_sincos(KMUL(dz, pe_pi), s1, c1);
+                kpn_sincos(RMUL(dz, pe_pi), s1, c1);
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
                 const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
                 x[0] = dz * w;
@@ -474,14 +475,14 @@ __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows,
                                                 float (&pooled)[64]) {
     float pwsum = 0.0f;
     for (int v = 0; v < V; ++v)
-        if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
+        if ((keep >> v) & 1u) pwsum = RADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
 #pragma unroll
     for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
     for (int pass = 0; pass < 2; ++pass)
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
             const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-            const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
+            const float pw = src[8 * 64 + p].w / RADD(pwsum, 1e-6f);
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) {
                 const float4 x = src[q4 * 64 + lane];
@@ -489,8 +490,8 @@ __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * q4 + e;
-                    if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
-                    else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
+                    if (pass == 0) pooled[i] = RADD(pooled[i], RMUL(pw, xe[e]));
+                    else { const float d = RSUB(xe[e], pooled[i]); pooled[32 + i] = RADD(pooled[32 + i], RMUL(pw, RMUL(d, d))); }
                 }
             }
         }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         // (kpn_pool_views spelled out: through the helper this kernel measured 1.7 ms per frame slower)
         float pwsum = 0.0f;
         for (int v = 0; v < V; ++v)
-            if ((keep >> v) & 1u) pwsum = KADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
+            if ((keep >> v) & 1u) pwsum = RADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
 #pragma unroll
         for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             for (int v = 0; v < V; ++v) {
                 if (!((keep >> v) & 1u)) continue;
                 const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-                const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
+                const float pw = src[8 * 64 + p].w / RADD(pwsum, 1e-6f);
 #pragma unroll
                 for (int q4 = 0; q4 < 8; ++q4) {
                     const float4 x = src[q4 * 64 + lane];
@@ -555,8 +556,8 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * q4 + e;
-                        if (pass == 0) pooled[i] = KADD(pooled[i], KMUL(pw, xe[e]));
-                        else { const float d = KSUB(xe[e], pooled[i]); pooled[32 + i] = KADD(pooled[32 + i], KMUL(pw, KMUL(d, d))); }
+                        if (pass == 0) pooled[i] = RADD(pooled[i], RMUL(pw, xe[e]));
+                        else { const float d = RSUB(xe[e], pooled[i]); pooled[32 + i] = RADD(pooled[32 + i], RMUL(pw, RMUL(d, d))); }
                     }
                 }
             }
@@ -598,21 +599,21 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
                 const float dot = rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w;
-                const float e = kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f)));
+                const float e = kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f)));
                 if (pass == 0) emin = fminf(emin, e);  // min over ALL views (:1288)
-                else if ((keep >> v) & 1u) esum = KADD(esum, KSUB(e, emin));
+                else if ((keep >> v) & 1u) esum = RADD(esum, RSUB(e, emin));
             }
         // fused mean/var over views of x' (utils.py:91-95): K-steps mean' (16 + 3 + pad), var' (16 + 3 + pad)
         float mv[40];
 #pragma unroll
         for (int i = 0; i < 40; ++i) mv[i] = 0.0f;
         auto stats = [&](int pass, float dot, const kpn_ibr_view& iv) {
-            const float wv = KSUB(kpn_fast_exp(KMUL(ani, KSUB(dot, 1.0f))), emin) / KADD(esum, 1e-8f);
+            const float wv = RSUB(kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f))), emin) / RADD(esum, 1e-8f);
 #pragma unroll
             for (int i = 0; i < 19; ++i) {
                 const float x = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
-                if (pass == 0) mv[i] = KADD(mv[i], KMUL(x, wv));
-                else { const float d = KSUB(x, mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
+                if (pass == 0) mv[i] = RADD(mv[i], RMUL(x, wv));
+                else { const float d = RSUB(x, mv[i]); mv[20 + i] = RADD(mv[20 + i], RMUL(wv, RMUL(d, d))); }
             }
         };
         // x' of a view is needed three times (two statistics passes, the head).  With park_x the first pass parks it
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         // SOURCE colours (model.py:1300-1301)
         float lmax = -3.0e38f, lden = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
         auto head = [&](const kpn_view_gather& g, const kpn_ibr_view& iv) {
-            const float wv = KSUB(kpn_fast_exp(KMUL(ani, KSUB(g.rd[3], 1.0f))), emin) / KADD(esum, 1e-8f);
+            const float wv = RSUB(kpn_fast_exp(RMUL(ani, RSUB(g.rd[3], 1.0f))), emin) / RADD(esum, 1e-8f);
             float xin[20];
 #pragma unroll
             for (int i = 0; i < 19; ++i) xin[i] = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;
             if (mode == 1) {  // eval_func with mask = 1 (model.py:981-996)
-                if (ps.noise) rad = KADD(rad, KMUL(ps.noise[n], ps.noise_std));
+                if (ps.noise) rad = RADD(rad, RMUL(ps.noise[n], ps.noise_std));
                 o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw;
             }
             else { o[0] = sdf_raw; o[1] = rad; }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_fuse_bwd(kpn_scene_dev sc, kpn_point
         const float* go = d_out + n * 5;
         float d_sdf, d_rad;
         if (mode == 1) {  // eval_func, mask = 1: out0 = relu(rad + noise), out1 = sdf_raw (model.py:981-996)
-            if (ps.noise) rad = KADD(rad, KMUL(ps.noise[n], ps.noise_std));
+            if (ps.noise) rad = RADD(rad, RMUL(ps.noise[n], ps.noise_std));
             d_rad = rad > 0.0f ? go[0] : 0.0f;
             d_sdf = go[1];
         } else { d_sdf = go[0]; d_rad = go[1]; }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_fuse_bwd(kpn_scene_dev sc, kpn_point
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
             const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-            const float pw = src[8 * 64 + p].w / KADD(pwsum, 1e-6f);
+            const float pw = src[8 * 64 + p].w / RADD(pwsum, 1e-6f);
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) {
                 const float4 x = src[q4 * 64 + lane];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_fuse_bwd(kpn_scene_dev sc, kpn_point
             float* drow = bufs.dxrows + (((size_t)t * V + v) * KPN_TILE + p) * 64;
             const bool on = (keep >> v) & 1u;
             const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-            const float pw = on ? src[8 * 64 + p].w / KADD(pwsum, 1e-6f) : 0.0f;
+            const float pw = on ? src[8 * 64 + p].w / RADD(pwsum, 1e-6f) : 0.0f;
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) {
                 const float4 x = src[q4 * 64 + lane];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_gather_view(xscr, t, V, v, lane, h, g);
             dotv[v] = g.rd[3];
             rgbv[v][0] = g.rgb[0]; rgbv[v][1] = g.rgb[1]; rgbv[v][2] = g.rgb[2];
-            emin = fminf(emin, kpn_fast_exp(KMUL(ani, KSUB(g.rd[3], 1.0f))));
+            emin = fminf(emin, kpn_fast_exp(RMUL(ani, RSUB(g.rd[3], 1.0f))));
             if (h == 0) *reinterpret_cast<float4*>(B.Xrd + hrow(v) * 4) = make_float4(g.rd[0], g.rd[1], g.rd[2], g.rd[3]);
             if (!((keep >> v) & 1u)) continue;
             const float in4[4] = {h ? g.rd[1] : g.rd[0], h ? g.rd[3] : g.rd[2], 0.0f, 0.0f};
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_st_xprime(B.Xbl + hrow(v) * KPN_LD_XBL + 72, h, xq);
         }
         for (int v = 0; v < V; ++v)
-            if ((keep >> v) & 1u) esum = KADD(esum, KSUB(kpn_fast_exp(KMUL(ani, KSUB(dotv[v], 1.0f))), emin));
-        auto blend_w = [&](int v) { return KSUB(kpn_fast_exp(KMUL(ani, KSUB(dotv[v], 1.0f))), emin) / KADD(esum, 1e-8f); };
+            if ((keep >> v) & 1u) esum = RADD(esum, RSUB(kpn_fast_exp(RMUL(ani, RSUB(dotv[v], 1.0f))), emin));
+        auto blend_w = [&](int v) { return RSUB(kpn_fast_exp(RMUL(ani, RSUB(dotv[v], 1.0f))), emin) / RADD(esum, 1e-8f); };
         // fused mean / var over views of x' (utils.py:91-95)
         float mv[40];
 #pragma unroll
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
                 const float wv = blend_w(v);
 #pragma unroll
                 for (int i = 0; i < 19; ++i) {
-                    if (pass == 0) mv[i] = KADD(mv[i], KMUL(xq[i], wv));
-                    else { const float d = KSUB(xq[i], mv[i]); mv[20 + i] = KADD(mv[20 + i], KMUL(wv, KMUL(d, d))); }
+                    if (pass == 0) mv[i] = RADD(mv[i], RMUL(xq[i], wv));
+                    else { const float d = RSUB(xq[i], mv[i]); mv[20 + i] = RADD(mv[20 + i], RMUL(wv, RMUL(d, d))); }
                 }
             }
         kpn_f32x16 base[2];
@@ -666,11 +666,11 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
         }
         // ---------------- reverse: blend weights -> |ani_al| (model.py:1287-1289) ----------------
         {
-            const float S = KADD(esum, 1e-8f);
+            const float S = RADD(esum, 1e-8f);
             float ev[VMAX], dot_du = 0.0f;
             int imin = 0;
             for (int v = 0; v < V; ++v) {
-                ev[v] = kpn_fast_exp(KMUL(ani, KSUB(dotv[v], 1.0f)));
+                ev[v] = kpn_fast_exp(RMUL(ani, RSUB(dotv[v], 1.0f)));
                 if (ev[v] < ev[imin]) imin = v;
                 if ((keep >> v) & 1u) dot_du += dwv[v] * (ev[v] - emin);
             }

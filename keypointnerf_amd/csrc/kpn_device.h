@@ -5,11 +5,41 @@
 // "geometry" arithmetic: separate IEEE multiply/add (no FMA contraction) so that projections, ray
 // set-up, AABB tests and mask thresholds are bit-identical to the scalar restatement they are tested
 // against (validity masks are discrete decisions; everything downstream depends on them).
-#define KMUL(a, b) __fmul_rn((a), (b))
-#define KADD(a, b) __fadd_rn((a), (b))
-#define KSUB(a, b) __fadd_rn((a), -(b))
+// NOTE: HIP's __fmul_rn / __fadd_rn are plain `x * y` / `x + y` (clang's __clang_hip_math.h) and hipcc compiles device
+// code with -ffp-contract=fast-honor-pragmas, so they DO get fused into v_fma_f32 wherever the optimiser sees a
+// multiply feeding an add.  Observed: `cam_pos + dir * z` of the ray-marched point was contracted in k_mask_compact,
+// which moved one point of 262,144 across the fg-mask threshold (reference fixture case_p, ray 3866 / sample 42).  The
+// helpers below switch contraction off for their own operations; an fmul and an fadd fuse only if BOTH allow it.
+__device__ __forceinline__ float kpn_mul_nofma(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float kpn_add_nofma(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float kpn_sub_nofma(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+#define KMUL(a, b) kpn_mul_nofma((a), (b))
+#define KADD(a, b) kpn_add_nofma((a), (b))
+#define KSUB(a, b) kpn_sub_nofma((a), (b))
+// Two arithmetic flavours of the shared geometry helpers (projection, bilinear taps, point set-up):
+//   STRICT = true : separate multiplies and adds — every DISCRETE decision (validity, fg-mask threshold, AABB hits,
+//                   sample ordering) is taken on these values: k_mask_compact and the ray kernels;
+//   STRICT = false: plain operators, free to contract — the same quantities where they only feed continuous arithmetic
+//                   (tap weights and encodings inside the MFMA-bound kernels, where the extra VALU issue slots of the
+//                   unfused form cost 6 % of k_geo_rows).
+template <bool S> __device__ __forceinline__ float kpn_mul(float a, float b) { if constexpr (S) return kpn_mul_nofma(a, b); else return a * b; }
+template <bool S> __device__ __forceinline__ float kpn_add(float a, float b) { if constexpr (S) return kpn_add_nofma(a, b); else return a + b; }
+template <bool S> __device__ __forceinline__ float kpn_sub(float a, float b) { if constexpr (S) return kpn_sub_nofma(a, b); else return a - b; }
+#define RMUL(a, b) ((a) * (b))
+#define RADD(a, b) ((a) + (b))
+#define RSUB(a, b) ((a) - (b))
+template <bool S = false>
 __device__ __forceinline__ float kpn_dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
-    return KADD(KADD(KMUL(a0, b0), KMUL(a1, b1)), KMUL(a2, b2));
+    return kpn_add<S>(kpn_add<S>(kpn_mul<S>(a0, b0), kpn_mul<S>(a1, b1)), kpn_mul<S>(a2, b2));
 }
 
 __device__ __forceinline__ float kpn_sigmoid(float x) { return 1.0f / (1.0f + kpn_fast_exp(-x)); }
@@ -52,17 +82,18 @@ struct kpn_proj {
     float xn, yn, zn;  // normalised to [-1,1]
     int in;            // inside the view volume (xy within +-1.01, z >= znear)
 };
+template <bool S = false>
 __device__ __forceinline__ kpn_proj kpn_project(const float* __restrict__ tb, float px, float py, float pz,
                                                 const kpn_scene_dev& sc) {
     const float* M = tb + KPN_TBL_KRT;
-    const float vx = KADD(kpn_dot3(px, py, pz, M[0], M[1], M[2]), M[3]);
-    const float vy = KADD(kpn_dot3(px, py, pz, M[4], M[5], M[6]), M[7]);
-    const float vz = KADD(kpn_dot3(px, py, pz, M[8], M[9], M[10]), M[11]);
+    const float vx = kpn_add<S>(kpn_dot3<S>(px, py, pz, M[0], M[1], M[2]), M[3]);
+    const float vy = kpn_add<S>(kpn_dot3<S>(px, py, pz, M[4], M[5], M[6]), M[7]);
+    const float vz = kpn_add<S>(kpn_dot3<S>(px, py, pz, M[8], M[9], M[10]), M[11]);
     const float x = vx / vz, y = vy / vz;
     kpn_proj q;
-    q.xn = KSUB(KMUL(2.0f, x / KSUB((float)sc.W, 1.0f)), 1.0f);
-    q.yn = KSUB(KMUL(2.0f, y / KSUB((float)sc.H, 1.0f)), 1.0f);
-    q.zn = KSUB(KMUL(2.0f, KSUB(vz, sc.znear)) / KSUB(sc.zfar, sc.znear), 1.0f);
+    q.xn = kpn_sub<S>(kpn_mul<S>(2.0f, x / kpn_sub<S>((float)sc.W, 1.0f)), 1.0f);
+    q.yn = kpn_sub<S>(kpn_mul<S>(2.0f, y / kpn_sub<S>((float)sc.H, 1.0f)), 1.0f);
+    q.zn = kpn_sub<S>(kpn_mul<S>(2.0f, kpn_sub<S>(vz, sc.znear)) / kpn_sub<S>(sc.zfar, sc.znear), 1.0f);
     const float eps = 1e-2f;
     q.in = (q.xn >= -1.0f - eps) && (q.xn <= 1.0f + eps) && (q.yn >= -1.0f - eps) && (q.yn <= 1.0f + eps) &&
            (q.zn >= -1.0f);
@@ -77,34 +108,36 @@ struct kpn_taps {
     int o00, o01, o10, o11;
     float w00, w01, w10, w11;  // nw, ne, sw, se
 };
+template <bool S = false>
 __device__ __forceinline__ kpn_taps kpn_make_taps(float xn, float yn, int h, int w) {
-    float ix = KMUL(KADD(xn, 1.0f) / 2.0f, (float)(w - 1));
-    float iy = KMUL(KADD(yn, 1.0f) / 2.0f, (float)(h - 1));
+    float ix = kpn_mul<S>(kpn_add<S>(xn, 1.0f) / 2.0f, (float)(w - 1));
+    float iy = kpn_mul<S>(kpn_add<S>(yn, 1.0f) / 2.0f, (float)(h - 1));
     ix = fminf(fmaxf(ix, 0.0f), (float)(w - 1));
     iy = fminf(fmaxf(iy, 0.0f), (float)(h - 1));
     const float fx = floorf(ix), fy = floorf(iy);
     const int x0 = (int)fx, y0 = (int)fy;
     const float x1f = fx + 1.0f, y1f = fy + 1.0f;
     kpn_taps t;
-    t.w00 = KMUL(KSUB(x1f, ix), KSUB(y1f, iy));
-    t.w01 = KMUL(KSUB(ix, fx), KSUB(y1f, iy));
-    t.w10 = KMUL(KSUB(x1f, ix), KSUB(iy, fy));
-    t.w11 = KMUL(KSUB(ix, fx), KSUB(iy, fy));
+    t.w00 = kpn_mul<S>(kpn_sub<S>(x1f, ix), kpn_sub<S>(y1f, iy));
+    t.w01 = kpn_mul<S>(kpn_sub<S>(ix, fx), kpn_sub<S>(y1f, iy));
+    t.w10 = kpn_mul<S>(kpn_sub<S>(x1f, ix), kpn_sub<S>(iy, fy));
+    t.w11 = kpn_mul<S>(kpn_sub<S>(ix, fx), kpn_sub<S>(iy, fy));
     const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
     t.o00 = y0 * w + x0; t.o01 = y0 * w + x1; t.o10 = y1 * w + x0; t.o11 = y1 * w + x1;
     return t;
 }
 // 4 consecutive channels of a channels-last map (C floats per pixel) starting at channel c0
+template <bool S = false>
 __device__ __forceinline__ float4 kpn_tap4(const float* __restrict__ map, int C, int c0, const kpn_taps& t) {
     const float4 a = *reinterpret_cast<const float4*>(map + (size_t)t.o00 * C + c0);
     const float4 b = *reinterpret_cast<const float4*>(map + (size_t)t.o01 * C + c0);
     const float4 c = *reinterpret_cast<const float4*>(map + (size_t)t.o10 * C + c0);
     const float4 d = *reinterpret_cast<const float4*>(map + (size_t)t.o11 * C + c0);
     float4 r;  // same tap order as ATen: nw, ne, sw, se
-    r.x = KADD(KADD(KADD(KMUL(a.x, t.w00), KMUL(b.x, t.w01)), KMUL(c.x, t.w10)), KMUL(d.x, t.w11));
-    r.y = KADD(KADD(KADD(KMUL(a.y, t.w00), KMUL(b.y, t.w01)), KMUL(c.y, t.w10)), KMUL(d.y, t.w11));
-    r.z = KADD(KADD(KADD(KMUL(a.z, t.w00), KMUL(b.z, t.w01)), KMUL(c.z, t.w10)), KMUL(d.z, t.w11));
-    r.w = KADD(KADD(KADD(KMUL(a.w, t.w00), KMUL(b.w, t.w01)), KMUL(c.w, t.w10)), KMUL(d.w, t.w11));
+    r.x = kpn_add<S>(kpn_add<S>(kpn_add<S>(kpn_mul<S>(a.x, t.w00), kpn_mul<S>(b.x, t.w01)), kpn_mul<S>(c.x, t.w10)), kpn_mul<S>(d.x, t.w11));
+    r.y = kpn_add<S>(kpn_add<S>(kpn_add<S>(kpn_mul<S>(a.y, t.w00), kpn_mul<S>(b.y, t.w01)), kpn_mul<S>(c.y, t.w10)), kpn_mul<S>(d.y, t.w11));
+    r.z = kpn_add<S>(kpn_add<S>(kpn_add<S>(kpn_mul<S>(a.z, t.w00), kpn_mul<S>(b.z, t.w01)), kpn_mul<S>(c.z, t.w10)), kpn_mul<S>(d.z, t.w11));
+    r.w = kpn_add<S>(kpn_add<S>(kpn_add<S>(kpn_mul<S>(a.w, t.w00), kpn_mul<S>(b.w, t.w01)), kpn_mul<S>(c.w, t.w10)), kpn_mul<S>(d.w, t.w11));
     return r;
 }
 

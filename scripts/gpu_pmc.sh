@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counter passes for the bench workload (separate runs per counter group, kernel-trace only).
 R=$GRAFT_REPO_ROOT; TAG=${1:-x}; cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary"
 run() { name=$1; shift; (timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$TAG -o $name -- $CMD) > $R/gpurun_out/pmc_${TAG}_$name.log 2>&1; echo "$name rc=$?"; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_INSTS_SALU

@@ -24,6 +24,10 @@ class StandInNet(torch.nn.Module):
                 mod = getattr(mod, p)
             mod.register_parameter(parts[-1], torch.nn.Parameter(v.clone()))
         self.disable_fg_mask = False
+        # what install() reads from the spatial encoder (reference src/spatial.py:10-21, configs/zju.json:39-45)
+        self.sp_encoder = torch.nn.Module()
+        self.sp_encoder.sp_type, self.sp_encoder.sp_level, self.sp_encoder.n_kpt, self.sp_encoder.scale = "rel_z_decay", 3, 24, 1.0
+        self.sp_encoder.kwargs = {"sigma": 0.1}
         self._scene = scene
         self.encoder_calls = 0
         self.eval()
@@ -91,6 +95,7 @@ def test_seam_functions_match_reference_call_sites():
     assert zf.shape == g["importance_sample.0.out"].shape
 
 
+@torch.no_grad()                                                           # as render_novel_views, src/model.py:475
 def test_render_pifu_nerf_full_frame_and_weight_refresh():
     scene, cfg, g = load_case(TILED_CASE)
     net, s = _net(scene)
@@ -149,7 +154,7 @@ def test_validation_path_uniform_false_is_served():
     from oracle import oracle
     scene, cfg, g = load_case(CASES[0])
     net, s = _net(scene)
-    Sc, Sf, V, level = cfg["Sc"], cfg["Sf"], cfg["n_views"], cfg["level"]
+    Sc, Sf, V, level = cfg["Sc"], cfg["Sf"], cfg["n_views"], 2            # every second pixel, offset (1, 0)
     H, W = s["cam_tar"]["height"], s["cam_tar"]["width"]
     step = 2 ** (level - 1)
     stride = torch.tensor([[1, 0]])
