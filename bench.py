@@ -244,8 +244,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms, launches, rows = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0)
-    L.check(L.kpn_profile_collect(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows)))
+    ms, launches, rows, surplus = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.kpn_profile_collect2(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus)))
     L.check(L.kpn_profile_enable(0))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
@@ -298,6 +298,12 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
+                         "surplus_launches": surplus.value,
+                         "note": "the row scratch between k_geo_rows and k_fuse_color is capped ("
+                                 + f"{L.kpn_row_scratch_cap_bytes() / 2**30:.1f} GiB) and reused by batches of a pass; the worst-case "
+                                 "number of batches is launched and the surplus ones return at once (a few us each): "
+                                 "`launches` / `avg_launch_ms` cover the launches that processed rows, a rocprofv3 average "
+                                 "over ALL k_geo_rows launches is lower by the factor launches / (launches + surplus_launches)",
                          "algorithmic_flop_per_row": flops_row,
                          "kernel_time_share": (ms.value * 1e-3) / dt},
         }

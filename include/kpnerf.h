@@ -236,6 +236,13 @@ int kpn_ssim(const float* pred_chw, const float* gt_chw, int32_t height, int32_t
  * and returns the totals since kpn_profile_enable(1).  Diagnostic only; off by default. */
 int kpn_profile_enable(int32_t on);
 int kpn_profile_collect(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host);
+/* The row scratch between the two field kernels is capped (kpn_row_scratch_cap_bytes(): 3 GiB by default, environment
+ * variable KPN_ROW_SCRATCH_MIB); a pass with more valid (point, view) rows than fit is evaluated in batches that reuse it.
+ * The launcher cannot know the number of batches without a sync, so it launches the worst-case number and the surplus
+ * launches return at once: kpn_profile_collect2 reports them separately (ms / launches / rows cover the launches that
+ * processed rows). */
+int kpn_profile_collect2(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host, int64_t* surplus_launches_host);
+size_t kpn_row_scratch_cap_bytes(void);
 
 /* TRAIN branch of batch_render_pifu_nerf (forward only), every random draw supplied by the caller so that it can
  * be the reference's own: src/model.py:1008-1017 (patch pixels), :1049-1053 (stratified jitter), :993-994 (density

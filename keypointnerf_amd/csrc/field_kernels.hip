@@ -28,6 +28,19 @@ struct kpn_points {
     const float* noise;
     float noise_std;
 };
+// The row scratch holds at most `tiles_cap` tiles x V rows.  A pass whose valid list is longer is evaluated in
+// nb = ceil(ntiles / tiles_cap) batches (k_geo_rows + k_fuse_color per batch, the scratch reused); the host cannot know
+// nb without a sync, so it launches the worst-case number of batches and the surplus ones return at once.  Tiles are
+// split evenly: batch b owns [ntiles*b/nb, ntiles*(b+1)/nb).
+struct kpn_batch { int index, tiles_cap; };
+__device__ __forceinline__ bool kpn_batch_range(const kpn_batch& b, int ntiles, int& t0, int& t1) {
+    const int nb = (ntiles + b.tiles_cap - 1) / b.tiles_cap;
+    if (b.index >= nb) return false;
+    t0 = (int)((int64_t)ntiles * b.index / nb);
+    t1 = (int)((int64_t)ntiles * (b.index + 1) / nb);
+    return true;
+}
+
 template <bool S = false>
 __device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, float (&P)[3], float (&D)[3]) {
     if (ps.pts) {
@@ -154,14 +167,16 @@ __device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const fl
 // the lane's 32-register result (block b = q4/4, regs 4*(q4%4)..+3) — lane-contiguous 1-KB stores.
 __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                      const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                     int* __restrict__ tickets, float* __restrict__ xscr) {
+                                                     int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
-    const int nwork = ntiles * sc.V;
+    int t0, t1;
+    if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
+    const int nwork = (t1 - t0) * sc.V;
     const float pe_pi = 3.14159274101257324f;  // float32(pi), spatial.py:42-47
     // the four bias blocks (448 floats) sit in LDS for the lifetime of the persistent workgroup: a layer
     // starts with a ds_read instead of an exposed L2 round trip
@@ -183,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
         if (lane == 0) wi = atomicAdd(tickets + 0, 1);
         wi = __shfl(wi, 0);
         if (wi >= nwork) break;
-        const int t = wi / sc.V, v = wi - t * sc.V;
-        int ci = t * KPN_TILE + p;
+        const int tr = wi / sc.V, v = wi - tr * sc.V;   // tile relative to the batch; the scratch slot is wi
+        int ci = (t0 + tr) * KPN_TILE + p;
         if (ci >= count) ci = count - 1;  // pad lanes recompute the last point; their result is never read
         const int64_t n = list[ci];
         float P[3], D[3];
@@ -298,12 +313,14 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
 // fp32-class arithmetic (every product term above 2^-24 relative is kept), about twice the matrix rate.
 __global__ __launch_bounds__(256, 2) void k_geo_rows_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                       int* __restrict__ tickets, float* __restrict__ xscr) {
+                                                       int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
-    const int nwork = ntiles * sc.V;
+    int t0, t1;
+    if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
+    const int nwork = (t1 - t0) * sc.V;
     const float pe_pi = 3.14159274101257324f;
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
     {
@@ -319,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows_h(kpn_scene_dev sc, kpn_poi
         if (lane == 0) wi = atomicAdd(tickets + 0, 1);
         wi = __shfl(wi, 0);
         if (wi >= nwork) break;
-        const int t = wi / sc.V, v = wi - t * sc.V;
-        int ci = t * KPN_TILE + p;
+        const int tr = wi / sc.V, v = wi - tr * sc.V;
+        int ci = (t0 + tr) * KPN_TILE + p;
         if (ci >= count) ci = count - 1;
         const int64_t n = list[ci];
         float P[3], D[3];
@@ -504,13 +521,15 @@ __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows,
 __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                       int park_x, float* __restrict__ out) {
+                                                       int park_x, float* __restrict__ out, kpn_batch batch) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int count = *count_ptr;
-    const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
+    int t0, t1;
+    if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;   // before the LDS staging
+    const int ntiles = t1 - t0;
     const int V = sc.V;
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
     // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
@@ -529,8 +548,8 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         int t = 0;
         if (lane == 0) t = atomicAdd(tickets + 1, 1);
         t = __shfl(t, 0);
-        if (t >= ntiles) break;
-        const int ci_raw = t * KPN_TILE + p;
+        if (t >= ntiles) break;             // t: tile relative to the batch = its slot in the row scratch
+        const int ci_raw = (t0 + t) * KPN_TILE + p;
         const int ci = ci_raw < count ? ci_raw : count - 1;
         const int64_t n = list[ci];
 

@@ -515,14 +515,44 @@ extern "C" int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t 
 // ---------------------------------------------------------------------------------------------
 // field query
 namespace {
-struct QueryLayout { size_t count, list, xscr, total; };  // byte offsets
+// The row scratch (10 KB per valid tile and view) is capped: a pass with more valid tiles than fit is evaluated in
+// batches that reuse it (kpn_batch, field_kernels.hip).  Sized for the worst case it was 32 GiB for a 512^2 frame at
+// 64 + 64 samples — of which a scene uses the valid third; the cap keeps one pass per frame (one launch ramp, one
+// weight staging) at a fixed, small footprint.  KPN_ROW_SCRATCH_MIB overrides the default of 3 GiB.
+size_t row_scratch_cap_bytes() {
+#ifdef KPN_SIMT_EMU
+    static const size_t cap = [] { const char* e = getenv("KPN_ROW_SCRATCH_MIB"); return e ? (size_t)atoll(e) << 20 : (size_t)1 << 20; }();
+#else
+    static const size_t cap = [] { const char* e = getenv("KPN_ROW_SCRATCH_MIB"); return (e ? (size_t)atoll(e) : (size_t)3072) << 20; }();
+#endif
+    return cap;
+}
+const int kMaxBatches = 60;   // ticket pairs that fit the 512-byte counter block
+// passes of at most this many points always get their worst-case scratch (never batched): the backward entry points
+// read a pass's rows again and work in passes of kBwdChunk points
+#ifdef KPN_SIMT_EMU
+const int64_t kUncappedPoints = 2048;
+#else
+const int64_t kUncappedPoints = 262144;
+#endif
+struct QueryLayout { size_t count, list, xscr, total; int tiles_cap, nbatch; };  // byte offsets
 QueryLayout query_layout(int64_t N, int V) {
     QueryLayout L;
     size_t o = 0;
-    L.count = o; o += 256;
+    L.count = o; o += 512;   // [0] valid count, [1 + 2b] k_geo_rows tickets of batch b, [2 + 2b] k_fuse_color tickets
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
-    L.xscr = o; o += align_up(ntiles * (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4), 256);
+    const size_t tile_bytes = (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4);
+    // monotone in N (a render workspace is laid out for its largest pass and used by smaller ones): never fewer tiles
+    // than an uncapped pass of kUncappedPoints points needs
+    size_t cap = row_scratch_cap_bytes() / tile_bytes;
+    const size_t floor_tiles = (size_t)(kUncappedPoints + KPN_TILE - 1) / KPN_TILE;
+    if (cap < floor_tiles) cap = floor_tiles;
+    if ((ntiles + cap - 1) / cap > (size_t)kMaxBatches) cap = (ntiles + kMaxBatches - 1) / kMaxBatches;
+    if (cap > ntiles) cap = ntiles ? ntiles : 1;
+    L.tiles_cap = (int)cap;
+    L.nbatch = (int)((ntiles + cap - 1) / cap);
+    L.xscr = o; o += align_up(cap * tile_bytes, 256);
     L.total = o;
     return L;
 }
@@ -540,7 +570,8 @@ int field_grid_blocks() {
 struct ProfState {
     bool on = false;
     std::vector<hipEvent_t> ev;   // pairs
-    int* counts_host = nullptr;   // pinned
+    int* counts_host = nullptr;   // pinned: the pass's valid count, one copy per recorded launch
+    std::vector<kpn_batch> batch; // which batch of the pass the launch was
     size_t used = 0, cap = 0;
     int V = 0;
 };
@@ -578,32 +609,38 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
-    hipMemsetAsync(count, 0, 4 * sizeof(int), (hipStream_t)stream);  // [0] valid count, [1] k_geo_rows tickets, [2] k_fuse_color tickets
+    hipMemsetAsync(count, 0, 128 * sizeof(int), (hipStream_t)stream);
     const int ppt = mask_points_per_thread(N);
     KPN_LAUNCH(k_mask_compact, grid1d(N, 256 * ppt), dim3(256), stream, sc, ps, N, mode, lean, ppt, wp + kpn_scalar_off(), out, valid, list, count);
     const int blocks = field_grid_blocks();
-#ifndef KPN_SIMT_EMU
-    const bool prof = g_prof.on && g_prof.used < g_prof.cap;
-    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
-#endif
-    if (geo_rows_mode() == 1)
-        KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
-    else
-        KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1, xscr);
-#ifndef KPN_SIMT_EMU
-    if (prof) {
-        (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
-        (void)hipMemcpyAsync(g_prof.counts_host + g_prof.used, count, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
-        g_prof.V = sc.V;
-        ++g_prof.used;
-    }
-#endif
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
     static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
-    // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going to
-    // read them again (keep_rows)
-    KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, count + 1,
-               (const float*)xscr, mode, keep_rows ? 0 : 1, out);
+    if (keep_rows && L.nbatch > 1) return fail(KPN_EWORKSPACE, "a pass whose rows a backward call reads again must fit the row scratch");
+    for (int b = 0; b < L.nbatch; ++b) {
+        const kpn_batch batch{b, L.tiles_cap};
+        int* tickets = count + 1 + 2 * b;
+#ifndef KPN_SIMT_EMU
+        const bool prof = g_prof.on && g_prof.used < g_prof.cap;
+        if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
+#endif
+        if (geo_rows_mode() == 1)
+            KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+        else
+            KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+#ifndef KPN_SIMT_EMU
+        if (prof) {
+            (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
+            (void)hipMemcpyAsync(g_prof.counts_host + g_prof.used, count, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+            g_prof.batch[g_prof.used] = batch;
+            g_prof.V = sc.V;
+            ++g_prof.used;
+        }
+#endif
+        // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going
+        // to read them again (keep_rows)
+        KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                   (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch);
+    }
     return check_launch("field query");
 }
 }  // namespace
@@ -637,6 +674,7 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
 // backward of the field evaluation
 namespace {
 const int64_t kBwdChunk = 262144;  // points per pass: V=3 -> 786432 rows x 4.3 KB of dumps = 3.4 GB
+static_assert(kBwdChunk <= 262144, "kUncappedPoints (query_layout) must cover a backward pass");
 #ifdef KPN_SIMT_EMU
 const int kGradWorkers = 3;     // row workers (one workgroup each; its waves are the column groups)
 #else
@@ -803,7 +841,8 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, vcount, V, rows_dev);
         if (full) {
             if (!fwd_query_ws)
-                KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 1, xscr);
+                KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 1, xscr,
+                           kpn_batch{0, 1 << 30});
             if (full == 2) {
                 // rows of dropped views are skipped by k_color_bwd: their dumps must read as zeros in k_weight_grad
                 if (views_dropped) hipMemsetAsync(fp(L.color), 0, L.color_bytes, (hipStream_t)stream);
@@ -902,16 +941,13 @@ extern "C" int kpn_query_backward(const kpn_scene_desc* d, const void* scene_ws,
 namespace {
 struct RenderLayout { size_t cam_pos, dirs, nearv, farv, zc, zf, zn, src, rgba, rgba_c, rgba_n, contrib, color, depth, alpha, sdf, query, total; int64_t chunk; };
 int64_t pick_chunk(const kpn_scene_desc* d, const kpn_render_args* a) {
-    // default: as few, as equal passes as keep the row scratch (points x views x 320 B) under 40 GiB (of 288) and a pass under
-    // 262144 rays — large passes amortise launch ramps and the per-workgroup weight staging of the persistent field
-    // kernels (measured per 512^2 frame: 65536 rays/pass 33.6 ms, 131072 33.3 ms, 262144 32.2 ms)
+    // default: passes of up to 262144 rays (one per 512^2 frame) — large passes amortise launch ramps and the per-workgroup
+    // weight staging of the persistent field kernels (measured per 512^2 frame: 65536 rays/pass 33.6 ms, 131072 33.3 ms,
+    // 262144 32.2 ms).  The row scratch no longer scales with the pass: it is capped (query_layout) and reused by batches.
     const int64_t R = (int64_t)a->nx * a->ny;
     int64_t c = a->chunk_rays;
     if (c <= 0) {
-        const int64_t Sfull = a->n_coarse + (a->fine ? a->n_fine : 0);
-        int64_t cmax = (40ll << 30) / (Sfull * d->n_views * (int64_t)(KPN_ROW_SLABS * 32)) / 4096 * 4096;
-        if (cmax < 4096) cmax = 4096;
-        if (cmax > 262144) cmax = 262144;
+        const int64_t cmax = 262144;
         const int64_t npass = (R + cmax - 1) / cmax;
         c = ((R + npass - 1) / npass + 63) / 64 * 64;
     }
@@ -1206,6 +1242,7 @@ extern "C" int kpn_profile_enable(int32_t on) {
     if (on && g_prof.cap == 0) {
         g_prof.cap = 8192;
         g_prof.ev.resize(2 * g_prof.cap);
+        g_prof.batch.resize(g_prof.cap);
         for (auto& e : g_prof.ev) if (hipEventCreate(&e) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventCreate failed");
         if (hipHostMalloc((void**)&g_prof.counts_host, g_prof.cap * sizeof(int), 0) != hipSuccess)
             return fail(KPN_ELAUNCH, "hipHostMalloc failed");
@@ -1215,22 +1252,34 @@ extern "C" int kpn_profile_enable(int32_t on) {
 #endif
     return KPN_OK;
 }
-extern "C" int kpn_profile_collect(double* ms_out, int64_t* launches_out, int64_t* rows_out) {
-    KPN_REQUIRE(ms_out && launches_out && rows_out, "null pointer");
-    *ms_out = 0.0; *launches_out = 0; *rows_out = 0;
+extern "C" int kpn_profile_collect2(double* ms_out, int64_t* launches_out, int64_t* rows_out, int64_t* surplus_out) {
+    KPN_REQUIRE(ms_out && launches_out && rows_out && surplus_out, "null pointer");
+    *ms_out = 0.0; *launches_out = 0; *rows_out = 0; *surplus_out = 0;
 #ifndef KPN_SIMT_EMU
     for (size_t i = 0; i < g_prof.used; ++i) {
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventSynchronize failed");
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventElapsedTime failed");
+        // rows of this launch: the same arithmetic as kpn_batch_range (field_kernels.hip) on the pass's valid count
+        const int64_t count = g_prof.counts_host[i];
+        const kpn_batch b = g_prof.batch[i];
+        const int64_t ntiles = (count + KPN_TILE - 1) / KPN_TILE;
+        const int64_t nb = (ntiles + b.tiles_cap - 1) / b.tiles_cap;
+        if (b.index >= nb) { ++*surplus_out; continue; }     // surplus batch: returned at once, nothing processed
+        const int64_t p0 = ntiles * b.index / nb * KPN_TILE, p1 = ntiles * (b.index + 1) / nb * KPN_TILE;
+        *rows_out += ((p1 < count ? p1 : count) - p0) * g_prof.V;
         *ms_out += ms;
-        *rows_out += (int64_t)g_prof.counts_host[i] * g_prof.V;
+        ++*launches_out;
     }
-    *launches_out = (int64_t)g_prof.used;
     g_prof.used = 0;
 #endif
     return KPN_OK;
 }
+extern "C" int kpn_profile_collect(double* ms_out, int64_t* launches_out, int64_t* rows_out) {
+    int64_t surplus = 0;
+    return kpn_profile_collect2(ms_out, launches_out, rows_out, &surplus);
+}
+extern "C" size_t kpn_row_scratch_cap_bytes(void) { return row_scratch_cap_bytes(); }
 extern "C" double kpn_flops_per_row(void) { return 2.0 * 70080.0; }
 
 extern "C" double kpn_flops_per_point(int32_t V) {

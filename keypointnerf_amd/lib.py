@@ -97,6 +97,8 @@ _SIGNATURES = {
     "kpn_flops_per_row": (ctypes.c_double, []),
     "kpn_profile_enable": (ctypes.c_int, [c_i32]),
     "kpn_profile_collect": (ctypes.c_int, [c_p, c_p, c_p]),
+    "kpn_profile_collect2": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
+    "kpn_row_scratch_cap_bytes": (ctypes.c_size_t, []),
     "kpn_selftest_mfma": (ctypes.c_int, [c_p, c_p, c_p]),
 }
 ABI_VERSION = 1
