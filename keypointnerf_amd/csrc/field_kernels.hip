@@ -515,6 +515,29 @@ __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows,
     return pwsum;
 }
 
+// Copy of the k_fuse_color region of the packed weights (segments SEG_G2_0.., scalars, row vectors) into LDS.  The W part
+// of a segment whose lanes take more than one float4 per group (NOB = 2: G * NOB / 4 = 2) is re-laid from the global
+// [group][lane][q] to [group][q][lane], the conflict-free order for ds_read_b128 (kpn_load_group<NQ, 1>); everything
+// else (NQ = 1 streams, biases, scalars, row vectors) is copied as it is.
+__device__ __forceinline__ void kpn_stage_lds_streams(const float* __restrict__ wp, float* __restrict__ wlds) {
+    const float4* src = reinterpret_cast<const float4*>(wp + kpn_k2_base());
+    float4* dst = reinterpret_cast<float4*>(wlds);
+    for (int i = threadIdx.x; i < kpn_k2_floats() / 4; i += blockDim.x) {
+        int j = i;
+#pragma unroll
+        for (int seg = SEG_G2_0; seg < SEG_COUNT; ++seg) {
+            const int nq = kpn_seg_shapes[seg].g * kpn_seg_shapes[seg].nob / 4;
+            if (nq == 1) continue;
+            const int w0 = (kpn_seg_woff(seg) - kpn_k2_base()) / 4, w1 = w0 + kpn_seg_wfloats(seg) / 4;
+            if (i >= w0 && i < w1) {
+                const int r = i - w0, g = r / (64 * nq), e = r - g * 64 * nq;   // e = lane * nq + q
+                j = w0 + g * 64 * nq + (e % nq) * 64 + e / nq;
+            }
+        }
+        dst[j] = src[i];
+    }
+}
+
 // Any V <= KPN_MAXV: the per-view x' vectors are recomputed in each of the three passes over the views (two for the
 // weighted mean / variance, one for the head).  A V <= 3 variant that kept them in registers was measured slower: this
 // kernel is register-bound, and every spilled VGPR costs more than re-running the 624-MAC ray encoder.
@@ -534,11 +557,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
     // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
     __shared__ __attribute__((aligned(16))) float wlds[kpn_k2_floats()];
-    {
-        const float4* src = reinterpret_cast<const float4*>(wp + kpn_k2_base());
-        float4* dst = reinterpret_cast<float4*>(wlds);
-        for (int i = threadIdx.x; i < kpn_k2_floats() / 4; i += blockDim.x) dst[i] = src[i];
-    }
+    kpn_stage_lds_streams(wp, wlds);
     __syncthreads();
     const float* wl = wlds - kpn_k2_base();
     const float ani = wl[kpn_scalar_off() + 0];  // |ani_al|

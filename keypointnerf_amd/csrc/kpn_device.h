@@ -204,9 +204,13 @@ __device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, 
         for (int q = 0; q < NQ; ++q) w[q] = src[q];
 #endif
     } else {
-        const kpn_lptr4 src = KPN_LDS4(gbase) + lane * NQ;
+        // LDS copy of a stream: [group][q][64 lanes] float4 (re-laid by kpn_stage_lds_streams).  ds_read_b128 is served in
+        // four 16-lane groups over a 256-B bank row: consecutive lanes 16 B apart fill it exactly, whereas the global
+        // layout's 32-B lane stride (NQ = 2) put two lanes of every group on each 16-B slot (2-way conflict on every read:
+        // SQ_LDS_BANK_CONFLICT 3.0e8 vs SQ_INSTS_LDS 2.8e8 per two frames, profiles/r02_a_pmc_counters.txt).
+        const kpn_lptr4 src = KPN_LDS4(gbase) + lane;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) w[q] = src[q];
+        for (int q = 0; q < NQ; ++q) w[q] = src[q * 64];
     }
 }
 // in_fn(kpn_ic<g>, float (&x)[G]) produces the B operands of K-steps [g*G, (g+1)*G)
