@@ -216,7 +216,15 @@ int kpn_render_rays(const kpn_scene_desc* desc, const void* scene_ws, const floa
  *
  * kpn_mse_psnr: ZJUEvaluator.compute_score's mse / _compute_psnr (src/zju_evaluator.py:16-19,63-64):
  * mse = mean((pred-gt)^2) over all n elements, psnr = -10 ln(mse)/ln(10).  out2 (device, 2 doubles) = [mse, psnr];
- * partial sums are accumulated in fp64.  scratch: 2048 doubles + 1 int (device, 16,392 bytes). */
+ * partial sums are accumulated in fp64.  scratch: 2048 doubles + 1 int (device, 16,392 bytes).
+ *
+ * kpn_pix_l1_loss: the L1 terms of the training loss - pix_loss(src, tar, {"l1": lambda}) (src/utils.py:164-168) as
+ * compute_error_nerf applies it to tex_cal = tex_fg (lambda_l1_c) and tex_cal_fine = tex_fg_fine (lambda_l1), src/utils.py:
+ * 128-145, configs/zju.json:109-112 - together with its gradient: loss[0] (device) = lambda * mean|src - tar| over n
+ * elements; d_src (n floats, may be NULL) = lambda * sign(src - tar) / n, i.e. what loss.backward() hands to the renderer
+ * (the d_tex_fg / d_tex_fg_fine of kpn_render_grads).  scratch: 16,392 bytes as kpn_mse_psnr.  Deterministic. */
+int kpn_pix_l1_loss(const float* src, const float* tar, int64_t n, float lambda, float* loss, float* d_src, void* scratch,
+                    void* stream);
 int kpn_frame_to_rgb8(const float* chw, int32_t height, int32_t width, int32_t bgr, uint8_t* hwc_out, void* stream);
 int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2, void* scratch, void* stream);
 /* kpn_ssim: ZJUEvaluator._compute_ssim (src/zju_evaluator.py:21-45) = skimage 0.19 (environment.yml:135)

@@ -1216,6 +1216,19 @@ extern "C" int kpn_mse_psnr(const float* pred, const float* gt, int64_t n, doubl
     return check_launch("kpn_mse_psnr");
 }
 
+extern "C" int kpn_pix_l1_loss(const float* src, const float* tar, int64_t n, float lambda, float* loss, float* d_src, void* scratch,
+                               void* stream) {
+    KPN_REQUIRE(src && tar && loss && scratch, "null pointer");
+    KPN_REQUIRE(n > 0, "empty image");
+    double* partial = static_cast<double*>(scratch);
+    int* ticket = reinterpret_cast<int*>(partial + 2048);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    (void)hipMemsetAsync(ticket, 0, sizeof(int), (hipStream_t)stream);
+    KPN_LAUNCH(k_pix_l1, dim3((unsigned)blocks), dim3(256), stream, n, lambda, src, tar, partial, ticket, loss, d_src);
+    return check_launch("kpn_pix_l1_loss");
+}
+
 extern "C" size_t kpn_ssim_scratch_bytes(int32_t w, int32_t h) {
     if (w < 7 || h < 7) return 0;
     return align_up((size_t)5 * 3 * (h - 6) * w * sizeof(float), 256) + 2048 * sizeof(double) + 256;

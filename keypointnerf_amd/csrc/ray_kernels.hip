@@ -538,6 +538,43 @@ __global__ __launch_bounds__(256) void k_mse_psnr(int64_t n, const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// pix_loss's L1 term (reference src/utils.py:164-168): loss = lambda * mean|src - tar|, and what autograd derives for it,
+// d loss / d src = lambda * sign(src - tar) / n (sign(0) = 0, torch's abs backward) — the seed gradient of
+// kpn_render_rays_train_backward for tex_fg (lambda_l1_c, coarse) and tex_fg_fine (lambda_l1, fine), src/utils.py:128-145.
+// Deterministic: per-block fp64 partial sums, the last block adds them in block order.
+__global__ __launch_bounds__(256) void k_pix_l1(int64_t n, float lambda, const float* __restrict__ src, const float* __restrict__ tar,
+                                                double* __restrict__ partial, int* __restrict__ ticket, float* __restrict__ loss,
+                                                float* __restrict__ d_src) {
+    __shared__ double red[256];
+    __shared__ int last;
+    double acc = 0.0;
+    const float gscale = lambda / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = KSUB(src[i], tar[i]);
+        acc += (double)fabsf(d);
+        if (d_src) d_src[i] = d > 0.0f ? gscale : (d < 0.0f ? -gscale : 0.0f);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0];
+        __threadfence();
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double tot = 0.0;
+        for (unsigned k = 0; k < gridDim.x; ++k) tot += ((volatile double*)partial)[k];
+        loss[0] = lambda * (float)(tot / (double)n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // SSIM as ZJUEvaluator._compute_ssim computes it (reference src/zju_evaluator.py:21-45): skimage 0.19's
 // structural_similarity(pred, gt, multichannel=True) on the crop [y0, y0+h) x [x0, x0+w) of two float32 images —
 // 7x7 uniform window (scipy.ndimage.uniform_filter: separable, fp64 accumulation, fp32 result per axis), sample

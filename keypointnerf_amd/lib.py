@@ -96,6 +96,7 @@ _SIGNATURES = {
     "kpn_flops_per_point": (ctypes.c_double, [c_i32]),
     "kpn_flops_per_row": (ctypes.c_double, []),
     "kpn_profile_enable": (ctypes.c_int, [c_i32]),
+    "kpn_pix_l1_loss": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, ctypes.c_float, c_p, c_p, c_p, c_p]),
     "kpn_profile_collect": (ctypes.c_int, [c_p, c_p, c_p]),
     "kpn_profile_collect2": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     "kpn_row_scratch_cap_bytes": (ctypes.c_size_t, []),

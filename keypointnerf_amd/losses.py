@@ -1,0 +1,71 @@
+"""Training loss of the reference (compute_error / compute_error_nerf / pix_loss, reference src/utils.py:97-196) with its
+L1 terms on the device — SURVEY.md §8(f) row 3.
+
+``compute_error(out_nerf, vggloss, lambdas)`` has the reference's signature, returns the reference's ``(loss, err_dict)``
+with the reference's keys (``e_pix_c``, ``e_pix_l1``, ``e_vgg``, ``e_all``) and is differentiable: the two L1 terms —
+``lambda_l1_c * mean|tex_cal - tar|`` (coarse) and ``lambda_l1 * mean|tex_cal_fine - tar|`` (fine), configs/zju.json:109-112 —
+are ``torch.ops.kpnerf.pix_l1_loss`` (one kernel each, value and seed gradient together), so ``loss.backward()`` hands
+``kpn_render_rays_train_backward`` its ``d_tex_fg`` / ``d_tex_fg_fine`` without eager elementwise passes.  The perceptual
+term stays the caller's ``vggloss`` module (a pretrained torchvision VGG19 — model weights that are not part of this
+path; its gradient joins ``d_tex_fg_fine`` through autograd).  Terms the shipped configuration switches off (l2, lp, ssim,
+top-k, mask loss, aux outputs) are refused rather than silently dropped.
+
+``install_loss(module)`` rebinds the module-global ``compute_error`` that ``KeypointNeRF.forward`` looks up
+(reference src/model.py:894) — the same kind of seam as dropin.install uses for the renderer.
+"""
+import torch
+
+from . import torch_ops  # noqa: F401  (registers torch.ops.kpnerf.*)
+
+
+def pix_loss(src, tar, w_losses={"l1": 1.0}):
+    """reference src/utils.py:159-185, L1 term only."""
+    losses = {}
+    for k, v in w_losses.items():
+        if v <= 0.0:
+            continue
+        if k != "l1":
+            raise NotImplementedError(f"pix_loss term {k!r} is switched off in configs/zju.json and not built here")
+        losses[k] = torch.ops.kpnerf.pix_l1_loss(src.contiguous(), tar.contiguous(), float(v))[0]
+    return losses
+
+
+def compute_error_nerf(out_nerf, lambdas, vggloss):
+    """reference src/utils.py:108-171 for the outputs batch_render_pifu_nerf produces (no aux heads)."""
+    lambda_l1_c = lambdas.get("lambda_l1_c", 10.0)
+    pix_weights = {"l1": lambdas.get("lambda_l1", 10.0), "l2": lambdas.get("lambda_l2", 0.0), "lp": lambdas.get("lambda_lp", 0.0),
+                   "ssim": lambdas.get("lambda_ssim", 0.0)}
+    lambda_vgg = lambdas.get("lambda_vgg", 1.0)
+    if lambdas.get("lambda_mloss", 0.0) > 0.0 or any("top" in k for k in lambdas):
+        raise NotImplementedError("mask loss / top-k pixel losses are not used by configs/zju.json and not built here")
+    if "tex_aux_cal" in out_nerf or "tex_aux_cal_fine" in out_nerf:
+        raise NotImplementedError("auxiliary texture heads are not produced by batch_render_pifu_nerf")
+    err_dict = {}
+    if "tex_cal" in out_nerf and lambda_l1_c > 0.0:
+        err_dict["e_pix_c"] = pix_loss(out_nerf["tex_cal"], out_nerf["tar_img"], {"l1": lambda_l1_c})["l1"]
+    if "tex_cal_fine" in out_nerf:
+        for k, v in pix_loss(out_nerf["tex_cal_fine"], out_nerf["tar_img"], pix_weights).items():
+            err_dict[f"e_pix_{k}"] = v
+    if vggloss is not None and "tex_cal_fine" in out_nerf:
+        loss_vgg = lambda_vgg * vggloss(out_nerf["tex_cal_fine"], out_nerf["tar_img"])
+        if loss_vgg > 0.0:                       # the reference's own test, src/utils.py:168 (one host sync, as there)
+            err_dict["e_vgg"] = loss_vgg
+    return err_dict
+
+
+def compute_error(out_nerf=None, vggloss=None, lambdas={}):
+    """reference src/utils.py:97-106."""
+    err_dict = compute_error_nerf(out_nerf, lambdas, vggloss)
+    loss = 0.0
+    for v in err_dict.values():
+        loss = loss + v
+    err_dict["e_all"] = loss
+    return loss, err_dict
+
+
+def install_loss(model_module):
+    """Rebinds ``compute_error`` in the namespace KeypointNeRF.forward resolves it in (``src.model``); returns the
+    reference's function so that it can be restored."""
+    ref = model_module.compute_error
+    model_module.compute_error = compute_error
+    return ref

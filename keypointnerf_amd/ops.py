@@ -482,6 +482,20 @@ def mse_psnr(pred, gt):
     return out
 
 
+def pix_l1_loss(src, tar, lam, want_grad=True):
+    """pix_loss(src, tar, {"l1": lam})["l1"] of the reference (src/utils.py:164-168) and d loss / d src: returns
+    (loss: 0-dim device tensor, d_src: tensor like src or None)."""
+    L = kl.get_library()
+    a, b = _dev(src, "src"), _dev(tar, "tar")
+    if a.shape != b.shape:
+        raise ValueError("src and tar must have the same shape")
+    loss = torch.empty(1, dtype=_f32, device=a.device)
+    d = torch.empty_like(a) if want_grad else None
+    scratch = torch.empty(2048 * 8 + 8, dtype=torch.uint8, device=a.device)
+    L.check(L.kpn_pix_l1_loss(_p(a), _p(b), a.numel(), float(lam), _p(loss), _p(d), _p(scratch), _stream()))
+    return loss.reshape(()), d
+
+
 def ssim(pred, gt, mask_at_box=None):
     """SSIM of ZJUEvaluator._compute_ssim (reference src/zju_evaluator.py:21-45): pred, gt (3,H,W) or (1,3,H,W) in [0,1];
     mask_at_box (H,W): the images are cropped to its bounding rectangle (cv2.boundingRect) first.  Returns a float."""

@@ -19,6 +19,8 @@ calling them on CPU tensors raises NotImplementedError from the dispatcher.
 
 ``scene_ws / scene_dims / scene_scalars`` come from ``ops.PreparedScene.as_op_args()``.
 
+    torch.ops.kpnerf.pix_l1_loss(src, tar, lam) -> (loss, d loss / d src)   the L1 terms of the training loss, DIFFERENTIABLE
+
 ``rgba2out`` and ``render_rays_train`` carry ``register_autograd`` formulas whose backward is itself a registered op
 (``kpnerf::rgba2out_backward``, ``kpnerf::render_rays_train_backward`` = kpn_render_rays_train_backward): gradients reach
 the flat effective-parameter vector ``plain`` (and from there ``weight_g`` / ``weight_v`` / ``bias`` / ``ani_al`` through
@@ -226,3 +228,28 @@ def _train_bwd(ctx, *grads):
 
 
 render_rays_train.register_autograd(_train_bwd, setup_context=_train_setup)
+
+
+@_lib.custom_op("kpnerf::pix_l1_loss", mutates_args=(), device_types="cuda")
+def pix_l1_loss(src: torch.Tensor, tar: torch.Tensor, lam: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(lam * mean|src - tar|, d loss / d src) = the L1 term of the reference's pix_loss (src/utils.py:164-168) and the seed
+    gradient autograd derives for it (kpn_pix_l1_loss).  Differentiable w.r.t. src."""
+    loss, d = ops.pix_l1_loss(src, tar, lam, want_grad=True)
+    return loss, d.reshape(src.shape)
+
+
+@pix_l1_loss.register_fake
+def _(src, tar, lam):
+    return src.new_empty(()), torch.empty_like(src)
+
+
+def _l1_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+
+
+def _l1_bwd(ctx, d_loss, _d_grad):
+    (g,) = ctx.saved_tensors
+    return g * d_loss, None, None
+
+
+pix_l1_loss.register_autograd(_l1_bwd, setup_context=_l1_setup)

@@ -706,6 +706,17 @@ void kpo_mse_psnr(const float* pred, const float* gt, int64_t n, double* out2) {
     out2[1] = -10.0 * log(out2[0]) / log(10.0);
 }
 
+/* pix_loss's L1 term and its autograd gradient (utils.py:164-168: v * (src - tar).abs().mean(); abs' = sign, sign(0) = 0) */
+void kpo_pix_l1_loss(const float* src, const float* tar, int64_t n, float lambda, float* loss, float* d_src) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        float d = src[i] - tar[i];
+        acc += fabs((double)d);
+        if (d_src) d_src[i] = d > 0.0f ? lambda / (float)n : (d < 0.0f ? -lambda / (float)n : 0.0f);
+    }
+    loss[0] = lambda * (float)(acc / (double)n);
+}
+
 /* ------------------------------------------------------------------------------------------
  * Backward of rgba2out (model.py:1162-1174) as torch autograd derives it; fp64 restatement.  z has no gradient
  * in the reference (drawn under no_grad).  d_* may be NULL (= zero upstream gradient). */

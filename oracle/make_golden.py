@@ -474,6 +474,43 @@ def run_output_case(name, seed=9):
     print(f"{name}: psnr={psnr:.4f} -> {path}")
 
 
+def run_loss_case(name="case_r_loss", seed=23):
+    """The reference's training loss (compute_error, src/utils.py:97-171) with the shipped lambdas (configs/zju.json:
+    109-119) on a random 64x64 patch as KeypointNeRF.forward assembles it (src/model.py:885-894; VGG stubbed out: it needs
+    downloaded weights), and the gradients loss.backward() sends to tex_fg / tex_fg_fine."""
+    rmodel = ref_shim.load_reference()
+    import src.utils as rutils
+    cfg = ref_shim.load_config()
+
+    def find(d, key):
+        if isinstance(d, dict):
+            if key in d:
+                return d[key]
+            for v in d.values():
+                r = find(v, key)
+                if r is not None:
+                    return r
+        return None
+    lambdas = find(cfg, "lambdas")
+    g = torch.Generator().manual_seed(seed)
+    tex_c = torch.rand(1, 3, 64, 64, generator=g).requires_grad_(True)
+    tex_f = torch.rand(1, 3, 64, 64, generator=g).requires_grad_(True)
+    tar = torch.rand(1, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        tar[0, :, :8] = tex_f[0, :, :8]          # exact ties: abs'(0) = 0 in torch
+    out = {"tex_fg": tex_c, "tex_fg_fine": tex_f, "tar_img": tar, "tex": tex_c, "tex_cal": tex_c, "tex_fine": tex_f,
+           "tex_cal_fine": tex_f}
+    loss, err = rutils.compute_error(out_nerf=out, vggloss=None, lambdas=lambdas)
+    loss.backward()
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, tex_fg=_np(tex_c), tex_fg_fine=_np(tex_f), tar_img=_np(tar), loss=np.float32(float(loss)),
+                        e_pix_c=np.float32(float(err["e_pix_c"])), e_pix_l1=np.float32(float(err["e_pix_l1"])),
+                        err_keys=np.array(sorted(err.keys())), d_tex_fg=_np(tex_c.grad), d_tex_fg_fine=_np(tex_f.grad),
+                        lambda_l1_c=np.float32(lambdas["lambda_l1_c"]), lambda_l1=np.float32(lambdas["lambda_l1"]),
+                        lambdas_json=np.array(__import__("json").dumps(lambdas)))
+    print(f"{name}: loss={float(loss):.6f} keys={sorted(err.keys())} -> {path}")
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     net = ref_shim.build_reference_net(seed=0)
@@ -483,6 +520,9 @@ def main():
         return
     if "--only-sigma" in sys.argv:
         run_sigma_nofine_case(net)
+        return
+    if "--only-loss" in sys.argv:
+        run_loss_case()
         return
     if "--only-headline" in sys.argv:
         run_headline_cases(net)
@@ -511,6 +551,7 @@ def main():
     run_nofgmask_case(net)
     run_sigma_nofine_case(net)
     run_headline_cases(net)
+    run_loss_case()
 
 
 def run_headline_cases(net):

@@ -180,6 +180,14 @@ def mse_psnr(pred, gt):
     return out
 
 
+def pix_l1_loss(src, tar, lam):
+    """lambda * mean|src - tar| and its gradient w.r.t. src (reference src/utils.py:164-168)."""
+    a, b = _f32(src).reshape(-1), _f32(tar).reshape(-1)
+    loss, d = np.empty(1, np.float32), np.empty_like(a)
+    lib().kpo_pix_l1_loss(_ptr(a), _ptr(b), ctypes.c_int64(a.size), ctypes.c_float(lam), _ptr(loss), _ptr(d))
+    return float(loss[0]), d.reshape(np.shape(src))
+
+
 def query_ex(oscene, wflat, pts, view, apply_eval_func=False, keep=0xFFFFFFFF, noise=None, noise_std=0.0):
     pts, view = _f32(pts).reshape(-1, 3), _f32(view).reshape(-1, 3)
     N = pts.shape[0]

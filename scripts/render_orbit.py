@@ -34,7 +34,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from keypointnerf_amd import ops
-    from keypointnerf_amd.parallel import orbit_target_camera, render_job
+    from keypointnerf_amd.parallel import orbit_cam_tar, render_job, zju_orbit_cameras
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
 
     scene = make_scene(args.views, (args.res, args.res), (args.res, args.res), "ellipsoid", seed=1, device="cuda")
@@ -42,8 +42,15 @@ def main():
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"], scene["src_foreground_mask"])
     plan = ops.RenderPlan(ps, (0, 0, 1, args.res, args.res), args.samples, args.samples, fine=True)
 
+    # the reference's own turntable (get_360cameras as render_video_zju calls it, src/model.py:178-214, src/utils.py:23-72:
+    # 90 cameras at 5 m, focal 1337.6 px at 512, near/far 2/8).  The head pose is the subject's frame: the synthetic
+    # subject stands along world -y (OpenCV y-down sources), i.e. rotated by pi about x against the orbit's convention.
+    headpose = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0])).cuda()
+    cams = zju_orbit_cameras(headpose, sc_factor=1.0, n_frames=90, im_w=args.res, im_h=args.res)
+    cam_tars = [orbit_cam_tar(c) for c in cams]
+
     def render_frame(i):
-        cam = orbit_target_camera(scene["cam_tar"], i % 90, n_frames=90)          # camera = orbit[frame_index % 90]
+        cam = cam_tars[i % 90]                                                      # camera = orbit[frame_index % 90], :214
         out = ops.render_rays(ps, w, cam, scene["bounds"], plan=plan)
         return ops.frame_to_rgb8(out["tex_fg_fine"]).permute(2, 0, 1).contiguous()  # (3,H,W) uint8, what the gather moves
 

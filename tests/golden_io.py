@@ -84,3 +84,45 @@ def check_query_against_reference(out, valid, g, i, scene, tol):
     if (m & ~well).any():
         assert err[m & ~well].max() < 20 * tol
     return int((m & well).sum()), int((m & ~well).sum())
+
+
+def ssim_from_definition(x_chw, y_chw, data_range=2.0, win=7):
+    """SSIM straight from its published definition (Wang, Bovik, Sheikh, Simoncelli 2004, eq. 13 with the two-constant
+    form), in float64 with explicit loops over windows — no filtering library: for every fully interior win x win window
+    the means, the UNBIASED sample variances / covariance (skimage's use_sample_covariance default), C1 = (0.01 L)^2,
+    C2 = (0.03 L)^2 with L = data_range (2 for float images in skimage 0.19, which is what reference
+    src/zju_evaluator.py:44 inherits), averaged over windows and then over channels.  Hand-checkable, slow: small images."""
+    x, y = np.asarray(x_chw, np.float64), np.asarray(y_chw, np.float64)
+    C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    n = win * win
+    per_channel = []
+    for c in range(x.shape[0]):
+        vals = []
+        for i in range(x.shape[1] - win + 1):
+            for j in range(x.shape[2] - win + 1):
+                a, b = x[c, i:i + win, j:j + win].reshape(-1), y[c, i:i + win, j:j + win].reshape(-1)
+                ma, mb = a.sum() / n, b.sum() / n
+                va, vb = ((a - ma) ** 2).sum() / (n - 1), ((b - mb) ** 2).sum() / (n - 1)
+                cab = ((a - ma) * (b - mb)).sum() / (n - 1)
+                vals.append(((2 * ma * mb + C1) * (2 * cab + C2)) / ((ma * ma + mb * mb + C1) * (va + vb + C2)))
+        per_channel.append(np.mean(vals))
+    return float(np.mean(per_channel))
+
+
+def ssim_pin_cases():
+    """(name, pred, gt, expected) with expected from the definition above or in closed form."""
+    rng = np.random.default_rng(31)
+    H, W = 19, 23
+    gt = rng.random((3, H, W)).astype(np.float32)
+    pred = np.clip(gt + 0.1 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    ramp = np.broadcast_to(np.linspace(0.1, 0.9, W, dtype=np.float32)[None, None], (3, H, W)).copy()
+    a, b = np.float32(0.25), np.float32(0.75)
+    C1 = (0.01 * 2.0) ** 2
+    cases = [("noisy copy", pred, gt, ssim_from_definition(pred, gt)),
+             ("ramp vs shifted ramp", ramp, (ramp + np.float32(0.05)), ssim_from_definition(ramp, ramp + np.float32(0.05))),
+             ("anticorrelated", gt, (1.0 - gt).astype(np.float32), ssim_from_definition(gt, 1.0 - gt)),
+             # two constant images: every variance and covariance is 0, the structure term is C2/C2 = 1
+             ("constants", np.full((3, H, W), a), np.full((3, H, W), b),
+              (2 * float(a) * float(b) + C1) / (float(a) ** 2 + float(b) ** 2 + C1)),
+             ("identical", gt, gt, 1.0)]
+    return cases

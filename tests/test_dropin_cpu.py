@@ -68,3 +68,17 @@ def test_install_refuses_unsupported_spatial_encoders():
     net.sp_encoder.sp_type = "rel_z"                                 # same feature width, different arithmetic
     with pytest.raises(NotImplementedError):
         install(net)
+
+
+def test_install_loss_rebinds_the_global_forward_resolves():
+    """KeypointNeRF.forward calls the module-global compute_error (src/model.py:894): install_loss swaps exactly that name."""
+    from keypointnerf_amd import losses
+    rmodel = ref_shim.load_reference()
+    ref = losses.install_loss(rmodel)
+    try:
+        assert rmodel.compute_error is losses.compute_error
+        assert rmodel.KeypointNeRF.forward.__globals__["compute_error"] is losses.compute_error
+    finally:
+        rmodel.compute_error = ref
+    import inspect
+    assert list(inspect.signature(losses.compute_error).parameters) == list(inspect.signature(ref).parameters)

@@ -261,3 +261,35 @@ def test_training_step_through_the_dropin(monkeypatch, case, seed):
     assert abs(float(got_params["mlp_tex.ani_al"]) - ref) <= 2e-3 * abs(ref) + 1e-6
     for t, key in ((feat_geo[0], "d_geo0"), (feat_geo[1], "d_geo1"), (feat_tex, "d_tex")):
         assert np.abs(t.grad.cpu().numpy() - g[key]).max() <= 1e-4 * np.abs(g[key]).max(), key
+
+
+def test_training_loss_on_the_device():
+    """keypointnerf_amd.losses.compute_error = the reference's compute_error (src/utils.py:97-171) with the L1 terms as
+    torch.ops.kpnerf.pix_l1_loss: same (loss, err_dict) and, after loss.backward(), the same gradients on tex_fg /
+    tex_fg_fine as the reference's autograd recorded (golden case R); a VGG stand-in adds its term through autograd."""
+    import os
+    from keypointnerf_amd.losses import compute_error
+    from tests.golden_io import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "case_r_loss.npz"))
+    import json
+    lambdas = json.loads(str(g["lambdas_json"]))
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    tex_c, tex_f = t("tex_fg").requires_grad_(True), t("tex_fg_fine").requires_grad_(True)
+    out = {"tex_fg": tex_c, "tex_fg_fine": tex_f, "tar_img": t("tar_img"), "tex": tex_c, "tex_cal": tex_c, "tex_fine": tex_f,
+           "tex_cal_fine": tex_f}
+    loss, err = compute_error(out_nerf=out, vggloss=None, lambdas=lambdas)
+    assert sorted(err) == list(g["err_keys"])
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * float(g["loss"])
+    assert abs(float(err["e_pix_c"]) - float(g["e_pix_c"])) <= 2e-6 and abs(float(err["e_pix_l1"]) - float(g["e_pix_l1"])) <= 2e-5
+    loss.backward()
+    assert np.array_equal(tex_c.grad.cpu().numpy(), g["d_tex_fg"]) and np.array_equal(tex_f.grad.cpu().numpy(), g["d_tex_fg_fine"])
+    # with a perceptual term (stand-in for the reference's VGGLoss module): its gradient joins through autograd
+    tex_f.grad = None
+    vgg = lambda a, b: ((a - b) ** 2).mean()
+    loss2, err2 = compute_error(out_nerf=out, vggloss=vgg, lambdas=lambdas)
+    assert "e_vgg" in err2 and abs(float(loss2) - float(loss) - 0.5 * float(((tex_f - out["tar_img"]) ** 2).mean())) < 1e-5
+    loss2.backward()
+    extra = (0.5 * 2.0 * (tex_f - out["tar_img"]) / tex_f.numel()).detach().cpu().numpy()
+    assert np.abs(tex_f.grad.cpu().numpy() - (g["d_tex_fg_fine"] + extra)).max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        compute_error(out_nerf=out, vggloss=None, lambdas=dict(lambdas, lambda_l2=1.0))

@@ -587,6 +587,15 @@ def test_ssim(ops):
     assert abs(ops.ssim(gt.cuda(), gt.cuda()) - 1.0) < 1e-7
 
 
+def test_ssim_vs_published_definition(ops):
+    """kpn_ssim against the published SSIM definition evaluated window by window in float64 and against closed forms
+    (tests/golden_io.py::ssim_pin_cases): pins window, unbiased covariance, constants, interior crop and channel mean."""
+    from tests.golden_io import ssim_pin_cases
+    for name, pred, gt, expect in ssim_pin_cases():
+        got = ops.ssim(torch.from_numpy(np.ascontiguousarray(pred)).cuda(), torch.from_numpy(np.ascontiguousarray(gt)).cuda())
+        assert abs(got - expect) < 3e-6, (name, got, expect)
+
+
 def test_fine_pass_reuses_coarse_values_bit_exactly(ops, monkeypatch):
     """The eval render evaluates the field only at the NEW samples of the fine pass and takes the coarse samples' values
     from the coarse pass: every output is bit-identical to evaluating all Sc+Sf merged samples again (what the reference

@@ -496,3 +496,33 @@ def test_sigma_and_coarse_only(env):
     for k in ("tex_fg", "alpha"):
         assert np.abs(o[k] - g["out." + k][0]).max() < 1e-4, k
     np.testing.assert_allclose(o["depth"], g["out.depth"][0], rtol=2e-4, atol=2e-4)
+
+
+def test_l1_loss_kernel(env):
+    """k_pix_l1 (kpn_pix_l1_loss) on the emulator against the reference's compute_error golden (case R)."""
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    lib = env[0]
+    g = np.load(os.path.join(GOLDEN_DIR, "case_r_loss.npz"))
+    for src, lam, ref_loss, ref_grad in ((g["tex_fg"], float(g["lambda_l1_c"]), float(g["e_pix_c"]), g["d_tex_fg"]),
+                                         (g["tex_fg_fine"], float(g["lambda_l1"]), float(g["e_pix_l1"]), g["d_tex_fg_fine"])):
+        a, b = sh.f32(src).reshape(-1), sh.f32(g["tar_img"]).reshape(-1)
+        loss, d = np.zeros(1, np.float32), np.full(a.size, np.nan, np.float32)
+        scratch = np.zeros(2048 * 8 + 8, np.uint8)
+        lib.check(lib.kpn_pix_l1_loss(sh.ptr(a), sh.ptr(b), a.size, lam, sh.ptr(loss), sh.ptr(d), sh.ptr(scratch), None))
+        assert abs(float(loss[0]) - ref_loss) <= 2e-6 * abs(ref_loss)
+        assert np.array_equal(d.reshape(ref_grad.shape), ref_grad)
+        lib.check(lib.kpn_pix_l1_loss(sh.ptr(a), sh.ptr(b), a.size, lam, sh.ptr(loss), None, sh.ptr(scratch), None))   # value only
+        assert abs(float(loss[0]) - ref_loss) <= 2e-6 * abs(ref_loss)
+
+
+def test_ssim_kernel_vs_published_definition(env):
+    import ctypes
+    from tests.golden_io import ssim_pin_cases
+    lib = env[0]
+    for name, pred, gt, expect in ssim_pin_cases():
+        pred, gt = sh.f32(pred), sh.f32(gt)
+        _, H, W = pred.shape
+        scratch, out = np.zeros(lib.kpn_ssim_scratch_bytes(W, H), np.uint8), np.zeros(1, np.float64)
+        lib.check(lib.kpn_ssim(sh.ptr(pred), sh.ptr(gt), H, W, 0, 0, W, H, sh.ptr(out), sh.ptr(scratch), None))
+        assert abs(out[0] - expect) < 3e-6, (name, out[0], expect)

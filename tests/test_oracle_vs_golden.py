@@ -289,3 +289,28 @@ def test_sigma_and_coarse_only_vs_golden(wflat):
     o = oracle.render_rays(osc, wflat, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=False)
     assert np.abs(o["tex_fg"] - g["out.tex_fg"][0].transpose(1, 2, 0).reshape(-1, 3)).max() < 2e-5
     assert np.abs(o["alpha"] - g["out.alpha"].reshape(-1)).max() < 2e-5
+
+
+def test_l1_loss_vs_reference_compute_error():
+    """pix_loss's L1 terms and their gradients against the reference's compute_error + loss.backward() with the shipped
+    lambdas (golden case R; src/utils.py:97-171, configs/zju.json:109-119)."""
+    import os
+    from tests.golden_io import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "case_r_loss.npz"))
+    assert list(g["err_keys"]) == ["e_all", "e_pix_c", "e_pix_l1"]
+    lc, dc = oracle.pix_l1_loss(g["tex_fg"], g["tar_img"], float(g["lambda_l1_c"]))
+    lf, df = oracle.pix_l1_loss(g["tex_fg_fine"], g["tar_img"], float(g["lambda_l1"]))
+    assert abs(lc - float(g["e_pix_c"])) <= 2e-6 * abs(lc) and abs(lf - float(g["e_pix_l1"])) <= 2e-6 * abs(lf)
+    assert abs(lc + lf - float(g["loss"])) <= 2e-6 * float(g["loss"])
+    assert np.array_equal(dc, g["d_tex_fg"]) and np.array_equal(df, g["d_tex_fg_fine"])     # +-lambda/n or 0: exact
+    assert (df == 0).sum() >= 3 * 8 * 64                                                    # the tied pixels
+
+
+def test_ssim_oracle_vs_published_definition():
+    """The oracle's SSIM (a scipy.ndimage restatement of skimage 0.19's structural_similarity) against the published SSIM
+    definition evaluated window by window in float64, and against closed forms — skimage itself is not installed, so this
+    pins the algorithm (window, unbiased covariance, constants, interior crop, channel mean), not skimage's binary."""
+    from tests.golden_io import ssim_pin_cases
+    for name, pred, gt, expect in ssim_pin_cases():
+        got = oracle.ssim(pred, gt)
+        assert abs(got - expect) < 3e-6, (name, got, expect)
