@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
 // ---------------------------------------------------------------------------------------------
 // k_geo_rows with split-bf16 operands on v_mfma_f32_32x32x16_bf16 (kpn_mfma16_layer): same rows, same row scratch,
 // fp32-class arithmetic (every product term above 2^-24 relative is kept), about twice the matrix rate.
-__global__ __launch_bounds__(256, 2) void k_geo_rows_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+#ifndef KPN_GEOH_OCC
+#define KPN_GEOH_OCC 2
+#endif
+__global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
     const int lane = threadIdx.x & 63;

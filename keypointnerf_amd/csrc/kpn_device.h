@@ -352,7 +352,9 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
     kpn_bf16x8 wa[3][H0], wb[3][H1 > 0 ? H1 : 1];
     auto load_half = [&](int s, int ob0, int n, auto& w) {
         const float* gp = hseg + (size_t)s * (3 * NOB * 64 * 4);
+#ifndef KPN_MFMA16_PLAIN
         KPN_PIN_POINTER(gp);
+#endif
         const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
@@ -374,10 +376,16 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
     // them can be recycled (the compiler otherwise lets a VALU instruction overwrite a 4-VGPR MFMA source in the very
     // next issue slot; cheap insurance: 16 of ~770 cycles per step).
     auto arrive_half = [&](auto nn, auto& w, kpn_bf16x8 (&x)[3]) {
+#ifdef KPN_MFMA16_PLAIN
+        (void)w; (void)x; return;
+#endif
         if constexpr (decltype(nn)::value == 2) kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
         else kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0], x[0], x[1], x[2]);
     };
     auto guard_half = [&](int ob0, auto nn, const auto& w, const kpn_bf16x8 (&x)[3]) {
+#ifdef KPN_MFMA16_PLAIN
+        (void)ob0; (void)w; (void)x; return;
+#endif
         if constexpr (decltype(nn)::value == 2)
             kpn_mfma16_guard(acc[ob0], acc[ob0 + 1], w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
         else
@@ -400,7 +408,9 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
         }
         // VALU phase (above) and MFMA phase (below) are kept apart: see the note at kpn_mfma16_arrive.  The other wave
         // of the SIMD fills the matrix pipe meanwhile.
+#if !defined(KPN_MFMA16_PLAIN) || defined(KPN_MFMA16_PLAIN_BARRIERS)
         if constexpr (SEPARATE) KPN_SCHED_BARRIER();
+#endif
         arrive_half(kpn_ic<H0>{}, wa, xp[cur]);
         mfma_half(0, H0, wa, xp[cur]);
         guard_half(0, kpn_ic<H0>{}, wa, xp[cur]);
@@ -411,9 +421,13 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
             guard_half(H0, kpn_ic<H1>{}, wb, xp[cur]);
             if constexpr (s + 1 < KS16) load_half(s + 1, H0, H1, wb);
         }
+#if !defined(KPN_MFMA16_PLAIN) || defined(KPN_MFMA16_PLAIN_BARRIERS)
         if constexpr (SEPARATE) KPN_SCHED_BARRIER();
+#endif
     });
+#ifndef KPN_MFMA16_PLAIN
     kpn_mfma16_tail<NOB>(acc);
+#endif
 }
 
 // A single-output Linear over a lane's 16 chained features: both halves of a point add their partial
