@@ -133,10 +133,15 @@ def time_training(ops, torch, dev, sd, steps=10):
     n_c, n_f = torch.randn(R * Sc, device=dev, generator=g), torch.randn(R * (Sc + Sf), device=dev, generator=g)
     grads = {"tex_fg": torch.randn(1, 3, R, device=dev, generator=g) / R, "tex_fg_fine": torch.randn(1, 3, R, device=dev, generator=g) / R}
     kw = dict(noise_coarse=n_c, noise_fine=n_f, rand_noise_std=0.01, n_coarse=Sc, n_fine=Sf)
-    fwd = lambda: ops.render_rays_train(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, **kw)
-    bwd = lambda: ops.render_rays_train_backward(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, grads, **kw)
+    kept = {}
+
+    def fwd():
+        kept["state"] = ops.render_rays_train(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, keep_state=True, **kw)[1]
+    bwd = lambda: ops.render_rays_train_backward(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, grads,
+                                                 state=kept["state"], **kw)
+    bwd_classic = lambda: ops.render_rays_train_backward(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, grads, **kw)
     out = {}
-    for name, fn in (("forward_ms", fwd), ("backward_ms", bwd)):
+    for name, fn in (("forward_ms", fwd), ("backward_ms", bwd), ("backward_repeating_the_forward_ms", bwd_classic)):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -145,7 +150,8 @@ def time_training(ops, torch, dev, sd, steps=10):
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / steps * 1e3
     out["iterations_per_sec"] = 1e3 / (out["forward_ms"] + out["backward_ms"])
-    out["workload"] = "configs[3] field part: 1024 rays x (64 coarse + 128 fine-pass) evaluations, V=3, view dropout + density noise, fwd + bwd in HIP"
+    out["workload"] = ("configs[3] field part: 1024 rays x (64 coarse + 128 fine-pass) evaluations, V=3, view dropout + density noise, "
+                       "fwd (kpn_render_rays_train_keep) + bwd (kpn_render_rays_train_backward_kept) in HIP")
     return out
 
 

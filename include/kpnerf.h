@@ -287,6 +287,23 @@ int kpn_render_rays_train_backward(const kpn_scene_desc* desc, const void* scene
                                    float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* workspace,
                                    size_t workspace_bytes, void* stream);
 
+/* The same pair with the forward's work KEPT for the backward: kpn_render_rays_train_keep is kpn_render_rays_train (same
+ * outputs, bit for bit) that also fills `state` (kpn_render_rays_train_state_bytes: rays, depths, field values and the
+ * valid lists + (point, view) rows of both field passes, per chunk of rays — about 1 KB per field evaluation);
+ * kpn_render_rays_train_backward_kept is kpn_render_rays_train_backward (same gradients up to summation order: the
+ * order of the valid list varies from call to call) that reads them from `state` instead of repeating the forward — the field part of a
+ * training iteration then runs the forward once (reference: autograd keeps every activation; here only the pass state is
+ * kept, the MLP activations are still recomputed tile by tile inside the backward kernels).  `workspace` is the one of
+ * kpn_render_rays_train_backward_workspace_bytes.  The state is valid until the weights, the scene or the draws change. */
+size_t kpn_render_rays_train_state_bytes(const kpn_scene_desc* desc, const kpn_render_args* args);
+int kpn_render_rays_train_keep(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
+                               const kpn_render_args* args, const kpn_train_args* train, void* state, size_t state_bytes,
+                               void* stream);
+int kpn_render_rays_train_backward_kept(const kpn_scene_desc* desc, const void* scene_ws, const float* packed_weights,
+                                        const kpn_render_args* args, const kpn_train_args* train, const kpn_render_grads* grads,
+                                        float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* state,
+                                        size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
 /* FLOP / byte model of one field evaluation, for roofline reporting */
 double kpn_flops_per_point(int32_t n_views);
 /* algorithmic FLOPs of one k_geo_rows row = 2 * 70,080 MACs (MLPUNet layers1) */

@@ -1114,7 +1114,7 @@ TrainBwdLayout train_bwd_layout(const kpn_scene_desc* d, const kpn_render_args* 
     L.dirs = take((size_t)R * 3 * 4); L.nearv = take((size_t)R * 4); L.farv = take((size_t)R * 4);
     L.zc = take((size_t)C * a->n_coarse * 4); L.zf = take((size_t)C * Sfull * 4);
     L.rgba_c = take((size_t)C * a->n_coarse * 5 * 4); L.rgba_f = take((size_t)C * Sfull * 5 * 4);
-    L.contrib = take((size_t)C * Sfull * 4);
+    L.contrib = take((size_t)C * (Sfull > 8 ? Sfull : 8) * 4);
     L.scratch = take((size_t)C * 8 * 4);  // colour / depth / alpha / sdf of the recomputed forward (unused results)
     L.g3 = take((size_t)C * 3 * 4); L.g1a = take((size_t)C * 4); L.g1b = take((size_t)C * 4); L.g1c = take((size_t)C * 4);
     L.drgba_c = take((size_t)C * a->n_coarse * 5 * 4); L.drgba_f = take((size_t)C * Sfull * 5 * 4);
@@ -1134,6 +1134,142 @@ __global__ void k_load_planar(int64_t r0, int64_t n, int64_t R, int C, const flo
     dst[i] = src ? src[(int64_t)c * R + r0 + r] : 0.0f;
 }
 
+// State a train-branch forward call can leave behind for its backward call (kpn_render_rays_train_keep): rays, and per
+// chunk of rays the depths, the field values and — the expensive part — the valid lists and (point, view) rows of both
+// field passes.  With it the backward call skips the forward it otherwise repeats (k_make_rays, k_coarse_z, 2 x
+// k_mask_compact + k_geo_rows + k_fuse_color, compositor, sampler: 1.05 of 9.1 ms at 1024 rays x 192 samples).
+namespace {
+struct TrainStateLayout { size_t cam_pos, dirs, nearv, farv, chunk0, zc, zf, rgba_c, rgba_f, contrib, query_c, query_f, chunk_bytes, total;
+                          int64_t chunk, nchunks; };
+TrainStateLayout train_state_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
+    TrainStateLayout S;
+    const TrainBwdLayout L = train_bwd_layout(d, a);
+    const int64_t R = (int64_t)a->nx * a->ny, C = L.chunk;
+    const int64_t Sfull = a->n_coarse + a->n_fine;
+    S.chunk = C; S.nchunks = (R + C - 1) / C;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
+    S.cam_pos = take(64);
+    S.dirs = take((size_t)R * 3 * 4); S.nearv = take((size_t)R * 4); S.farv = take((size_t)R * 4);
+    S.chunk0 = o;
+    o = 0;   // offsets inside one chunk block
+    S.zc = take((size_t)C * a->n_coarse * 4); S.zf = take((size_t)C * Sfull * 4);
+    S.rgba_c = take((size_t)C * a->n_coarse * 5 * 4); S.rgba_f = take((size_t)C * Sfull * 5 * 4);
+    S.contrib = take((size_t)C * (Sfull > 8 ? Sfull : 8) * 4);   // also stages the fine composite of a forward call (6 floats per ray)
+    S.query_c = take(query_layout(C * a->n_coarse, d->n_views).total);
+    S.query_f = take(query_layout(C * Sfull, d->n_views).total);
+    S.chunk_bytes = o;
+    S.total = S.chunk0 + S.chunk_bytes * (size_t)S.nchunks;
+    return S;
+}
+
+// one implementation, three uses: state == nullptr: the classic backward (forward repeated inside `ws`);
+// forward_only: fills `state` and writes the outputs of `a` (kpn_render_rays_train_keep); otherwise: backward from `state`
+int train_impl(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a, const kpn_train_args* t,
+               const kpn_render_grads* g, float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* state, size_t state_bytes,
+               bool forward_only, void* ws, size_t ws_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    if (int e = check_render(a)) return e;
+    KPN_REQUIRE(t != nullptr, "train args null");
+    KPN_REQUIRE(a->fine, "the train branch renders coarse + fine (dr_kwargs.fine)");
+    KPN_REQUIRE(scene_ws && wp, "null pointer");
+    KPN_REQUIRE(t->pix && t->u_coarse && t->u_fine, "train args: pix, u_coarse, u_fine are required");
+    KPN_REQUIRE(t->rand_noise_std == 0.0f || (t->noise_coarse && t->noise_fine), "train args: noise tensors missing");
+    KPN_REQUIRE((t->keep_coarse & ((1u << d->n_views) - 1u)) && (t->keep_fine & ((1u << d->n_views) - 1u)),
+                "train args: view dropout must keep at least one view (reference src/model.py:744)");
+    const bool backward = !forward_only;
+    if (backward) KPN_REQUIRE(g && d_plain && d_geo0 && d_geo1 && d_tex && ws, "gradient pointers / workspace null");
+    if (forward_only) KPN_REQUIRE(state != nullptr, "state null");
+    const TrainBwdLayout L = train_bwd_layout(d, a);
+    const TrainStateLayout S = train_state_layout(d, a);
+    if (backward && ws_bytes < L.total) return fail(KPN_EWORKSPACE, "train backward workspace too small");
+    if (state && state_bytes < S.total) return fail(KPN_EWORKSPACE, "train state too small");
+    char* base = static_cast<char*>(ws);
+    char* sbase = static_cast<char*>(state);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    kpn_scene_dev sc = scene_dev(d, scene_ws);
+    const int64_t R = (int64_t)a->nx * a->ny;
+    const int Sc = a->n_coarse, Sf = a->n_fine, Sfull = Sc + Sf;
+    const bool run_forward = forward_only || state == nullptr;
+    // ray set-up lives in the state when there is one
+    float* cam_pos = state ? reinterpret_cast<float*>(sbase + S.cam_pos) : F(L.cam_pos);
+    float* dirs_all = state ? reinterpret_cast<float*>(sbase + S.dirs) : F(L.dirs);
+    float* nearv = state ? reinterpret_cast<float*>(sbase + S.nearv) : F(L.nearv);
+    float* farv = state ? reinterpret_cast<float*>(sbase + S.farv) : F(L.farv);
+    if (run_forward)
+        KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
+                   (int)a->step, (int)a->nx, (int)a->ny, (const int*)t->pix, dirs_all, cam_pos, nearv, farv);
+    const float std_ = t->rand_noise_std;
+    int64_t ci = 0;
+    for (int64_t r0 = 0; r0 < R; r0 += L.chunk, ++ci) {
+        const int64_t n = (R - r0) < L.chunk ? (R - r0) : L.chunk;
+        const float* dirs = dirs_all + r0 * 3;
+        char* cb = state ? sbase + S.chunk0 + S.chunk_bytes * (size_t)ci : nullptr;
+        auto CS = [&](size_t s_off, size_t l_off) { return state ? reinterpret_cast<float*>(cb + s_off) : F(l_off); };
+        float *zc = CS(S.zc, L.zc), *zf = CS(S.zf, L.zf), *rgba_c = CS(S.rgba_c, L.rgba_c), *rgba_f = CS(S.rgba_f, L.rgba_f);
+        float* contrib = CS(S.contrib, L.contrib);
+        char* query_c = state ? cb + S.query_c : base + L.query;
+        char* query_f = state ? cb + S.query_f : base + L.query;
+        kpn_points pc{nullptr, nullptr, cam_pos, dirs, zc, Sc, std_ != 0.0f ? t->noise_coarse + r0 * Sc : nullptr, std_};
+        kpn_points pf{nullptr, nullptr, cam_pos, dirs, zf, Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
+        float* sc4 = forward_only ? nullptr : F(L.scratch);   // per-ray results of a repeated forward (unused)
+        if (run_forward) {
+            // ---- forward: z, rgba of the coarse pass ----
+            KPN_LAUNCH(k_coarse_z, grid1d(n * Sc, 256), dim3(256), stream, n, Sc, (const float*)(nearv + r0), (const float*)(farv + r0),
+                       t->u_coarse + r0 * Sc, zc);
+            sc.keep = t->keep_coarse;
+            if (int e = run_field(sc, pc, wp, n * Sc, 1, rgba_c, nullptr, query_c, stream, 1, 1)) return e;
+        }
+        if (forward_only) {
+            // per-ray composites are staged in the (still unused) head of this chunk's fine rgba buffer: 8 floats per ray
+            float* st = rgba_f;
+            if (int e = kpn_rgba2out(rgba_c, zc, n, Sc, st, st + 3 * n, st + 4 * n, contrib, st + 5 * n, stream)) return e;
+            if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)st, a->tex_fg);
+            if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)(st + 3 * n), a->depth);
+            if (a->alpha) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)(st + 4 * n), a->alpha);
+        } else if (run_forward) {
+            if (int e = kpn_rgba2out(rgba_c, zc, n, Sc, sc4, sc4 + 3 * n, sc4 + 4 * n, contrib, sc4 + 5 * n, stream)) return e;
+        }
+        const size_t bwd_bytes = backward ? L.total - L.bwd : 0;
+        if (backward) {
+            // ---- coarse pass reverse (in the classic call: before the fine forward overwrites the query workspace whose
+            //      valid list and row scratch it reuses); sample positions carry no gradient (model.py:1038,1118) ----
+            KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg, F(L.g3));
+            KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth, F(L.g1a));
+            KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha, F(L.g1b));
+            if (int e = kpn_rgba2out_backward(rgba_c, zc, n, Sc, F(L.g3), F(L.g1a), F(L.g1b), nullptr, F(L.drgba_c), stream)) return e;
+            if (int e = run_backward(d, scene_ws, wp, n * Sc, nullptr, nullptr, 1, t->keep_coarse, nullptr, 0.0f, nullptr, F(L.drgba_c),
+                                     d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pc, query_c)) return e;
+        }
+        if (run_forward) {
+            // ---- fine pass: samples, forward ----
+            launch_fine_samples(stream, n, Sc, Sf, zc, contrib, t->u_fine + r0 * Sf, zf, nullptr, nullptr);
+            sc.keep = t->keep_fine;
+            if (int e = run_field(sc, pf, wp, n * Sfull, 1, rgba_f, nullptr, query_f, stream, 1, 1)) return e;
+        }
+        if (forward_only) {
+            float* st = contrib;   // the coarse contributions have been consumed by the sampler: 8 floats per ray of staging
+            if (int e = kpn_rgba2out(rgba_f, zf, n, Sfull, st, st + 3 * n, st + 4 * n, nullptr, st + 5 * n, stream)) return e;
+            if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)st, a->tex_fg_fine);
+            if (a->depth_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)(st + 3 * n), a->depth_fine);
+            if (a->alpha_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)(st + 4 * n), a->alpha_fine);
+            if (a->sdf) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)(st + 5 * n), a->sdf);
+        }
+        if (backward) {
+            // ---- fine pass reverse ----
+            KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg_fine, F(L.g3));
+            KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth_fine, F(L.g1a));
+            KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha_fine, F(L.g1b));
+            KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_sdf, F(L.g1c));
+            if (int e = kpn_rgba2out_backward(rgba_f, zf, n, Sfull, F(L.g3), F(L.g1a), F(L.g1b), F(L.g1c), F(L.drgba_f), stream)) return e;
+            if (int e = run_backward(d, scene_ws, wp, n * Sfull, nullptr, nullptr, 1, t->keep_fine, nullptr, 0.0f, nullptr, F(L.drgba_f),
+                                     d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pf, query_f)) return e;
+        }
+    }
+    return check_launch(forward_only ? "kpn_render_rays_train_keep" : "kpn_render_rays_train_backward");
+}
+}  // namespace
+
 extern "C" size_t kpn_render_rays_train_backward_workspace_bytes(const kpn_scene_desc* d, const kpn_render_args* a) {
     if (check_desc(d) != KPN_OK || check_render(a) != KPN_OK || !a->fine) return 0;
     return train_bwd_layout(d, a).total;
@@ -1143,59 +1279,23 @@ extern "C" int kpn_render_rays_train_backward(const kpn_scene_desc* d, const voi
                                               const kpn_render_args* a, const kpn_train_args* t, const kpn_render_grads* g,
                                               float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* ws,
                                               size_t ws_bytes, void* stream) {
-    if (int e = check_desc(d)) return e;
-    if (int e = check_render(a)) return e;
-    KPN_REQUIRE(t && g, "train args / gradients null");
-    KPN_REQUIRE(a->fine, "the train branch renders coarse + fine (dr_kwargs.fine)");
-    KPN_REQUIRE(scene_ws && wp && ws && d_plain && d_geo0 && d_geo1 && d_tex, "null pointer");
-    KPN_REQUIRE(t->pix && t->u_coarse && t->u_fine, "train args: pix, u_coarse, u_fine are required");
-    KPN_REQUIRE(t->rand_noise_std == 0.0f || (t->noise_coarse && t->noise_fine), "train args: noise tensors missing");
-    KPN_REQUIRE((t->keep_coarse & ((1u << d->n_views) - 1u)) && (t->keep_fine & ((1u << d->n_views) - 1u)),
-                "train args: view dropout must keep at least one view (reference src/model.py:744)");
-    const TrainBwdLayout L = train_bwd_layout(d, a);
-    if (ws_bytes < L.total) return fail(KPN_EWORKSPACE, "train backward workspace too small");
-    char* base = static_cast<char*>(ws);
-    auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
-    kpn_scene_dev sc = scene_dev(d, scene_ws);
-    const int64_t R = (int64_t)a->nx * a->ny;
-    const int Sc = a->n_coarse, Sf = a->n_fine, Sfull = Sc + Sf;
-    KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
-               (int)a->step, (int)a->nx, (int)a->ny, (const int*)t->pix, F(L.dirs), F(L.cam_pos), F(L.nearv), F(L.farv));
-    const float std_ = t->rand_noise_std;
-    for (int64_t r0 = 0; r0 < R; r0 += L.chunk) {
-        const int64_t n = (R - r0) < L.chunk ? (R - r0) : L.chunk;
-        const float* dirs = F(L.dirs) + r0 * 3;
-        float* sc4 = F(L.scratch);
-        // ---- forward again (nothing is kept from kpn_render_rays_train): z, rgba of both passes ----
-        KPN_LAUNCH(k_coarse_z, grid1d(n * Sc, 256), dim3(256), stream, n, Sc, (const float*)(F(L.nearv) + r0),
-                   (const float*)(F(L.farv) + r0), t->u_coarse + r0 * Sc, F(L.zc));
-        kpn_points pc{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zc), Sc, std_ != 0.0f ? t->noise_coarse + r0 * Sc : nullptr, std_};
-        sc.keep = t->keep_coarse;
-        if (int e = run_field(sc, pc, wp, n * Sc, 1, F(L.rgba_c), nullptr, base + L.query, stream, 1, 1)) return e;
-        if (int e = kpn_rgba2out(F(L.rgba_c), F(L.zc), n, Sc, sc4, sc4 + 3 * n, sc4 + 4 * n, F(L.contrib), sc4 + 5 * n, stream)) return e;
-        // ---- coarse pass reverse (before the fine forward overwrites the query workspace whose valid list and row
-        //      scratch it reuses); sample positions carry no gradient (model.py:1038,1118) ----
-        const size_t bwd_bytes = L.total - L.bwd;
-        KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg, F(L.g3));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth, F(L.g1a));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha, F(L.g1b));
-        if (int e = kpn_rgba2out_backward(F(L.rgba_c), F(L.zc), n, Sc, F(L.g3), F(L.g1a), F(L.g1b), nullptr, F(L.drgba_c), stream)) return e;
-        if (int e = run_backward(d, scene_ws, wp, n * Sc, nullptr, nullptr, 1, t->keep_coarse, nullptr, 0.0f, nullptr, F(L.drgba_c),
-                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pc, base + L.query)) return e;
-        // ---- fine pass: samples, forward, reverse ----
-        launch_fine_samples(stream, n, Sc, Sf, F(L.zc), F(L.contrib), t->u_fine + r0 * Sf, F(L.zf), nullptr, nullptr);
-        kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull, std_ != 0.0f ? t->noise_fine + r0 * Sfull : nullptr, std_};
-        sc.keep = t->keep_fine;
-        if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba_f), nullptr, base + L.query, stream, 1, 1)) return e;
-        KPN_LAUNCH(k_load_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, g->d_tex_fg_fine, F(L.g3));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_depth_fine, F(L.g1a));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_alpha_fine, F(L.g1b));
-        KPN_LAUNCH(k_load_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, g->d_sdf, F(L.g1c));
-        if (int e = kpn_rgba2out_backward(F(L.rgba_f), F(L.zf), n, Sfull, F(L.g3), F(L.g1a), F(L.g1b), F(L.g1c), F(L.drgba_f), stream)) return e;
-        if (int e = run_backward(d, scene_ws, wp, n * Sfull, nullptr, nullptr, 1, t->keep_fine, nullptr, 0.0f, nullptr, F(L.drgba_f),
-                                 d_plain, d_geo0, d_geo1, d_tex, base + L.bwd, bwd_bytes, stream, &pf, base + L.query)) return e;
-    }
-    return check_launch("kpn_render_rays_train_backward");
+    return train_impl(d, scene_ws, wp, a, t, g, d_plain, d_geo0, d_geo1, d_tex, nullptr, 0, false, ws, ws_bytes, stream);
+}
+
+extern "C" size_t kpn_render_rays_train_state_bytes(const kpn_scene_desc* d, const kpn_render_args* a) {
+    if (check_desc(d) != KPN_OK || check_render(a) != KPN_OK || !a->fine) return 0;
+    return train_state_layout(d, a).total;
+}
+extern "C" int kpn_render_rays_train_keep(const kpn_scene_desc* d, const void* scene_ws, const float* wp, const kpn_render_args* a,
+                                          const kpn_train_args* t, void* state, size_t state_bytes, void* stream) {
+    return train_impl(d, scene_ws, wp, a, t, nullptr, nullptr, nullptr, nullptr, nullptr, state, state_bytes, true, nullptr, 0, stream);
+}
+extern "C" int kpn_render_rays_train_backward_kept(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
+                                                   const kpn_render_args* a, const kpn_train_args* t, const kpn_render_grads* g,
+                                                   float* d_plain, float* d_geo0, float* d_geo1, float* d_tex, void* state,
+                                                   size_t state_bytes, void* ws, size_t ws_bytes, void* stream) {
+    KPN_REQUIRE(state != nullptr, "state null");
+    return train_impl(d, scene_ws, wp, a, t, g, d_plain, d_geo0, d_geo1, d_tex, state, state_bytes, false, ws, ws_bytes, stream);
 }
 
 extern "C" int kpn_frame_to_rgb8(const float* chw, int32_t H, int32_t W, int32_t bgr, uint8_t* hwc_out, void* stream) {

@@ -221,7 +221,9 @@ def install(net):
             None if getattr(net, "disable_fg_mask", False) else fg,
             [float(cam_in["znear"]), float(cam_in["zfar"]), float(cam_in.get("nml_scale", 100.0)), encoder_sigma(net)],
             tar["K"], tar["RT"], config["bounds"], float(tar["znear"]), float(tar["zfar"]), grids.to(torch.int32), u_c, u_f,
-            noise_c, noise_f, int(keep_c), int(keep_f), std, int(Sc), int(Sf))
+            noise_c, noise_f, int(keep_c), int(keep_f), std, int(Sc), int(Sf),
+            # training: keep the forward's pass state so that loss.backward() does not repeat the forward
+            bool(torch.is_grad_enabled() and (plain.requires_grad or feat_geo[0].requires_grad or feat_tex.requires_grad)))
         out = {}
         for k, v in zip(_OUT_KEYS, res):                            # (1,3,R) / (1,R) in pixel-list order
             out[k] = v.view(1, 3, out_h, out_w) if k.startswith("tex") else v.view(1, out_h, out_w)

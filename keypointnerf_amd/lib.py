@@ -96,6 +96,12 @@ _SIGNATURES = {
     "kpn_flops_per_point": (ctypes.c_double, [c_i32]),
     "kpn_flops_per_row": (ctypes.c_double, []),
     "kpn_profile_enable": (ctypes.c_int, [c_i32]),
+    "kpn_render_rays_train_state_bytes": (c_sz, [ctypes.POINTER(SceneDesc), ctypes.POINTER(RenderArgs)]),
+    "kpn_render_rays_train_keep": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs),
+                                                  ctypes.POINTER(TrainArgs), c_p, c_sz, c_p]),
+    "kpn_render_rays_train_backward_kept": (ctypes.c_int, [ctypes.POINTER(SceneDesc), c_p, c_p, ctypes.POINTER(RenderArgs),
+                                                           ctypes.POINTER(TrainArgs), ctypes.POINTER(RenderGrads), c_p, c_p, c_p, c_p,
+                                                           c_p, c_sz, c_p, c_sz, c_p]),
     "kpn_pix_l1_loss": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, ctypes.c_float, c_p, c_p, c_p, c_p]),
     "kpn_profile_collect": (ctypes.c_int, [c_p, c_p, c_p]),
     "kpn_profile_collect2": (ctypes.c_int, [c_p, c_p, c_p, c_p]),

@@ -365,7 +365,7 @@ def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=
 
 
 def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, keep_coarse, keep_fine, noise_coarse=None,
-                      noise_fine=None, rand_noise_std=0.0, n_coarse=64, n_fine=64, chunk_rays=0):
+                      noise_fine=None, rand_noise_std=0.0, n_coarse=64, n_fine=64, chunk_rays=0, keep_state=False):
     """TRAIN branch of batch_render_pifu_nerf, forward only, with the random draws passed in (reference
     src/model.py:1008-1017,1049-1053,993-994,742-748,1129): pix (R,2) int32 patch pixels (x,y); u_coarse (R,Sc);
     u_fine (R,Sf); keep_* = (V,) 0/1 view-dropout vectors (or bit masks) of the coarse / fine query; noise_* flat
@@ -389,19 +389,31 @@ def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, ke
     t.noise_coarse = nc.data_ptr() if nc is not None else None
     t.noise_fine = nf.data_ptr() if nf is not None else None
     t.keep_coarse, t.keep_fine, t.rand_noise_std = bits(keep_coarse), bits(keep_fine), float(rand_noise_std)
-    L.check(L.kpn_render_rays_train(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
-                                    _p(plan.ws), plan.nbytes, _stream()))
+    state = None
+    if keep_state:
+        nb = L.kpn_render_rays_train_state_bytes(ctypes.byref(scene.desc), ctypes.byref(a))
+        if nb == 0:
+            raise kl.KpnError("bad render arguments: " + L.kpn_last_error().decode())
+        state = torch.empty(nb, dtype=torch.uint8, device=px.device)
+        L.check(L.kpn_render_rays_train_keep(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a),
+                                             ctypes.byref(t), _p(state), nb, _stream()))
+    else:
+        L.check(L.kpn_render_rays_train(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
+                                        _p(plan.ws), plan.nbytes, _stream()))
     # no host sync: every launch above is on torch's current stream, and the caching allocator hands a freed block to
     # later work of the SAME stream only, so the argument tensors may be released as soon as this returns
-    return {k: v.reshape(1, *v.shape[1:-2], R) if v.dim() == 4 else v.reshape(1, R) for k, v in plan.out.items()}
+    out = {k: v.reshape(1, *v.shape[1:-2], R) if v.dim() == 4 else v.reshape(1, R) for k, v in plan.out.items()}
+    return (out, state) if keep_state else out
 
 
 def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, keep_coarse, keep_fine, grads,
-                               noise_coarse=None, noise_fine=None, rand_noise_std=0.0, n_coarse=64, n_fine=64, chunk_rays=0):
+                               noise_coarse=None, noise_fine=None, rand_noise_std=0.0, n_coarse=64, n_fine=64, chunk_rays=0,
+                               state=None):
     """loss.backward() through render_rays_train (kpn_render_rays_train_backward): `grads` maps output names
     ('tex_fg', 'depth', 'alpha', 'tex_fg_fine', 'depth_fine', 'alpha_fine', 'sdf') to the gradients of those outputs,
     shaped like them ((1,3,R) / (1,R)); missing keys are zero.  Same other arguments as the forward call.
-    Returns (d_plain, d_geo0, d_geo1, d_tex) as ops.query_backward."""
+    `state`: the tensor render_rays_train(..., keep_state=True) returned for the SAME arguments (kpn_render_rays_train_
+    backward_kept: the forward is not repeated).  Returns (d_plain, d_geo0, d_geo1, d_tex) as ops.query_backward."""
     L = kl.get_library()
     px = pix.to(torch.int32).contiguous()
     if not px.is_cuda:
@@ -440,8 +452,13 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
     if nb == 0:
         raise kl.KpnError("bad render arguments: " + L.kpn_last_error().decode())
     ws = torch.empty(nb, dtype=torch.uint8, device=dv)
-    L.check(L.kpn_render_rays_train_backward(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
-                                             ctypes.byref(g), _p(d_plain), _p(d_g0), _p(d_g1), _p(d_tx), _p(ws), nb, _stream()))
+    if state is not None and state.numel() > 0:
+        L.check(L.kpn_render_rays_train_backward_kept(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
+                                                      ctypes.byref(g), _p(d_plain), _p(d_g0), _p(d_g1), _p(d_tx), _p(state),
+                                                      state.numel(), _p(ws), nb, _stream()))
+    else:
+        L.check(L.kpn_render_rays_train_backward(ctypes.byref(d), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), ctypes.byref(t),
+                                                 ctypes.byref(g), _p(d_plain), _p(d_g0), _p(d_g1), _p(d_tx), _p(ws), nb, _stream()))
     # no host sync (stream-ordered reuse of freed blocks, see render_rays_train)
     return d_plain, d_g0.permute(0, 3, 1, 2), d_g1.permute(0, 3, 1, 2), d_tx.permute(0, 3, 1, 2)
 

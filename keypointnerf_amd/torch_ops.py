@@ -130,6 +130,7 @@ def _(scene_ws, scene_dims, scene_scalars, weights, pts, view, mode):
 
 
 _OUT7 = Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]
+_OUT8 = Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]
 _OUT_KEYS = ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")
 
 
@@ -168,25 +169,28 @@ def render_rays_train(plain: torch.Tensor, geo0: torch.Tensor, geo1: torch.Tenso
                       scene_scalars: List[float], K: torch.Tensor, RT: torch.Tensor, bounds: torch.Tensor, znear: float,
                       zfar: float, pix: torch.Tensor, u_c: torch.Tensor, u_f: torch.Tensor, noise_c: Optional[torch.Tensor],
                       noise_f: Optional[torch.Tensor], keep_c: int, keep_f: int, noise_std: float, n_coarse: int,
-                      n_fine: int) -> _OUT7:
+                      n_fine: int, keep_state: bool = False) -> _OUT8:
     """The stochastic (`uniform=False`) branch of batch_render_pifu_nerf with every draw an input (kpn_render_rays_train).
     plain: flat effective parameters (weights.flatten_plain layout); geo0/geo1/tex: the encoders' NCHW maps; fg_mask None =
     disable_fg_mask; scene_scalars = [znear, zfar, nml_scale, sigma] of the SOURCE cameras / spatial encoder.
-    Outputs: (1,3,R) / (1,R) tensors in the order of `pix`."""
+    Outputs: (1,3,R) / (1,R) tensors in the order of `pix`, then the pass state (uint8; empty unless keep_state): with it
+    the backward op starts from the forward's rays, depths, field values, valid lists and rows instead of repeating the
+    forward (kpn_render_rays_train_keep / kpn_render_rays_train_backward_kept)."""
     scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
     w = ops.PackedWeights.from_plain(plain, device=geo0.device)
-    out = ops.render_rays_train(scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f,
+    res = ops.render_rays_train(scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f,
                                 noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse,
-                                n_fine=n_fine)
-    return tuple(out[k].clone() for k in _OUT_KEYS)
+                                n_fine=n_fine, keep_state=keep_state)
+    out, state = res if keep_state else (res, torch.empty(0, dtype=torch.uint8, device=geo0.device))
+    return tuple(out[k].clone() for k in _OUT_KEYS) + (state,)
 
 
 @render_rays_train.register_fake
 def _(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scene_scalars, K, RT, bounds, znear, zfar, pix, u_c, u_f, noise_c,
-      noise_f, keep_c, keep_f, noise_std, n_coarse, n_fine):
+      noise_f, keep_c, keep_f, noise_std, n_coarse, n_fine, keep_state=False):
     R = pix.shape[0]
     f = lambda *s: geo0.new_empty(s)
-    return f(1, 3, R), f(1, R), f(1, R), f(1, 3, R), f(1, R), f(1, R), f(1, R)
+    return f(1, 3, R), f(1, R), f(1, R), f(1, 3, R), f(1, R), f(1, R), f(1, R), geo0.new_empty(0, dtype=torch.uint8)
 
 
 @_lib.custom_op("kpnerf::render_rays_train_backward", mutates_args=(), device_types="cuda")
@@ -198,7 +202,8 @@ def render_rays_train_backward(plain: torch.Tensor, geo0: torch.Tensor, geo1: to
                                noise_std: float, n_coarse: int, n_fine: int, d_tex_fg: Optional[torch.Tensor],
                                d_depth: Optional[torch.Tensor], d_alpha: Optional[torch.Tensor],
                                d_tex_fg_fine: Optional[torch.Tensor], d_depth_fine: Optional[torch.Tensor],
-                               d_alpha_fine: Optional[torch.Tensor], d_sdf: Optional[torch.Tensor]
+                               d_alpha_fine: Optional[torch.Tensor], d_sdf: Optional[torch.Tensor],
+                               state: Optional[torch.Tensor] = None
                                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """loss.backward() through render_rays_train (kpn_render_rays_train_backward) -> (d_plain, d_geo0, d_geo1, d_tex),
     the map gradients NCHW like the maps."""
@@ -207,7 +212,7 @@ def render_rays_train_backward(plain: torch.Tensor, geo0: torch.Tensor, geo1: to
     grads = dict(zip(_OUT_KEYS, (d_tex_fg, d_depth, d_alpha, d_tex_fg_fine, d_depth_fine, d_alpha_fine, d_sdf)))
     d_plain, d_g0, d_g1, d_tx = ops.render_rays_train_backward(
         scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f, grads,
-        noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse, n_fine=n_fine)
+        noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse, n_fine=n_fine, state=state)
     return d_plain, d_g0.contiguous(), d_g1.contiguous(), d_tx.contiguous()
 
 
@@ -217,14 +222,18 @@ def _(plain, geo0, geo1, tex, *rest):
 
 
 def _train_setup(ctx, inputs, output):
-    ctx.args = inputs                      # tensors and scalars of the forward call (nothing else is kept: the backward
-    ctx.set_materialize_grads(False)       # entry point recomputes z, rgba and the field activations)
+    ctx.args = inputs[:25]                 # tensors and scalars of the forward call
+    ctx.n_inputs = len(inputs)
+    ctx.state = output[7]                  # the pass state (empty unless keep_state): rays, depths, rgba, lists, rows
+    ctx.set_materialize_grads(False)
 
 
 def _train_bwd(ctx, *grads):
+    state = ctx.state if ctx.state.numel() > 0 else None
     d_plain, d_g0, d_g1, d_tx = torch.ops.kpnerf.render_rays_train_backward(
-        *ctx.args, *[None if g is None else g.contiguous() for g in grads])
-    return (d_plain, d_g0, d_g1, d_tx) + (None,) * (len(ctx.args) - 4)
+        *ctx.args, *[None if g is None else g.contiguous() for g in grads[:7]], state)
+    ctx.state = None                       # release the rows as soon as they have been used
+    return (d_plain, d_g0, d_g1, d_tx) + (None,) * (ctx.n_inputs - 4)
 
 
 render_rays_train.register_autograd(_train_bwd, setup_context=_train_setup)

@@ -236,3 +236,45 @@ def render_train_backward(lib, hs, packed, cam_tar, bounds, pix, Sc, Sf, u_c, no
     lib.check(lib.kpn_render_rays_train_backward(ctypes.byref(d), ptr(hs.ws), ptr(packed), ctypes.byref(a), ctypes.byref(t), ctypes.byref(g),
                                                  ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(d_tx), ptr(ws), nb, None))
     return d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2), d_tx.transpose(0, 3, 1, 2)
+
+
+def render_train_keep_and_backward(lib, hs, packed, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std,
+                                   grads, chunk_rays=0):
+    """kpn_render_rays_train_keep + kpn_render_rays_train_backward_kept on host buffers: returns (outputs, gradients)."""
+    K, RT, b = f32(cam_tar["K"]).reshape(4, 4), f32(cam_tar["RT"]).reshape(4, 4), f32(bounds).reshape(2, 3)
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    o = {k: np.full((3, R), np.nan, np.float32) for k in ("tex_fg", "tex_fg_fine")}
+    o.update({k: np.full(R, np.nan, np.float32) for k in ("depth", "alpha", "depth_fine", "alpha_fine", "sdf")})
+    a = kl.RenderArgs()
+    a.K, a.RT, a.bounds = K.ctypes.data, RT.ctypes.data, b.ctypes.data
+    a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
+    a.x0, a.y0, a.step, a.nx, a.ny = 0, 0, 1, R, 1
+    a.n_coarse, a.n_fine, a.fine, a.chunk_rays = Sc, Sf, 1, chunk_rays
+    for k, v in o.items():
+        setattr(a, k, v.ctypes.data)
+    bufs = dict(u_c=f32(u_c).reshape(R, Sc), noise_c=f32(noise_c).reshape(-1), noise_f=f32(noise_f).reshape(-1), u_f=f32(u_f).reshape(R, Sf))
+    t = kl.TrainArgs()
+    t.pix, t.u_coarse, t.noise_coarse, t.noise_fine, t.u_fine = (pix.ctypes.data, bufs["u_c"].ctypes.data, bufs["noise_c"].ctypes.data,
+                                                                 bufs["noise_f"].ctypes.data, bufs["u_f"].ctypes.data)
+    t.keep_coarse, t.keep_fine, t.rand_noise_std = keep_c, keep_f, float(noise_std)
+    d = hs.desc
+    ns = lib.kpn_render_rays_train_state_bytes(ctypes.byref(d), ctypes.byref(a))
+    assert ns > 0, lib.kpn_last_error()
+    state = np.zeros(ns, np.uint8)
+    lib.check(lib.kpn_render_rays_train_keep(ctypes.byref(d), ptr(hs.ws), ptr(packed), ctypes.byref(a), ctypes.byref(t), ptr(state), ns, None))
+    g, keep_alive = kl.RenderGrads(), []
+    for name, arr in grads.items():
+        arr = f32(arr).reshape(-1)
+        keep_alive.append(arr)
+        setattr(g, "d_" + name, arr.ctypes.data)
+    d_plain = np.zeros(lib.kpn_plain_weight_floats(), np.float32)
+    d_g0 = np.zeros((hs.V, d.geo0_h, d.geo0_w, 64), np.float32)
+    d_g1 = np.zeros((hs.V, d.geo1_h, d.geo1_w, 8), np.float32)
+    d_tx = np.zeros((hs.V, d.tex_h, d.tex_w, 8), np.float32)
+    nb = lib.kpn_render_rays_train_backward_workspace_bytes(ctypes.byref(d), ctypes.byref(a))
+    ws = np.zeros(nb, np.uint8)
+    lib.check(lib.kpn_render_rays_train_backward_kept(ctypes.byref(d), ptr(hs.ws), ptr(packed), ctypes.byref(a), ctypes.byref(t),
+                                                      ctypes.byref(g), ptr(d_plain), ptr(d_g0), ptr(d_g1), ptr(d_tx), ptr(state), ns,
+                                                      ptr(ws), nb, None))
+    return o, (d_plain, d_g0.transpose(0, 3, 1, 2), d_g1.transpose(0, 3, 1, 2), d_tx.transpose(0, 3, 1, 2))

@@ -444,6 +444,16 @@ def test_train_render_backward(ops, golden_weights, case):
     got = ops.render_rays_train_backward(ps, w, s["cam_tar"], s["bounds"], cu(g["pix"]), cu(g["u_c"]), cu(g["u_f"]),
                                          keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), grads, **args)
     assert_train_grads_vs_golden([x.cpu().numpy() for x in got], g, sd, 1e-4)
+    # the same pair with the forward's pass state kept for the backward (kpn_render_rays_train_keep / _backward_kept):
+    # bit-identical outputs, the reference's gradients without repeating the forward; one chunk and several
+    for chunk in (0, 24):
+        out2, state = ops.render_rays_train(ps, w, s["cam_tar"], s["bounds"], cu(g["pix"]), cu(g["u_c"]), cu(g["u_f"]),
+                                            keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), keep_state=True, chunk_rays=chunk, **args)
+        for k in out:
+            assert torch.equal(out[k], out2[k]), k
+        got2 = ops.render_rays_train_backward(ps, w, s["cam_tar"], s["bounds"], cu(g["pix"]), cu(g["u_c"]), cu(g["u_f"]),
+                                              keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), grads, state=state, chunk_rays=chunk, **args)
+        assert_train_grads_vs_golden([x.cpu().numpy() for x in got2], g, sd, 1e-4)
 
 
 def test_backward_multi_pass_and_chunking(ops, golden_weights):

@@ -367,6 +367,32 @@ def test_train_render_backward_kernels(env, case):
     assert_train_grads_vs_golden(got, g, load_weights(), 1e-4)
 
 
+@pytest.mark.parametrize("chunk", [0, 24])
+def test_train_forward_kept_for_the_backward(env, chunk):
+    """kpn_render_rays_train_keep + kpn_render_rays_train_backward_kept: the forward's pass state (rays, depths, field
+    values, valid lists, rows) kept for the backward instead of repeating the forward — outputs bit-identical to
+    kpn_render_rays_train, gradients identical to kpn_render_rays_train_backward and equal to the reference's (golden k);
+    chunk = 24: several chunks of rays, each with its own state block."""
+    from tests.golden_io import keep_bits
+    lib, packed, wflat = env
+    case = TRAIN_GRAD_CASES[0]
+    scene, cfg, g = load_case(case)
+    hs = sh.HostScene(lib, scene)
+    args = (scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"], g["u_c"], g["noise_c"], g["noise_f"], g["u_f"],
+            keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), float(g["noise_std"]))
+    out, got = sh.render_train_keep_and_backward(lib, hs, packed, *args, train_grad_inputs(g), chunk_rays=chunk)
+    plain = sh.render_train(lib, hs, packed, *args, chunk_rays=chunk)
+    for k in plain:
+        assert np.array_equal(out[k], plain[k]), k
+    assert_train_grads_vs_golden(got, g, load_weights(), 1e-4)
+    if chunk == 0:
+        ref = sh.render_train_backward(lib, hs, packed, *args, train_grad_inputs(g))
+        # not bit-equal: the valid list's order (atomic compaction) differs from call to call, and with it the tiles the
+        # per-tile partial sums are formed over
+        for a_, b_ in zip(got, ref):
+            assert np.abs(a_ - b_).max() <= 2e-5 * max(1e-30, np.abs(b_).max())
+
+
 @pytest.mark.parametrize("n_views", [1, 2, 4])
 def test_query_backward_other_view_counts(env, n_views):
     """View counts other than 3: V = 1 (softmax over one view: no colour gradient at all), V = 2, and V = 4 (the generic

@@ -22,7 +22,8 @@ def test_ops_are_registered_with_fake_kernels():
             e(100), e(V, 64, 8, 8), e(V, 8, 32, 32), e(V, 8, 16, 16), e(V, 3, 64, 64), e(V, 4, 4), e(V, 4, 4), e(1, 24, 3), None,
             [2.0, 5.0, 100.0, 0.1], e(1, 4, 4), e(1, 4, 4), e(1, 2, 3), 2.0, 8.0, e(R, 2, dtype=torch.int32), e(1, R, 8), e(1, R, 8),
             None, None, 7, 7, 0.0, 8, 8)
-        assert [tuple(o.shape) for o in outs] == [(1, 3, R), (1, R), (1, R), (1, 3, R), (1, R), (1, R), (1, R)]
+        assert [tuple(o.shape) for o in outs[:7]] == [(1, 3, R), (1, R), (1, R), (1, 3, R), (1, R), (1, R), (1, R)]
+        assert outs[7].dtype == torch.uint8                                # the pass state (empty unless keep_state)
         outs = torch.ops.kpnerf.render_rays(e(16), [V, 64, 64, 8, 8, 32, 32, 16, 16, 0], [2.0, 5.0, 100.0, 0.1], e(16), e(1, 4, 4),
                                             e(1, 4, 4), e(1, 2, 3), 2.0, 8.0, [0, 0, 1, 6, 5], 8, 8, True)
         assert tuple(outs[0].shape) == (1, 3, 5, 6) and tuple(outs[6].shape) == (1, 5, 6)
