@@ -143,9 +143,36 @@ __device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
 __device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, int h,
                                                const kpn_proj& q, const float (&P)[3], const float (&D)[3], float4& rec0,
                                                float4& rec1) {
+#ifdef KPN_DBG_REC_NOBRANCH   // bisection: both halves compute both records, then select
+    float4 ra0, ra1, rb0, rb1;
+    {
+        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);
+        ra0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
+        const float* cp = tb + KPN_TBL_CPOS;
+        float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
+        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+        const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
+        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
+        ra1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
+        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+        rb0 = kpn_tap4(tx, 8, 0, tt);
+        rb1 = kpn_tap4(tx, 8, 4, tt);
+    }
+    rec0 = h ? rb0 : ra0;
+    rec1 = h ? rb1 : ra1;
+    return;
+#endif
     if (h == 0) {
         const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+#ifdef KPN_DBG_REC_NOLOAD
+        const float4 c = make_float4(0.3f, 0.4f, 0.5f, 1.0f);
+        (void)ti;
+#else
         const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
+#endif
         rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
         const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
         float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
@@ -157,8 +184,13 @@ __device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const fl
     } else {
         const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
         const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+#ifdef KPN_DBG_REC_NOLOAD
+        rec0 = make_float4(0.1f, 0.2f, -0.1f, 0.3f); rec1 = make_float4(-0.2f, 0.1f, 0.0f, 0.2f);
+        (void)tt; (void)tx;
+#else
         rec0 = kpn_tap4(tx, 8, 0, tt);
         rec1 = kpn_tap4(tx, 8, 4, tt);
+#endif
     }
 }
 
@@ -334,11 +366,15 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
         }
     }
     __syncthreads();
+#ifdef KPN_DBG_STATIC   // bisection of the 2-waves-per-SIMD failure: no ticket atomics
+    for (int wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < nwork; wi += (gridDim.x * blockDim.x) >> 6) {
+#else
     for (;;) {
         int wi = 0;
         if (lane == 0) wi = atomicAdd(tickets + 0, 1);
         wi = __shfl(wi, 0);
         if (wi >= nwork) break;
+#endif
         const int tr = wi / sc.V, v = wi - tr * sc.V;
         int ci = (t0 + tr) * KPN_TILE + p;
         if (ci >= count) ci = count - 1;
@@ -380,12 +416,20 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
                 x[3] = s2 * w; x[4] = c2 * w;
                 x[5] = s4 * w; x[6] = c4 * w;
                 x[7] = 0.0f;
+#ifdef KPN_DBG_NOPE
+                x[0] = 0.01f * (float)j; x[1] = 0.02f; x[2] = -0.03f; x[3] = 0.04f * cz; x[4] = 0.05f; x[5] = -0.06f; x[6] = 0.07f;
+#endif
             }, a0);
             const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
             kpn_mfma16_layer<4, 4>(wp + kpn_hseg_off(HSEG_G1_0B), lane, [&](auto gi, float (&x)[8]) {
                 constexpr int g = decltype(gi)::value;
+#if defined(KPN_DBG_NOGATHER) || defined(KPN_DBG_NOGEO0)
+                const float4 f0 = make_float4(0.1f, -0.2f, 0.3f, 0.05f * (float)g), f1 = make_float4(-0.1f, 0.2f, 0.15f, -0.05f * (float)h);
+                (void)g0; (void)tp;
+#else
                 const float4 f0 = kpn_tap4(g0, 64, 32 * h + 8 * g, tp), f1 = kpn_tap4(g0, 64, 32 * h + 8 * g + 4, tp);
+#endif
                 x[0] = f0.x; x[1] = f0.y; x[2] = f0.z; x[3] = f0.w; x[4] = f1.x; x[5] = f1.y; x[6] = f1.z; x[7] = f1.w;
             }, a0);
         }
@@ -400,7 +444,12 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
         kpn_f32x16 a2[4];
         {
             const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
+#if defined(KPN_DBG_NOGATHER) || defined(KPN_DBG_NOGEO1)
+            const float4 f = make_float4(0.1f, -0.2f, 0.3f, 0.05f);
+            (void)tp;
+#else
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
+#endif
             kpn_load_bias<4>(bias_s[2], h, a2);
             kpn_mfma16_layer<9, 4>(wp + kpn_hseg_off(HSEG_G1_2), lane, [&](auto gi, float (&x)[8]) {
                 constexpr int s = decltype(gi)::value;
@@ -420,7 +469,9 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
                 constexpr int s = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a2[s / 2][(s % 2) * 8 + i]);
+#ifndef KPN_DBG_NOREC
                 if constexpr (s == 1) kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
+#endif
             }, acc);
 #pragma unroll
             for (int b = 0; b < 2; ++b)

@@ -377,6 +377,9 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
     // next issue slot; cheap insurance: 16 of ~770 cycles per step).
     auto arrive_half = [&](auto nn, auto& w, kpn_bf16x8 (&x)[3]) {
 #ifdef KPN_MFMA16_PLAIN
+#ifdef KPN_MFMA16_PLAIN_WAIT0   // bisection: every outstanding memory operation has completed before a half's MFMAs
+        __builtin_amdgcn_s_waitcnt(0);
+#endif
         (void)w; (void)x; return;
 #endif
         if constexpr (decltype(nn)::value == 2) kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
