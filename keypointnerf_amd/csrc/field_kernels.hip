@@ -473,6 +473,15 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
                 if constexpr (s == 1) kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
 #endif
             }, acc);
+#ifdef KPN_DBG_EXPORT   // bisection: block 1 of the rows carries an earlier layer's accumulator instead of the result
+#if KPN_DBG_EXPORT == 0
+            acc[1] = a0[1];
+#elif KPN_DBG_EXPORT == 1
+            acc[1] = a1[1];
+#else
+            acc[1] = a2[1];
+#endif
+#endif
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll

@@ -18,7 +18,12 @@ def regs(tok):
     return out
 
 
+LINEAR = "--linear" in sys.argv
+
+
 def main():
+    if LINEAR:
+        sys.argv.remove("--linear")
     path, sym = sys.argv[1], sys.argv[2]
     req = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     s = open(path).read()
@@ -49,8 +54,13 @@ def main():
             if name == 's_nop':
                 states += int(l2.split()[1]) + 1
                 continue
-            if name.startswith('s_branch') or name.startswith('s_cbranch') or name == 's_endpgm':
-                break  # conservative end of the straight-line scan
+            if name == 's_endpgm' or (name == 's_branch' and not LINEAR):
+                break
+            if name.startswith('s_cbranch') or name == 's_branch':
+                if not LINEAR:
+                    break  # end of the straight-line scan
+                states += 1   # LINEAR: keep scanning the fall-through path (over-approximates the layout order)
+                continue
             body = l2.split(None, 1)[1] if ' ' in l2 else ''
             touched = regs(body)
             if name.startswith('v_mfma'):
