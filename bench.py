@@ -332,6 +332,12 @@ def main():
             rj = os.path.join(ROOT, "profiles", "reference_cpu_pytorch.json")
             if os.path.exists(rj):   # the unmodified reference (PyTorch CPU), timed where it is mounted: scripts/time_reference_cpu.py
                 line["cpu_baseline"]["reference_pytorch"] = json.load(open(rj))
+            ej = os.path.join(ROOT, "profiles", "r02_eager_pytorch_on_mi355x.json")
+            if os.path.exists(ej):   # eager PyTorch restatement of the path on an MI355X (scripts/bench_torch_eager.py), recorded
+                e = json.load(open(ej))
+                line["eager_pytorch_same_gpu"] = {"rays_per_sec": max(v["rays_per_sec"] for k, v in e.items() if "ray" in k and isinstance(v, dict)),
+                                                  "recorded_by": "scripts/bench_torch_eager.py (profiles/r02_eager_pytorch_on_mi355x.json)",
+                                                  "what": e["what"]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
