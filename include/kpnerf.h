@@ -251,6 +251,8 @@ int kpn_profile_collect(double* geo_rows_ms_host, int64_t* launches_host, int64_
  * processed rows). */
 int kpn_profile_collect2(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host, int64_t* surplus_launches_host);
 size_t kpn_row_scratch_cap_bytes(void);
+/* Process-wide; workspace sizes queried before a change are stale (query kpn_*_workspace_bytes again). */
+int kpn_set_row_scratch_cap_bytes(size_t bytes);
 
 /* TRAIN branch of batch_render_pifu_nerf (forward only), every random draw supplied by the caller so that it can
  * be the reference's own: src/model.py:1008-1017 (patch pixels), :1049-1053 (stratified jitter), :993-994 (density

@@ -519,13 +519,17 @@ namespace {
 // batches that reuse it (kpn_batch, field_kernels.hip).  Sized for the worst case it was 32 GiB for a 512^2 frame at
 // 64 + 64 samples — of which a scene uses the valid third; the cap keeps one pass per frame (one launch ramp, one
 // weight staging) at a fixed, small footprint.  KPN_ROW_SCRATCH_MIB overrides the default of 3 GiB.
+size_t g_row_scratch_cap = 0;   // 0 = not set yet: KPN_ROW_SCRATCH_MIB or the default
 size_t row_scratch_cap_bytes() {
+    if (g_row_scratch_cap == 0) {
+        const char* e = getenv("KPN_ROW_SCRATCH_MIB");
 #ifdef KPN_SIMT_EMU
-    static const size_t cap = [] { const char* e = getenv("KPN_ROW_SCRATCH_MIB"); return e ? (size_t)atoll(e) << 20 : (size_t)1 << 20; }();
+        g_row_scratch_cap = e ? (size_t)atoll(e) << 20 : (size_t)1 << 20;
 #else
-    static const size_t cap = [] { const char* e = getenv("KPN_ROW_SCRATCH_MIB"); return (e ? (size_t)atoll(e) : (size_t)3072) << 20; }();
+        g_row_scratch_cap = (e ? (size_t)atoll(e) : (size_t)3072) << 20;
 #endif
-    return cap;
+    }
+    return g_row_scratch_cap;
 }
 const int kMaxBatches = 60;   // ticket pairs that fit the 512-byte counter block
 // passes of at most this many points always get their worst-case scratch (never batched): the backward entry points
@@ -535,11 +539,11 @@ const int64_t kUncappedPoints = 2048;
 #else
 const int64_t kUncappedPoints = 262144;
 #endif
-struct QueryLayout { size_t count, list, xscr, total; int tiles_cap, nbatch; };  // byte offsets
+struct QueryLayout { size_t count, list, xscr, lat, total; int tiles_cap, nbatch; };  // byte offsets
 QueryLayout query_layout(int64_t N, int V) {
     QueryLayout L;
     size_t o = 0;
-    L.count = o; o += 512;   // [0] valid count, [1 + 2b] k_geo_rows tickets of batch b, [2 + 2b] k_fuse_color tickets
+    L.count = o; o += 1024;  // [0] valid count, [1 + 3b .. 3 + 3b] work tickets of batch b's persistent kernels
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
     const size_t tile_bytes = (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4);
@@ -553,8 +557,13 @@ QueryLayout query_layout(int64_t N, int V) {
     L.tiles_cap = (int)cap;
     L.nbatch = (int)((ntiles + cap - 1) / cap);
     L.xscr = o; o += align_up(cap * tile_bytes, 256);
+    L.lat = o; o += align_up(cap * (size_t)(4 * 64 * sizeof(float4)), 256);   // compressed latent per tile (split colour path)
     L.total = o;
     return L;
+}
+int fuse_split_mode() {   // 0: k_fuse_color (default); 1: k_pool_geo + k_color_head, an A/B knob read per call
+    const char* e = getenv("KPN_FUSE_SPLIT");
+    return e ? atoi(e) : 0;
 }
 int field_grid_blocks() {
     // persistent grid: 256 CUs x 2 blocks of 256 threads (launch_bounds(256,2) -> 8 waves per CU)
@@ -609,7 +618,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
-    hipMemsetAsync(count, 0, 128 * sizeof(int), (hipStream_t)stream);
+    hipMemsetAsync(count, 0, 256 * sizeof(int), (hipStream_t)stream);
     const int ppt = mask_points_per_thread(N);
     KPN_LAUNCH(k_mask_compact, grid1d(N, 256 * ppt), dim3(256), stream, sc, ps, N, mode, lean, ppt, wp + kpn_scalar_off(), out, valid, list, count);
     const int blocks = field_grid_blocks();
@@ -618,7 +627,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     if (keep_rows && L.nbatch > 1) return fail(KPN_EWORKSPACE, "a pass whose rows a backward call reads again must fit the row scratch");
     for (int b = 0; b < L.nbatch; ++b) {
         const kpn_batch batch{b, L.tiles_cap};
-        int* tickets = count + 1 + 2 * b;
+        int* tickets = count + 1 + 3 * b;
 #ifndef KPN_SIMT_EMU
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
@@ -638,8 +647,20 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 #endif
         // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going
         // to read them again (keep_rows)
-        KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                   (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch);
+        if (fuse_split_mode() == 1 && out) {
+            float* lat = reinterpret_cast<float*>(base + L.lat);
+            // measured on the bench frame: one 512-thread workgroup per CU 53.7 ms, two 384-thread
+            // workgroups per CU (3 waves per SIMD) 54.6 ms, the fused kernel 52.3 ms
+            static const int pblocks = [] { const char* e = getenv("KPN_SPLIT_BLOCKS"); return e ? atoi(e) : fuse_grid_blocks(); }();
+            static const int pthreads = [] { const char* e = getenv("KPN_SPLIT_THREADS"); return e ? atoi(e) : 512; }();
+            KPN_LAUNCH(k_pool_geo, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                       (const float*)xscr, mode, lat, out, batch);
+            KPN_LAUNCH(k_color_head, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                       (const float*)xscr, keep_rows ? 0 : 1, (const float*)lat, out, batch);
+        } else {
+            KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                       (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch);
+        }
     }
     return check_launch("field query");
 }
@@ -1393,6 +1414,11 @@ extern "C" int kpn_profile_collect(double* ms_out, int64_t* launches_out, int64_
     return kpn_profile_collect2(ms_out, launches_out, rows_out, &surplus);
 }
 extern "C" size_t kpn_row_scratch_cap_bytes(void) { return row_scratch_cap_bytes(); }
+extern "C" int kpn_set_row_scratch_cap_bytes(size_t bytes) {
+    KPN_REQUIRE(bytes >= ((size_t)1 << 20), "the row scratch cap must be at least 1 MiB");
+    g_row_scratch_cap = bytes;   // workspaces sized before the change must be re-queried (kpn_*_workspace_bytes)
+    return KPN_OK;
+}
 extern "C" double kpn_flops_per_row(void) { return 2.0 * 70080.0; }
 
 extern "C" double kpn_flops_per_point(int32_t V) {

@@ -30,8 +30,8 @@ def rows(mode):
     h = ws.cpu().numpy()
     count = int(h[:4].view(np.int32)[0])
     al = lambda b: (b + 255) // 256 * 256
-    list_off = 512
-    xs_off = 512 + al(N * 4)
+    list_off = 1024
+    xs_off = 1024 + al(N * 4)
     lst = h[list_off:list_off + count * 4].view(np.int32)
     ntiles = (count + 31) // 32
     x = h[xs_off:xs_off + ntiles * V * 10 * 64 * 16].view(np.float32).reshape(ntiles, V, 10, 64, 4)

@@ -140,6 +140,44 @@ def test_headline_configs_vs_reference(ops, golden_weights, case, fine):
     assert (v.cpu().numpy().reshape(-1) != bits).sum() <= 4   # a point within an ulp of a mask / frustum threshold may flip
 
 
+def test_split_colour_path_is_bit_identical(ops, golden_weights, monkeypatch):
+    """KPN_FUSE_SPLIT=1 (k_pool_geo + k_color_head instead of k_fuse_color): bit-identical frame."""
+    scene, cfg, g = load_case(CASES[0])
+    s, ps = _prep(ops, scene)
+    H, W = s["cam_tar"]["height"], s["cam_tar"]["width"]
+    outs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+        o = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(0, 0, 1, W, H), n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+        outs.append({k: v.clone() for k, v in o.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_capped_row_scratch_batches_are_bit_identical(ops):
+    """The row scratch between k_geo_rows and k_fuse_color is capped and reused by batches of a pass: a frame rendered with
+    a cap that forces many batches (and surplus launches) equals the single-batch frame bit for bit."""
+    from keypointnerf_amd import lib as kl
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    L = kl.get_library()
+    scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(192, 192), mask="ellipsoid", seed=4, tar_focal_at_512=800.0)
+    s, ps = _prep(ops, scene)
+    w = ops.PackedWeights(random_hotpath_state_dict(seed=3))
+    old = L.kpn_row_scratch_cap_bytes()
+    outs = []
+    try:
+        for cap in (old, 96 << 20):                        # 36864 rays x 64 samples: 2.4 M points > the uncapped-pass limit
+            L.check(L.kpn_set_row_scratch_cap_bytes(cap))
+            plan = ops.RenderPlan(ps, (0, 0, 1, 192, 192), 64, 64, fine=True)
+            outs.append(({k: v.clone() for k, v in ops.render_rays(ps, w, s["cam_tar"], s["bounds"], plan=plan).items()}, plan.nbytes))
+    finally:
+        L.check(L.kpn_set_row_scratch_cap_bytes(old))
+    assert outs[1][1] < outs[0][1]                          # the cap is what sizes the workspace
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert float(outs[0][0]["alpha_fine"].mean()) > 0.05
+
+
 def test_full_frame_equals_reference_tiles(ops, golden_weights):
     """render_pifu_nerf's 2^(level-1) x 2^(level-1) strided tiles + pixel_shuffle (reference
     src/model.py:916-938) == one full-frame launch."""

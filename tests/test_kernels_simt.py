@@ -552,3 +552,18 @@ def test_ssim_kernel_vs_published_definition(env):
         scratch, out = np.zeros(lib.kpn_ssim_scratch_bytes(W, H), np.uint8), np.zeros(1, np.float64)
         lib.check(lib.kpn_ssim(sh.ptr(pred), sh.ptr(gt), H, W, 0, 0, W, H, sh.ptr(out), sh.ptr(scratch), None))
         assert abs(out[0] - expect) < 3e-6, (name, out[0], expect)
+
+
+def test_split_colour_path_is_bit_identical(env, monkeypatch):
+    """KPN_FUSE_SPLIT=1: k_fuse_color as two kernels (pooling + layers2 + compress / colour head; the A/B experiment of
+    DESIGN.md section 9.3) — same arithmetic in the same order: bit-identical field values, eval and train-style calls."""
+    lib, packed, _ = env
+    scene, cfg, g = load_case(CASES[0])
+    hs = sh.HostScene(lib, scene)
+    pts, view = g["query.1.pts"][0], g["query.1.view"][0]
+    res = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+        res.append([sh.query(lib, hs, packed, pts, view, mode=m) for m in (0, 1)])
+    for (o0, v0), (o1, v1) in zip(res[0], res[1]):
+        assert np.array_equal(v0, v1) and np.array_equal(o0, o1)
