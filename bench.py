@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--tar-focal", type=float, default=800.0,
                     help="target camera focal length in px at 512 (800 = the subject framed like the reference's orbit, "
                          "31 %% of the field evaluations valid; 600 = round 1's scene, 17 %%)")
+    ap.add_argument("--density-bias", type=float, default=0.0,
+                    help="added to the bias of the density output (0 = every valid point has density > 0, as with the seeded "
+                         "random weights; -20 = about half of the visual hull is empty, as with a trained density)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (dense mask / round-1 scene / training) results")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
@@ -210,7 +213,7 @@ def main():
         os.environ.pop("KPN_NO_COARSE_REUSE", None)
     L = kl.get_library()
     L.check(L.kpn_set_geo_rows_mode(args.geo_rows_mode))
-    sd = random_hotpath_state_dict(seed=3)
+    sd = random_hotpath_state_dict(seed=3, density_bias=args.density_bias)
     res = args.res
     scene_cpu = make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), mask=args.mask, seed=1,
                            tar_focal_at_512=args.tar_focal)
@@ -324,6 +327,18 @@ def main():
                 sec[name] = {"ms_per_frame": ms2, "rays_per_sec": rays_per_step / (ms2 * 1e-3),
                              "valid_fraction_of_field_evaluations": rows2 / (args.views * rays_per_step * evals_per_ray)}
                 del sc2
+            if args.density_bias == 0.0:
+                # a density that is exactly 0 in about half of the visual hull (trained models: the free space between the
+                # hull and the surface): tiles of the valid list without a single live point skip the colour head
+                for db in (-20.0, -30.0):
+                    w2 = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=db), device=dev)
+                    ms2, rows2 = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
+                    os.environ["KPN_NO_ZERO_SKIP"] = "1"
+                    ms3, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
+                    os.environ.pop("KPN_NO_ZERO_SKIP")
+                    sec[f"partly_empty_hull_density_bias_{int(db)}"] = {
+                        "ms_per_frame": ms2, "ms_per_frame_without_the_zero_density_short_path": ms3,
+                        "rays_per_sec": rays_per_step / (ms2 * 1e-3)}
             if args.views == 3 and args.geo_rows_mode == 0:
                 sec["training_step_configs3"] = time_training(ops, torch, dev, sd)
             line["secondary"] = sec

@@ -14,6 +14,7 @@
 // kernels (ray_kernels.hip / field_kernels.hip)
 #include "ray_kernels.hip"
 #include "field_kernels.hip"
+#include "fuse_split_kernels.hip"
 #include "field_bwd_kernels.hip"
 #include "fuse_bwd_kernels.hip"
 
@@ -539,11 +540,11 @@ const int64_t kUncappedPoints = 2048;
 #else
 const int64_t kUncappedPoints = 262144;
 #endif
-struct QueryLayout { size_t count, list, xscr, lat, total; int tiles_cap, nbatch; };  // byte offsets
+struct QueryLayout { size_t count, list, xscr, lat, list2, total; int tiles_cap, nbatch; };  // byte offsets
 QueryLayout query_layout(int64_t N, int V) {
     QueryLayout L;
     size_t o = 0;
-    L.count = o; o += 1024;  // [0] valid count, [1 + 3b .. 3 + 3b] work tickets of batch b's persistent kernels
+    L.count = o; o += 1024;  // [0] valid count, [1 + 4b .. 3 + 4b] work tickets of batch b's persistent kernels, [4 + 4b] its live count
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
     const size_t tile_bytes = (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4);
@@ -558,6 +559,7 @@ QueryLayout query_layout(int64_t N, int V) {
     L.nbatch = (int)((ntiles + cap - 1) / cap);
     L.xscr = o; o += align_up(cap * tile_bytes, 256);
     L.lat = o; o += align_up(cap * (size_t)(4 * 64 * sizeof(float4)), 256);   // compressed latent per tile (split colour path)
+    L.list2 = o; o += align_up(cap * (size_t)KPN_TILE * sizeof(int), 256);      // points of a batch with density > 0
     L.total = o;
     return L;
 }
@@ -627,7 +629,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     if (keep_rows && L.nbatch > 1) return fail(KPN_EWORKSPACE, "a pass whose rows a backward call reads again must fit the row scratch");
     for (int b = 0; b < L.nbatch; ++b) {
         const kpn_batch batch{b, L.tiles_cap};
-        int* tickets = count + 1 + 3 * b;
+        int* tickets = count + 1 + 4 * b;
 #ifndef KPN_SIMT_EMU
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
@@ -647,19 +649,29 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 #endif
         // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going
         // to read them again (keep_rows)
-        if (fuse_split_mode() == 1 && out) {
+        if (fuse_split_mode() >= 1 && out) {
             float* lat = reinterpret_cast<float*>(base + L.lat);
+            const bool compact = fuse_split_mode() == 2 && lean && !keep_rows;   // render passes only
+            int* count2 = compact ? tickets + 3 : nullptr;
+            int* list2 = compact ? reinterpret_cast<int*>(base + L.list2) : nullptr;
             // measured on the bench frame: one 512-thread workgroup per CU 53.7 ms, two 384-thread
             // workgroups per CU (3 waves per SIMD) 54.6 ms, the fused kernel 52.3 ms
             static const int pblocks = [] { const char* e = getenv("KPN_SPLIT_BLOCKS"); return e ? atoi(e) : fuse_grid_blocks(); }();
             static const int pthreads = [] { const char* e = getenv("KPN_SPLIT_THREADS"); return e ? atoi(e) : 512; }();
             KPN_LAUNCH(k_pool_geo, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                       (const float*)xscr, mode, lat, out, batch);
-            KPN_LAUNCH(k_color_head, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                       (const float*)xscr, keep_rows ? 0 : 1, (const float*)lat, out, batch);
+                       (const float*)xscr, mode, lat, out, batch, count2, list2);
+            if (compact)
+                KPN_LAUNCH(k_color_head<true>, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                           (const float*)xscr, keep_rows ? 0 : 1, (const float*)lat, out, batch, (const int*)count2, (const int*)list2);
+            else
+                KPN_LAUNCH(k_color_head<false>, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                           (const float*)xscr, keep_rows ? 0 : 1, (const float*)lat, out, batch, (const int*)nullptr, (const int*)nullptr);
         } else {
+            // zero-density short path: render passes only (lean), never when a backward pass reads the rows again
+            const char* zs = getenv("KPN_NO_ZERO_SKIP");   // A/B knob, read per call
+            const int zero_skip = (lean && !keep_rows && !(zs && atoi(zs))) ? 1 : 0;
             KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                       (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch);
+                       (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch, zero_skip);
         }
     }
     return check_launch("field query");

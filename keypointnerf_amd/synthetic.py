@@ -167,12 +167,14 @@ HOTPATH_LAYERS = [
 ]
 
 
-def random_hotpath_state_dict(seed=0, bias_std=0.05, density_gain=25.0):
+def random_hotpath_state_dict(seed=0, bias_std=0.05, density_gain=25.0, density_bias=0.0):
     """A random state dict with the reference's parameter names/shapes for the hot-path modules.
 
     Used where the reference itself is not importable (GPU box): kaiming-like weights, non-zero
     biases (the reference's init leaves every bias at exactly 0, which would hide bias bugs) and a
-    density head scaled so that alpha along a ray is neither ~0 nor saturated.
+    density head scaled so that alpha along a ray is neither ~0 nor saturated.  density_bias is added to the bias of the
+    density output `rad` (mlp_geo.layers2.layers.2, row 1): a negative value makes relu(rad) exactly 0 in part of the visual
+    hull, as a trained density is in the free space between the silhouettes' hull and the surface.
     """
     g = torch.Generator().manual_seed(seed)
     sd = {}
@@ -186,7 +188,7 @@ def random_hotpath_state_dict(seed=0, bias_std=0.05, density_gain=25.0):
             sd[prefix + ".weight"] = w
         sd[prefix + ".bias"] = b
     sd["mlp_geo.layers2.layers.2.linear.weight"] *= density_gain
-    sd["mlp_geo.layers2.layers.2.linear.bias"] = torch.tensor([0.0, 0.5 * density_gain * 0.05])
+    sd["mlp_geo.layers2.layers.2.linear.bias"] = torch.tensor([0.0, 0.5 * density_gain * 0.05 + float(density_bias)])
     sd["mlp_tex.ani_al"] = torch.tensor(0.2)
     return sd
 

@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMT_DIR = os.path.join(ROOT, "tests", "simt")
 SIMT_SO = os.path.join(SIMT_DIR, "_build", "libkpnerf_simt.so")
 CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
-_SOURCES = [os.path.join(ROOT, "keypointnerf_amd", "csrc", f) for f in
-            ("kpn_api.hip", "ray_kernels.hip", "field_kernels.hip", "field_bwd_kernels.hip", "fuse_bwd_kernels.hip", "kpn_device.h", "kpn_common.h")] + \
+_CSRC = os.path.join(ROOT, "keypointnerf_amd", "csrc")
+_SOURCES = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h"))] + \
            [os.path.join(SIMT_DIR, f) for f in ("simt.h", "simt.cpp")] + [os.path.join(ROOT, "include", "kpnerf.h")]
 
 

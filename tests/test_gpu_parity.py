@@ -154,6 +154,38 @@ def test_split_colour_path_is_bit_identical(ops, golden_weights, monkeypatch):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+def test_zero_density_tiles_take_the_short_path_exactly(ops, monkeypatch):
+    """Tiles of the valid list whose 32 points all have relu(rad) == 0 skip compress + the colour head in the render passes
+    (their colours are multiplied by a contribution of exactly 0): with a density head biased so that half of the visual
+    hull is empty, the frame is bit-identical with and without the short path, and matches the oracle."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    from oracle import oracle
+    sd = random_hotpath_state_dict(seed=3, density_bias=-20.0)
+    scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(48, 48), mask="ellipsoid", seed=1, tar_focal_at_512=800.0)
+    s, ps = _prep(ops, scene)
+    w = ops.PackedWeights(sd)
+    outs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("KPN_NO_ZERO_SKIP", off)
+        o = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 48, 48), n_coarse=64, n_fine=64)
+        outs.append({k: v.clone() for k, v in o.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    monkeypatch.setenv("KPN_NO_ZERO_SKIP", "0")
+    for split in ("1", "2"):                                  # split kernels; 2 = colour head over the live points only
+        monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+        o = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 48, 48), n_coarse=64, n_fine=64)
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], o[k]), (split, k)
+    monkeypatch.setenv("KPN_FUSE_SPLIT", "0")
+    yy, xx = np.meshgrid(np.arange(48), np.arange(48), indexing="ij")
+    pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
+    ref = oracle.render_rays(oracle.OracleScene(scene), oracle.flat_weights(sd), scene["cam_tar"], scene["bounds"], pix, 64, 64)
+    assert np.abs(outs[0]["tex_fg_fine"][0].permute(1, 2, 0).reshape(-1, 3).cpu().numpy() - ref["tex_fg_fine"]).max() <= RGBA_TOL
+    assert np.abs(outs[0]["alpha_fine"].reshape(-1).cpu().numpy() - ref["alpha_fine"]).max() <= RGBA_TOL
+    assert 0.02 < float(outs[0]["alpha_fine"].mean()) < 0.9
+
+
 def test_capped_row_scratch_batches_are_bit_identical(ops):
     """The row scratch between k_geo_rows and k_fuse_color is capped and reused by batches of a pass: a frame rendered with
     a cap that forces many batches (and surplus launches) equals the single-batch frame bit for bit."""

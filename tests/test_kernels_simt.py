@@ -567,3 +567,32 @@ def test_split_colour_path_is_bit_identical(env, monkeypatch):
         res.append([sh.query(lib, hs, packed, pts, view, mode=m) for m in (0, 1)])
     for (o0, v0), (o1, v1) in zip(res[0], res[1]):
         assert np.array_equal(v0, v1) and np.array_equal(o0, o1)
+
+
+def test_zero_density_short_path_is_exact(env, monkeypatch):
+    """k_fuse_color skips compress + colour head for tiles whose points all have relu(rad) == 0 (render passes): same frame
+    bit for bit with the short path switched off (KPN_NO_ZERO_SKIP=1), density head biased so that such tiles exist."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    lib = env[0]
+    scene = make_scene(n_views=3, src_hw=(64, 64), tar_hw=(20, 20), mask="ellipsoid", seed=1, tar_focal_at_512=800.0)
+    hs = sh.HostScene(lib, scene)
+    res = []
+    for bias in (-20.0, -60.0):                      # about half of the hull empty / all of it
+        packed = sh.pack_weights(lib, random_hotpath_state_dict(seed=3, density_bias=bias))
+        pair = []
+        for off in ("0", "1"):
+            monkeypatch.setenv("KPN_NO_ZERO_SKIP", off)
+            pair.append(sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 20, 20), 32, 32))
+        for k in pair[0]:
+            assert np.array_equal(pair[0][k], pair[1][k]), (bias, k)
+        res.append(pair[0])
+    assert res[0]["alpha_fine"].max() > 0.1 and res[1]["alpha_fine"].max() == 0.0
+    # the same frames through the split kernels with the second compaction (colour head over the live points only)
+    for bias, ref in zip((-20.0, -60.0), res):
+        packed = sh.pack_weights(lib, random_hotpath_state_dict(seed=3, density_bias=bias))
+        monkeypatch.setenv("KPN_NO_ZERO_SKIP", "0")
+        for split in ("1", "2"):
+            monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+            o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 20, 20), 32, 32)
+            for k in ref:
+                assert np.array_equal(o[k], ref[k]), (bias, split, k)
