@@ -88,7 +88,7 @@ class _State:
         params = [p for n, p in self.net.named_parameters() if n.startswith(_HOT_PREFIXES)]
         key = _version_key(params)
         if key is None or key != self.weights_key:
-            dev = params[0].device if params and params[0].is_cuda else "cuda"
+            dev = params[0].device if params and ops._on_gpu(params[0]) else "cuda"
             # packed on the device from the live parameters (weight-norm fold + MFMA operand order): no host round trip
             with torch.no_grad():
                 self.weights = ops.PackedWeights.from_plain(plain_tensor_from_module(self.net).to(dev), device=dev)

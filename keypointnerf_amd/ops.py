@@ -27,10 +27,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_gpu(t):
+    return t.is_cuda
+
+
 def _dev(t, name, dtype=_f32):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
-    if not t.is_cuda:
+    if not _on_gpu(t):
         raise RuntimeError(f"{name} must live on the GPU (got {t.device}); keypointnerf_amd has no CPU path")
     if t.dtype != dtype:
         t = t.to(dtype)
@@ -60,7 +64,7 @@ class PackedWeights:
         """From the flat effective-parameter vector (weights.flatten_plain / plain_tensor_from_module layout).  A CUDA
         tensor is packed on the device (kpn_pack_weights_device: no host round trip, asynchronous)."""
         L = kl.get_library()
-        if isinstance(plain, torch.Tensor) and plain.is_cuda:
+        if isinstance(plain, torch.Tensor) and _on_gpu(plain):
             flat = plain.detach().to(_f32).contiguous()
             if flat.numel() != L.kpn_plain_weight_floats():
                 raise ValueError("unexpected hot-path parameter count")
@@ -112,7 +116,7 @@ class PreparedScene:
             self.fg = None
         else:
             m = src_foreground_mask
-            if not m.is_cuda:
+            if not _on_gpu(m):
                 raise RuntimeError("src_foreground_mask must live on the GPU")
             self.fg = (m.reshape(V, H, W) != 0).to(torch.uint8).contiguous()
         d = kl.SceneDesc()
@@ -372,7 +376,7 @@ def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, ke
     density noise.  Returns the out dict with (1,3,R) / (1,R) tensors in patch order (reshape to (out_h,out_w))."""
     L = kl.get_library()
     px = pix.to(torch.int32).contiguous()
-    if not px.is_cuda:
+    if not _on_gpu(px):
         raise RuntimeError("pix must live on the GPU")
     R = px.shape[0]
     plan = RenderPlan(scene, (0, 0, 1, R, 1), n_coarse, n_fine, fine=True, chunk_rays=chunk_rays)
@@ -416,7 +420,7 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
     backward_kept: the forward is not repeated).  Returns (d_plain, d_geo0, d_geo1, d_tex) as ops.query_backward."""
     L = kl.get_library()
     px = pix.to(torch.int32).contiguous()
-    if not px.is_cuda:
+    if not _on_gpu(px):
         raise RuntimeError("pix must live on the GPU")
     R, V = px.shape[0], scene.n_views
     K, RT, b = _dev(cam_tar["K"], "cam_tar['K']").reshape(4, 4), _dev(cam_tar["RT"], "cam_tar['RT']").reshape(4, 4), _dev(bounds, "bounds").reshape(2, 3)
