@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (dense mask / round-1 scene / training) results")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
-    ap.add_argument("--geo-rows-mode", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--geo-rows-mode", type=int, default=0, choices=[0, 1, 2],
                     help="0 = fp32 MFMA (default); 1 = split-bf16 operands on the bf16 MFMA (opt-in, fp32-class results)")
     ap.add_argument("--no-coarse-reuse", action="store_true",
                     help="evaluate the field at all Sc+Sf merged samples in the fine pass, as the reference does (default: the "
@@ -277,7 +277,7 @@ def main():
         valid_frac = rows_per_step / (args.views * rays_per_step * evals_per_ray)
         torch.cuda.synchronize()
         peak_alloc = torch.cuda.max_memory_allocated(dev)
-        peak = BF16_SPLIT_PEAK_TFLOPS if args.geo_rows_mode == 1 else FP32_MFMA_PEAK_TFLOPS
+        peak = BF16_SPLIT_PEAK_TFLOPS if args.geo_rows_mode >= 1 else FP32_MFMA_PEAK_TFLOPS
         line = {
             "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -303,7 +303,7 @@ def main():
                                       + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
                        "dist_world_size": (dist.get_world_size() if world > 1 else 1),
                        "dist_backend": (args.dist_backend if world > 1 else None)},
-            "roofline": {"kernel": "k_geo_rows" if args.geo_rows_mode == 0 else "k_geo_rows_h", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": ("k_geo_rows", "k_geo_rows_h", "k_geo_rows_h2")[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),

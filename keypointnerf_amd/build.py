@@ -10,7 +10,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_lib", "libkpnerf_hip.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# -fno-slp-vectorize: the SLP vectoriser gathers the hand-interleaved scalar VALU work of k_geo_rows_h2 into packed-f32
+# lumps (v_pk_mul_f32 ...) placed ahead of the MFMAs they were meant to sit between — measured 7.4 -> 6.8 ms per launch —
+# and packed f32 VALU is an anti-lever beside MFMAs anyway (MI355X_MICROARCH.md)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"]
 
 
 def needs_build():

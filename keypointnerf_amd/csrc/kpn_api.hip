@@ -15,6 +15,7 @@
 #include "ray_kernels.hip"
 #include "field_kernels.hip"
 #include "fuse_split_kernels.hip"
+#include "geo_rows_pair_kernels.hip"
 #include "field_bwd_kernels.hip"
 #include "fuse_bwd_kernels.hip"
 
@@ -151,7 +152,7 @@ void walk_hsegments(const size_t (&w_off)[4], Emit emit) {
 inline size_t hseg_slot(int hseg, size_t el, int pc) {
     const int NOB = kpn_hseg_shapes[hseg].nob;
     const size_t e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, s = el / (512 * (size_t)NOB);
-    return (size_t)kpn_hseg_off(hseg) * 2 + ((((s * 3 + pc) * NOB + ob) * 64 + lane) * 8 + e);
+    return (size_t)kpn_hseg_off(hseg) * 2 + ((((s * NOB + ob) * 3 + pc) * 64 + lane) * 8 + e);   // [step][block][piece][lane][8]
 }
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
 }  // namespace
@@ -595,6 +596,14 @@ int geo_rows_mode() {
     if (g_geo_rows_mode < 0) { const char* e = getenv("KPN_GEO_ROWS_MODE"); g_geo_rows_mode = e ? atoi(e) : 0; }
     return g_geo_rows_mode;
 }
+int pair_grid_blocks() {   // k_geo_rows_h2: one 256-thread workgroup per CU = one wave per SIMD
+#ifdef KPN_SIMT_EMU
+    return 8;
+#else
+    static int blocks = [] { const char* e = getenv("KPN_H2_BLOCKS"); return e ? atoi(e) : 256; }();
+    return blocks;
+#endif
+}
 int fuse_grid_blocks() {
 #ifdef KPN_SIMT_EMU
     return 4;
@@ -634,7 +643,9 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
 #endif
-        if (geo_rows_mode() == 1)
+        if (geo_rows_mode() == 2)
+            KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+        else if (geo_rows_mode() == 1)
             KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
         else
             KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
@@ -679,7 +690,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 }  // namespace
 
 extern "C" int kpn_set_geo_rows_mode(int32_t mode) {
-    KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
+    KPN_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (fp32 MFMA), 1 (split-bf16 MFMA) or 2 (split-bf16 MFMA, two tiles per wave)");
     g_geo_rows_mode = mode;
     return KPN_OK;
 }

@@ -74,6 +74,9 @@ __device__ __forceinline__ void kpn_split3(const float (&x)[8], kpn_bf16x8& h, k
     }
 }
 __device__ __forceinline__ kpn_bf16x8 kpn_as_bf16x8(kpn_f32x4 v) { return __builtin_bit_cast(kpn_bf16x8, v); }
+typedef __bf16 kpn_bf16_t;
+__device__ __forceinline__ kpn_bf16_t kpn_to_bf(float f) { return (__bf16)f; }   // round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float kpn_bf_to_f(kpn_bf16_t b) { return (float)b; }
 #define KPN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #else
 typedef uint16_t kpn_bf16x8 __attribute__((ext_vector_type(8)));
@@ -93,6 +96,9 @@ static inline void kpn_split3(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m,
     }
 }
 static inline kpn_bf16x8 kpn_as_bf16x8(kpn_f32x4 v) { kpn_bf16x8 r; memcpy(&r, &v, 16); return r; }
+typedef uint16_t kpn_bf16_t;
+static inline kpn_bf16_t kpn_to_bf(float f) { return kpn_f2bf(f); }
+static inline float kpn_bf_to_f(kpn_bf16_t b) { return kpn_bf2f(b); }
 #define KPN_MFMA16(a, b, c) simt_mfma_f32_32x32x16_bf16((a), (b), (c))
 #endif
 
@@ -205,7 +211,7 @@ constexpr int kpn_brow_off(int row) { return kpn_bseg_woff(BSEG_COUNT) + row * 6
 constexpr int kpn_bwd_end() { return kpn_brow_off(BROW_COUNT); }
 // Split-bf16 segments of layers1 (k_geo_rows_h), after the backward region.  K runs in steps of 16: the h = 0 lanes of
 // the B operand supply 8 values, the h = 1 lanes 8 — for chained inputs a lane's registers 8j..8j+7 of block b (step
-// 2b + j), i.e. features 32b + rowmap(8j + e, h).  Stream per step: [piece h,m,l][ob][64 lanes] x 16 B (8 bf16 =
+// 2b + j), i.e. features 32b + rowmap(8j + e, h).  Stream per step: [ob][piece h,m,l][64 lanes] x 16 B (8 bf16 =
 // A[i = lane&31][k = 8(lane>>5) + e]); the fp32 bias blocks of the forward segments are reused.
 //   HSEG_G1_0A: step j = keypoints j (h=0) and j+12 (h=1): 7 encoding values + 1 pad;  HSEG_G1_0B: 8 geometry channels per half
 //   HSEG_G1_2 : 8 chained steps + 1 step with the 4+4 hd channels (+ pads)

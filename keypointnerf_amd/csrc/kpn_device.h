@@ -359,7 +359,7 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-            for (int k = 0; k < n; ++k) w[pc][k] = kpn_as_bf16x8(src[(pc * NOB + ob0 + k) * 64]);
+            for (int k = 0; k < n; ++k) w[pc][k] = kpn_as_bf16x8(src[((ob0 + k) * 3 + pc) * 64]);
     };
     auto mfma_half = [&](int ob0, int n, auto& w, const kpn_bf16x8 (&x)[3]) {
 #pragma unroll

@@ -449,24 +449,30 @@ def test_device_weight_packer(env):
 
 def test_split_bf16_geo_rows(env):
     """k_geo_rows_h (split-bf16 operands on the emulated v_mfma_f32_32x32x16_bf16) vs the reference's recorded query
-    outputs and vs the fp32-MFMA kernel: fp32-class (three bf16 pieces, six products)."""
+    outputs and vs the fp32-MFMA kernel: fp32-class (three bf16 pieces, six products).  k_geo_rows_h2 (two tiles per wave,
+    mode 2) feeds every accumulator the same products in the same order: bit-equal to mode 1, with an even and an odd number
+    of tiles (the last pair's second tile is computed and not stored)."""
     lib, packed, wflat = env
     scene, cfg, g = load_case(CASES[0])
     hs = sh.HostScene(lib, scene)
     valid = g["query.0.valid"][0].reshape(-1)
-    idx = np.concatenate([np.where(valid)[0][:700], np.where(~valid)[0][:60]])
-    pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
-    try:
-        lib.check(lib.kpn_set_geo_rows_mode(1))
-        assert lib.kpn_get_geo_rows_mode() == 1
-        o1, v1 = sh.query(lib, hs, packed, pts, view)
-    finally:
-        lib.check(lib.kpn_set_geo_rows_mode(0))
-    o0, v0 = sh.query(lib, hs, packed, pts, view)
-    assert np.array_equal(v0, v1) and v1.sum() == 700
-    assert np.abs(o1 - ref)[v1].max() < 1e-5
-    assert np.abs(o1 - o0)[v1].max() < 5e-6
-    assert lib.kpn_set_geo_rows_mode(2) != 0
+    for n_valid in (704, 660):                                       # 22 and 21 tiles
+        idx = np.concatenate([np.where(valid)[0][:n_valid], np.where(~valid)[0][:60]])
+        pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
+        try:
+            lib.check(lib.kpn_set_geo_rows_mode(1))
+            assert lib.kpn_get_geo_rows_mode() == 1
+            o1, v1 = sh.query(lib, hs, packed, pts, view)
+            lib.check(lib.kpn_set_geo_rows_mode(2))
+            o2, v2 = sh.query(lib, hs, packed, pts, view)
+        finally:
+            lib.check(lib.kpn_set_geo_rows_mode(0))
+        o0, v0 = sh.query(lib, hs, packed, pts, view)
+        assert np.array_equal(v0, v1) and np.array_equal(v0, v2) and v1.sum() == n_valid
+        assert np.abs(o1 - ref)[v1].max() < 1e-5
+        assert np.abs(o1 - o0)[v1].max() < 5e-6
+        assert np.array_equal(o1, o2)
+    assert lib.kpn_set_geo_rows_mode(3) != 0
 
 
 def test_ssim_kernel(env):
