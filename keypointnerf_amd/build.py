@@ -10,10 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_lib", "libkpnerf_hip.so")
-# -fno-slp-vectorize: the SLP vectoriser gathers the hand-interleaved scalar VALU work of k_geo_rows_h2 into packed-f32
-# lumps (v_pk_mul_f32 ...) placed ahead of the MFMAs they were meant to sit between — measured 7.4 -> 6.8 ms per launch —
-# and packed f32 VALU is an anti-lever beside MFMAs anyway (MI355X_MICROARCH.md)
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-slp-vectorize"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# two translation units: the library, and the pair-tile rows kernel with its own flag (see csrc/geo_rows_pair_tu.hip)
+UNITS = [("kpn_api.hip", []), ("geo_rows_pair_tu.hip", ["-fno-slp-vectorize"])]
 
 
 def needs_build():
@@ -30,7 +29,17 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "kpn_api.hip"), "-o", OUT]
+    objs = []
+    for src, extra in UNITS:
+        obj = os.path.join(os.path.dirname(OUT), src.replace(".hip", ".o"))
+        cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        objs.append((obj, subprocess.Popen(cmd)))
+    for obj, proc in objs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in objs] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

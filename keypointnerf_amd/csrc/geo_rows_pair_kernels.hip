@@ -178,6 +178,10 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
 __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
+#if defined(KPN_H2_PAD) && !defined(KPN_SIMT_EMU)   // soak builds: shift every instruction of the kernel by 4 * KPN_H2_PAD bytes
+#pragma unroll
+    for (int i = 0; i < KPN_H2_PAD; ++i) asm volatile("s_nop 0");
+#endif
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int count = *count_ptr;

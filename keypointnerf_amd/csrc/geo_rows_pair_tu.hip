@@ -1,0 +1,15 @@
+// Translation unit of k_geo_rows_h2 (geo_rows_pair_kernels.hip) for the device build: compiled with -fno-slp-vectorize.
+// The kernel's VALU work is interleaved with its MFMAs by hand; the SLP vectoriser gathers those scalar operations into
+// packed-f32 lumps (v_pk_mul_f32 ...) placed ahead of the MFMAs they were meant to sit between (measured: 7.4 -> 6.8 ms per
+// launch without it), and packed f32 VALU is an anti-lever beside MFMAs anyway (MI355X_MICROARCH.md).  The flag changes
+// the rounding of other kernels' contracted arithmetic, so it is confined to this file; the rest of the library is
+// kpn_api.hip.  The host emulator build includes the kernel into kpn_api.hip directly (one translation unit, no flags).
+#include "kpn_field_shared.h"
+#include "geo_rows_pair_kernels.hip"
+
+// not part of the C ABI: called by run_field (kpn_api.hip) for kpn_set_geo_rows_mode(2)
+extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_geo_rows_h2(
+    int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp, const int* list, const int* count,
+    int* tickets, float* xscr, int batch_index, int tiles_cap) {
+    KPN_LAUNCH(k_geo_rows_h2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, kpn_batch{batch_index, tiles_cap});
+}

@@ -15,7 +15,12 @@
 #include "ray_kernels.hip"
 #include "field_kernels.hip"
 #include "fuse_split_kernels.hip"
-#include "geo_rows_pair_kernels.hip"
+#ifdef KPN_SIMT_EMU
+#include "geo_rows_pair_kernels.hip"   // the device build compiles this kernel as its own translation unit (geo_rows_pair_tu.hip)
+#else
+extern "C" void kpn_internal_launch_geo_rows_h2(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
+                                                const int* list, const int* count, int* tickets, float* xscr, int batch_index, int tiles_cap);
+#endif
 #include "field_bwd_kernels.hip"
 #include "fuse_bwd_kernels.hip"
 
@@ -644,7 +649,11 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
 #endif
         if (geo_rows_mode() == 2)
+#ifdef KPN_SIMT_EMU
             KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+#else
+            kpn_internal_launch_geo_rows_h2(pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, batch.index, batch.tiles_cap);
+#endif
         else if (geo_rows_mode() == 1)
             KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
         else

@@ -1,0 +1,119 @@
+// Device helpers shared by the field kernels (field_kernels.hip) and the pair-tile rows kernel, which is compiled as its
+// own translation unit (geo_rows_pair_tu.hip): the point source, the batches of the capped row scratch, the colour
+// head's gather record.
+#pragma once
+#include "kpn_device.h"
+
+struct kpn_points {
+    // explicit points (kpn_query): pts/view (N,3); or ray-marched (kpn_render_rays): cam_pos(3),
+    // dirs (R,3), z (R,S): point n = ray n/S at depth z[n], view = dirs[n/S]  (model.py:1057-1061)
+    const float* pts;
+    const float* view;
+    const float* cam_pos;
+    const float* dirs;
+    const float* z;
+    int S;
+    // train-time density noise of eval_func (model.py:993-994): rad += noise[n] * noise_std; NULL in eval
+    const float* noise;
+    float noise_std;
+};
+// The row scratch holds at most `tiles_cap` tiles x V rows.  A pass whose valid list is longer is evaluated in
+// nb = ceil(ntiles / tiles_cap) batches (k_geo_rows + k_fuse_color per batch, the scratch reused); the host cannot know
+// nb without a sync, so it launches the worst-case number of batches and the surplus ones return at once.  Tiles are
+// split evenly: batch b owns [ntiles*b/nb, ntiles*(b+1)/nb).
+struct kpn_batch { int index, tiles_cap; };
+__device__ __forceinline__ bool kpn_batch_range(const kpn_batch& b, int ntiles, int& t0, int& t1) {
+    const int nb = (ntiles + b.tiles_cap - 1) / b.tiles_cap;
+    if (b.index >= nb) return false;
+    t0 = (int)((int64_t)ntiles * b.index / nb);
+    t1 = (int)((int64_t)ntiles * (b.index + 1) / nb);
+    return true;
+}
+
+template <bool S = false>
+__device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, float (&P)[3], float (&D)[3]) {
+    if (ps.pts) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { P[k] = ps.pts[n * 3 + k]; D[k] = ps.view[n * 3 + k]; }
+    } else {
+        const int64_t r = n / ps.S;
+        const float zz = ps.z[n];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            D[k] = ps.dirs[r * 3 + k];
+            P[k] = kpn_add<S>(ps.cam_pos[k], kpn_mul<S>(D[k], zz));
+        }
+    }
+}
+
+// Boundary-smooth pooling weight of one view (model.py:752-759, mask == 1), un-normalised
+__device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
+    const float c3[3] = {RADD(RMUL(0.5f, q.xn), 0.5f), RADD(RMUL(0.5f, q.yn), 0.5f), RADD(RMUL(0.5f, q.zn), 0.5f)};
+    float w3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float d = fminf(c3[i], RSUB(1.0f, c3[i]));
+        w3[i] = kpn_sigmoid(RMUL(5.0f, RSUB(d / 0.1f, 1.0f)));
+    }
+    return RMUL(RMUL(w3[0], w3[1]), w3[2]);
+}
+
+// the colour head's per-(point,view) gather record (query_color, model.py:806-832): h=0 lanes [r,g,b, pooling
+// weight | ray_diff direction(3), dot], h=1 lanes the 8 texture channels (model.py:818)
+__device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, int h,
+                                               const kpn_proj& q, const float (&P)[3], const float (&D)[3], float4& rec0,
+                                               float4& rec1) {
+#ifdef KPN_DBG_REC_NOBRANCH   // bisection: both halves compute both records, then select
+    float4 ra0, ra1, rb0, rb1;
+    {
+        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);
+        ra0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
+        const float* cp = tb + KPN_TBL_CPOS;
+        float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
+        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+        const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
+        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
+        ra1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
+        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+        rb0 = kpn_tap4(tx, 8, 0, tt);
+        rb1 = kpn_tap4(tx, 8, 4, tt);
+    }
+    rec0 = h ? rb0 : ra0;
+    rec1 = h ? rb1 : ra1;
+    return;
+#endif
+    if (h == 0) {
+        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+#ifdef KPN_DBG_REC_NOLOAD
+        const float4 c = make_float4(0.3f, 0.4f, 0.5f, 1.0f);
+        (void)ti;
+#else
+        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
+#endif
+        rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
+        const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
+        float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
+        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+        const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
+        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
+        rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
+    } else {
+        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+#ifdef KPN_DBG_REC_NOLOAD
+        rec0 = make_float4(0.1f, 0.2f, -0.1f, 0.3f); rec1 = make_float4(-0.2f, 0.1f, 0.0f, 0.2f);
+        (void)tt; (void)tx;
+#else
+        rec0 = kpn_tap4(tx, 8, 0, tt);
+        rec1 = kpn_tap4(tx, 8, 4, tt);
+#endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row kernel.  x scratch layout: [(tile*V + v)*8 + q4][lane] float4, q4 = 4 consecutive registers of
+// the lane's 32-register result (block b = q4/4, regs 4*(q4%4)..+3) — lane-contiguous 1-KB stores.

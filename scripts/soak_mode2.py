@@ -22,11 +22,16 @@ def main():
     ap.add_argument("--repeats", type=int, default=50)
     ap.add_argument("--mode", type=int, default=2)
     ap.add_argument("--views", type=int, default=3)
+    ap.add_argument("--lib", default="", help="an experimental build of the library (code-placement variants) instead of the product one")
+    ap.add_argument("--mask", default="dense")
     args = ap.parse_args()
+    from keypointnerf_amd import lib as kl
+    if args.lib:
+        kl._default = kl.KpnLibrary(args.lib)
     from keypointnerf_amd import ops
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
     dev = torch.device("cuda", 0)
-    sc = to_device(make_scene(n_views=args.views, src_hw=(256, 256), tar_hw=(64, 64), mask="dense", seed=1), dev)
+    sc = to_device(make_scene(n_views=args.views, src_hw=(256, 256), tar_hw=(64, 64), mask=args.mask, seed=1), dev)
     w = ops.PackedWeights(random_hotpath_state_dict(seed=3), device=dev)
     ps = ops.PreparedScene(sc["img"], sc["cam"], sc["feat_geo"], sc["feat_tex"], sc["sp_data"], sc["src_foreground_mask"])
     lo, hi = sc["bounds"].reshape(2, 3)[0], sc["bounds"].reshape(2, 3)[1]
@@ -51,7 +56,7 @@ def main():
         worst = max(worst, d)
     torch.cuda.synchronize()
     ops.set_geo_rows_mode(0)
-    print(json.dumps({"mode": args.mode, "points": args.points, "valid_points": n_valid, "views": args.views, "repeats": args.repeats,
+    print(json.dumps({"lib": os.path.basename(args.lib) or "product", "mask": args.mask, "mode": args.mode, "points": args.points, "valid_points": n_valid, "views": args.views, "repeats": args.repeats,
                       "row_evaluations": n_valid * args.views * (args.repeats + 1), "points_off_vs_fp32_mfma": off,
                       "max_abs_vs_fp32_mfma": float((first - ref).abs().max()), "differing_points_total": differing,
                       "differing_points_worst_repeat": worst, "seconds": time.time() - t0}))
