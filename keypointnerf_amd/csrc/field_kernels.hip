@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
                 const float4 f0 = make_float4(0.1f, -0.2f, 0.3f, 0.05f * (float)g), f1 = make_float4(-0.1f, 0.2f, 0.15f, -0.05f * (float)h);
                 (void)g0; (void)tp;
 #else
-                const float4 f0 = kpn_tap4(g0, 64, 32 * h + 8 * g, tp), f1 = kpn_tap4(g0, 64, 32 * h + 8 * g + 4, tp);
+                const float4 f0 = kpn_tap4(g0, 64, 16 * g + 8 * h, tp), f1 = kpn_tap4(g0, 64, 16 * g + 8 * h + 4, tp);
 #endif
                 x[0] = f0.x; x[1] = f0.y; x[2] = f0.z; x[3] = f0.w; x[4] = f1.x; x[5] = f1.y; x[6] = f1.z; x[7] = f1.w;
             }, a0);

@@ -30,6 +30,9 @@
 #ifndef KPN_H2_GV
 #define KPN_H2_GV 5
 #endif
+#ifndef KPN_H2_LOOKAHEAD
+#define KPN_H2_LOOKAHEAD true   // the next layer's step-0 operands are produced under the last step
+#endif
 #ifndef KPN_H2_L0_STEPS
 #define KPN_H2_L0_STEPS 16   // timing experiments shorten the chain (wrong results)
 #endif
@@ -48,20 +51,87 @@ __device__ __forceinline__ float kpn_h2_softplus100(float x) {
     return x > 0.2f ? x : sp;
 #endif
 }
+// Empty volatile asm statements keep their program order and anchor the (side-effect free) MFMAs and VALU slices between the
+// scheduling barriers: without them instruction selection is free to sink a whole layer's MFMAs below all of its slices —
+// it did, for layers1.1 — and the barriers then fence nothing.  Accumulators live in AGPRs ("a"), the rest in VGPRs.
+#ifdef KPN_SIMT_EMU
+#define KPN_H2_PIN_ACC(v) ((void)0)
+#define KPN_H2_PIN(v) ((void)0)
+#else
+#define KPN_H2_PIN_ACC(v) asm volatile("" : "+a"(v))
+#define KPN_H2_PIN(v) asm volatile("" : "+v"(v))
+#endif
 constexpr int kpn_h2_pa(int pr) { return pr == 2 || pr == 3 ? 1 : (pr == 5 ? 2 : 0); }   // A piece of product pr: h h m m h l
 constexpr int kpn_h2_pb(int pr) { return pr == 1 || pr == 3 ? 1 : (pr == 4 ? 2 : 0); }   // B piece:                h m h m l h
 
-// val_fn(kpn_ic<step>, kpn_ic<tile>, kpn_ic<e>) -> the value this lane supplies at K slot e of the step for the tile;
-// hook_fn(kpn_ic<step>, kpn_ic<tile>): called once per (step, tile) two steps ahead of the step it names, after the last
-// value of step - 1 has been produced (memory loads whose data val_fn(step, ...) consumes are issued here).
-template <int KS16, int NOB, class ValFn, class HookFn>
-__device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg, int lane, ValFn&& val_fn, HookFn&& hook_fn,
-                                                  kpn_f32x16 (&acc)[2][NOB]) {
+// ---- staged production of one operand pair (two fp32 values -> three bf16 pieces each), in SIX slices of 3-5 instructions.
+// With ACT the values go through Softplus(beta 100, threshold 20 taken on x itself: x > 0.2) first; its two transcendentals
+// (8 issue cycles each against 4.4 of a plain VALU instruction: scripts/mfma16_filler_probe.hip) land in different slices:
+//   0: read x0 x1, scale both, exp x0        1: exp x1, 1 + e0, log, 1 + e1       2: log, scale both, select x0
+//   3: select x1, hi piece, residual 0       4: residual 1, mid piece, residual 0  5: residual 1, lo piece
+// Without ACT: 0: x0 = v0()   1: x1 = v1()   2: -   3..5 as above.
+struct kpn_h2_pair { float x0, x1, u0, u1; kpn_bf16_t h0, h1; };
+template <bool ACT, int Q, int J, class V0, class V1>
+__device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_bf16x8 (&dst)[3], V0&& v0, V1&& v1) {
+    if constexpr (Q == 0) {
+        p.x0 = v0();
+        if constexpr (ACT) {
+            p.x1 = v1();
+            p.u0 = p.x0 * 144.269504088896341f; p.u1 = p.x1 * 144.269504088896341f;
+            p.u0 = kpn_exp2(p.u0);
+        }
+    } else if constexpr (Q == 1) {
+        if constexpr (ACT) { p.u1 = kpn_exp2(p.u1); p.u0 = kpn_log2(1.0f + p.u0); p.u1 = 1.0f + p.u1; }
+        else p.x1 = v1();
+    } else if constexpr (Q == 2) {
+        if constexpr (ACT) {
+            p.u1 = kpn_log2(p.u1);
+            p.u0 *= 6.93147180559945309e-3f; p.u1 *= 6.93147180559945309e-3f;   // ln2 / 100
+#ifndef KPN_ABLATE_ACT
+            p.x0 = p.x0 > 0.2f ? p.x0 : p.u0;
+#endif
+        }
+    } else if constexpr (Q == 3) {
+#ifndef KPN_ABLATE_ACT
+        if constexpr (ACT) p.x1 = p.x1 > 0.2f ? p.x1 : p.u1;
+#endif
+        p.h0 = kpn_to_bf(p.x0); p.h1 = kpn_to_bf(p.x1);
+        dst[0][2 * J] = p.h0; dst[0][2 * J + 1] = p.h1;
+        p.x0 = p.x0 - kpn_bf_to_f(p.h0);
+    } else if constexpr (Q == 4) {
+        p.x1 = p.x1 - kpn_bf_to_f(p.h1);
+        p.h0 = kpn_to_bf(p.x0); p.h1 = kpn_to_bf(p.x1);
+        dst[1][2 * J] = p.h0; dst[1][2 * J + 1] = p.h1;
+        p.x0 = p.x0 - kpn_bf_to_f(p.h0);
+    } else {
+        p.x1 = p.x1 - kpn_bf_to_f(p.h1);
+        dst[2][2 * J] = kpn_to_bf(p.x0); dst[2][2 * J + 1] = kpn_to_bf(p.x1);
+    }
+    if constexpr (Q < 5) { KPN_H2_PIN(p.x0); KPN_H2_PIN(p.x1); }
+    if constexpr (ACT && Q < 3) { KPN_H2_PIN(p.u0); KPN_H2_PIN(p.u1); }
+}
+
+// One Linear layer for two tiles.  The instruction stream is laid out by hand: every MFMA is followed by one slice (NOB = 4;
+// two slices for NOB = 2) of the work that produces the NEXT step's B operands and by a scheduling barrier.
+//   val_fn(kpn_ic<step>, kpn_ic<tile>, kpn_ic<e>)   the value at K slot e (the pre-activation for steps < ACT)
+//   stage_fn(kpn_ic<step>, kpn_ic<tile>, kpn_ic<j>, kpn_ic<q>)   q = 0..2, steps >= ACT only: extra work in the slices of pair j
+//            that are nearly empty without an activation (look-ahead computations, loads for later steps)
+//   tail_fn(kpn_ic<m>)   after MFMA m of the LAST step, which has no operands of its own layer left to produce
+//   HAVE0: the operands of step 0 arrive in x0 (produced under the previous layer's last step) instead of being produced
+//          in a prologue that nothing hides;  NEXT: produce the next layer's step-0 operands (next_fn(kpn_ic<tile>, kpn_ic<e>),
+//          through the activation) into xn under the second half of the last step — the next layer's step 0 reads output
+//          block 0 only, whose accumulators are final once the first half (blocks 0 and 1) has been issued.
+template <int KS16, int NOB, int ACT, bool HAVE0, bool NEXT, class ValFn, class StageFn, class TailFn, class NextFn>
+__device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg, int lane, ValFn&& val_fn, StageFn&& stage_fn,
+                                                  TailFn&& tail_fn, NextFn&& next_fn, kpn_f32x16 (&acc)[2][NOB],
+                                                  kpn_bf16x8 (&x0)[2][3], kpn_bf16x8 (&xn)[2][3]) {
     static_assert(NOB == 4 || NOB == 2, "6 or 3 MFMAs per operand pair");
+    static_assert(!NEXT || NOB == 4, "the look-ahead needs blocks 0/1 in the first half of a step");
     constexpr int H0 = NOB / 2, H1 = NOB - H0;
     constexpr int MF = 12 * NOB, PP = MF / 8;
     kpn_bf16x8 xp[2][2][3];                              // [buffer][tile][piece]
     kpn_bf16x8 wa[3][H0], wb[3][H1];                     // the A pieces of the two halves of the output blocks
+    kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, kpn_to_bf(0.f), kpn_to_bf(0.f)};
     auto load_half = [&](int s, int ob0, int n, auto& w) {
         // a half's pieces are contiguous ([step][block][piece][lane]): one scalar base in its middle, immediate offsets
         // of -3..+2 KB (the 13-bit signed range of global_load), the lane offset in one register for the whole kernel
@@ -82,94 +152,72 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     auto mfma = [&](auto mi, const kpn_bf16x8 (&x)[2][3]) {
         constexpr int m = decltype(mi)::value;
         if constexpr (m < 12 * H0) {
-            constexpr int pr = m / (2 * H0), k = (m / 2) % H0, t = m % 2;
-            acc[t][k] = KPN_MFMA16(wa[kpn_h2_pa(pr)][k], x[t][kpn_h2_pb(pr)], acc[t][k]);
+            constexpr int prd = m / (2 * H0), k = (m / 2) % H0, t = m % 2;
+            acc[t][k] = KPN_MFMA16(wa[kpn_h2_pa(prd)][k], x[t][kpn_h2_pb(prd)], acc[t][k]);
+            KPN_H2_PIN_ACC(acc[t][k]);
         } else {
-            constexpr int mm = m - 12 * H0, pr = mm / (2 * H1), k = (mm / 2) % H1, t = mm % 2;
-            acc[t][H0 + k] = KPN_MFMA16(wb[kpn_h2_pa(pr)][k], x[t][kpn_h2_pb(pr)], acc[t][H0 + k]);
+            constexpr int mm = m - 12 * H0, prd = mm / (2 * H1), k = (mm / 2) % H1, t = mm % 2;
+            acc[t][H0 + k] = KPN_MFMA16(wb[kpn_h2_pa(prd)][k], x[t][kpn_h2_pb(prd)], acc[t][H0 + k]);
+            KPN_H2_PIN_ACC(acc[t][H0 + k]);
         }
     };
-    // operand pair j (values 2j, 2j+1) of tile t of step sn -> buffer b: value, three-way split (residuals exact in fp32)
-    auto produce = [&](auto sn, int b, auto ti, auto ji) {
-        constexpr int t = decltype(ti)::value, j = decltype(ji)::value;
-        const float x0 = val_fn(sn, ti, kpn_ic<2 * j>{}), x1 = val_fn(sn, ti, kpn_ic<2 * j + 1>{});
-        const kpn_bf16_t h0 = kpn_to_bf(x0), h1 = kpn_to_bf(x1);
-        const float p0 = x0 - kpn_bf_to_f(h0), p1 = x1 - kpn_bf_to_f(h1);
-#ifdef KPN_DBG_H2_NOSPLIT   // timing experiment (wrong results): the three pieces are the same register
-        xp[b][t][0][2 * j] = h0; xp[b][t][0][2 * j + 1] = h1;
-        xp[b][t][1][2 * j] = h0; xp[b][t][1][2 * j + 1] = h1;
-        xp[b][t][2][2 * j] = h0; xp[b][t][2][2 * j + 1] = h1;
-        (void)p0; (void)p1;
-#else
-        const kpn_bf16_t m0 = kpn_to_bf(p0), m1 = kpn_to_bf(p1);
-        xp[b][t][0][2 * j] = h0; xp[b][t][0][2 * j + 1] = h1;
-        xp[b][t][1][2 * j] = m0; xp[b][t][1][2 * j + 1] = m1;
-        xp[b][t][2][2 * j] = kpn_to_bf(p0 - kpn_bf_to_f(m0)); xp[b][t][2][2 * j + 1] = kpn_to_bf(p1 - kpn_bf_to_f(m1));
-#endif
+    // slice q of pair j of tile t of step sn -> buffer b
+    auto slice = [&](auto sn, int b, auto ti, auto ji, auto qi) {
+        constexpr int t = decltype(ti)::value, j = decltype(ji)::value, q = decltype(qi)::value;
+        constexpr bool act = decltype(sn)::value < ACT;
+        if constexpr (!act && q < 3) stage_fn(sn, ti, ji, qi);
+        kpn_h2_slice<act, q, j>(pr, xp[b][t], [&]() { return val_fn(sn, ti, kpn_ic<2 * j>{}); }, [&]() { return val_fn(sn, ti, kpn_ic<2 * j + 1>{}); });
     };
-    // ---- prologue: the weights of step 0 fly while its operands are produced (nothing to hide them under) ----
     load_half(0, 0, H0, wa);
     load_half(0, H0, H1, wb);
-    hook_fn(kpn_ic<0>{}, kpn_ic<0>{}); hook_fn(kpn_ic<0>{}, kpn_ic<1>{});
-    if constexpr (KS16 > 1) { hook_fn(kpn_ic<1>{}, kpn_ic<0>{}); hook_fn(kpn_ic<1>{}, kpn_ic<1>{}); }
-    kpn_static_for<0, 4>([&](auto ji) {
-        produce(kpn_ic<0>{}, 0, kpn_ic<0>{}, ji);
-        produce(kpn_ic<0>{}, 0, kpn_ic<1>{}, ji);
-    });
+    if constexpr (HAVE0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) xp[0][t][pc] = x0[t][pc];
+    } else {   // prologue: nothing to hide the production of step 0 under
+        kpn_static_for<0, 8>([&](auto pi) {
+            constexpr int t = decltype(pi)::value % 2, j = decltype(pi)::value / 2;
+            kpn_static_for<0, 6>([&](auto qi) { slice(kpn_ic<0>{}, 0, kpn_ic<t>{}, kpn_ic<j>{}, qi); });
+        });
+    }
     KPN_SCHED_BARRIER();
-    // One scheduling region per quarter step: MF/4 MFMAs and the production of operand pair j of BOTH tiles for the next step —
-    // four independent dependency chains (a lone chain of dependent VALU instructions exposes the ALU latency when no other
-    // wave shares the SIMD), spread over the MFMAs by the group pattern; nothing crosses a region's end.
     kpn_static_for<0, KS16>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int cur = s & 1, nxt = cur ^ 1;
-#if KPN_H2_REGIONS == 8
-        // one region per operand pair: MF/8 MFMAs, each followed by its share of the pair's VALU work (group pattern)
-        kpn_static_for<0, 8>([&](auto ri) {
-            constexpr int r = decltype(ri)::value, t = r % 2, j = r / 2;
-            if constexpr (s + 1 < KS16) produce(kpn_ic<s + 1>{}, nxt, kpn_ic<t>{}, kpn_ic<j>{});
-            kpn_static_for<r * (MF / 8), (r + 1) * (MF / 8)>([&](auto mi) {
-                constexpr int m = decltype(mi)::value;
-                mfma(mi, xp[cur]);
-                if constexpr (s + 1 < KS16 && m == 12 * H0 - 1) load_half(s + 1, 0, H0, wa);
-                if constexpr (s + 1 < KS16 && m == MF - 1) load_half(s + 1, H0, H1, wb);
-            });
-            if constexpr (s + 2 < KS16 && r == 7) { hook_fn(kpn_ic<s + 2>{}, kpn_ic<0>{}); hook_fn(kpn_ic<s + 2>{}, kpn_ic<1>{}); }
+        kpn_static_for<0, MF>([&](auto mi) {
+            constexpr int m = decltype(mi)::value;
+            mfma(mi, xp[cur]);
             if constexpr (s + 1 < KS16) {
-#pragma unroll
-                for (int i = 0; i < MF / 8; ++i) {
-                    KPN_SCHED_GROUP(0x008, 1);
-                    KPN_SCHED_GROUP(0x002, NOB == 4 ? KPN_H2_GV : 2 * KPN_H2_GV);
+                constexpr int pair = m / PP, t = pair % 2, j = pair / 2, q = m % PP;
+                using SN = kpn_ic<s + 1>; using TI = kpn_ic<t>; using JI = kpn_ic<j>;
+                if constexpr (PP == 6) slice(SN{}, nxt, TI{}, JI{}, kpn_ic<q>{});
+                else { slice(SN{}, nxt, TI{}, JI{}, kpn_ic<2 * q>{}); slice(SN{}, nxt, TI{}, JI{}, kpn_ic<2 * q + 1>{}); }
+                // each half's weight registers are reloaded right after that half's last MFMA has been issued (an MFMA
+                // captures its operands at issue: scripts/mfma16_war_probe.hip)
+                if constexpr (m == 12 * H0 - 1) load_half(s + 1, 0, H0, wa);
+                if constexpr (m == MF - 1) load_half(s + 1, H0, H1, wb);
+            } else {
+                tail_fn(mi);
+                if constexpr (NEXT && m >= MF / 2) {      // two slices of the next layer's step 0 per MFMA of the second half
+                    constexpr int i = m - MF / 2, pair = i / 3, t = pair % 2, j = pair / 2, q = 2 * (i % 3);
+                    auto v0 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j>{}); };
+                    auto v1 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j + 1>{}); };
+                    kpn_h2_slice<true, q, j>(pr, xn[t], v0, v1);
+                    kpn_h2_slice<true, q + 1, j>(pr, xn[t], v0, v1);
                 }
             }
             KPN_SCHED_BARRIER();
         });
-#else
-        constexpr int RG = KPN_H2_REGIONS;                 // scheduling regions per step
-        kpn_static_for<0, RG>([&](auto ri) {
-            constexpr int r = decltype(ri)::value;
-            constexpr int j0 = r * (4 / RG), j1 = (r + 1) * (4 / RG);
-            if constexpr (s + 1 < KS16) {
-                kpn_static_for<j0, j1>([&](auto ji) {
-                    produce(kpn_ic<s + 1>{}, nxt, kpn_ic<0>{}, ji);
-                    produce(kpn_ic<s + 1>{}, nxt, kpn_ic<1>{}, ji);
-                });
-            }
-            kpn_static_for<j0 * (MF / 4), j1 * (MF / 4)>([&](auto mi) {
-                constexpr int m = decltype(mi)::value;
-                mfma(mi, xp[cur]);
-                // each half's weight registers are reloaded right after that half's last MFMA has been issued (an MFMA
-                // captures its operands at issue: scripts/mfma16_war_probe.hip)
-                if constexpr (s + 1 < KS16 && m == 12 * H0 - 1) load_half(s + 1, 0, H0, wa);
-                if constexpr (s + 1 < KS16 && m == MF - 1) load_half(s + 1, H0, H1, wb);
-            });
-            if constexpr (s + 2 < KS16 && r == RG - 1) { hook_fn(kpn_ic<s + 2>{}, kpn_ic<0>{}); hook_fn(kpn_ic<s + 2>{}, kpn_ic<1>{}); }
-            KPN_SCHED_BARRIER();
-        });
-#endif
     });
 }
 
+#ifdef KPN_H2_TIMING   // debug builds: cycles (s_memtime) per phase of the work items of one wave, summed: prologue, 4 layers, epilogue
+__device__ unsigned long long kpn_h2_cycles[8];
+#define KPN_H2_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 3 && threadIdx.x == 64) atomicAdd(&kpn_h2_cycles[i], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define KPN_H2_STAMP(i) ((void)0)
+#endif
 #ifndef KPN_SIMT_EMU
 #define KPN_H2_BOUNDS __launch_bounds__(256, 1)
 #else
@@ -191,6 +239,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
     const int nbt = t1 - t0;                               // tiles of this batch
     const int nwork = ((nbt + 1) >> 1) * sc.V;
     const float pe_pi = 3.14159274101257324f;
+    const float neg_inv_two_sigma2 = -1.0f / sc.two_sigma2;   // exp(-d2 / 2 sigma^2) as one multiply per keypoint
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
     {
         const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
@@ -200,8 +249,11 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         }
     }
     __syncthreads();
-    auto no_hook = [](auto, auto) {};
+#ifdef KPN_H2_TIMING
+    unsigned long long stamp_ = clock64();
+#endif
     for (;;) {
+        KPN_H2_STAMP(6);
         int wi = 0;
         if (lane == 0) wi = atomicAdd(tickets + 0, 1);
         wi = __shfl(wi, 0);
@@ -234,11 +286,13 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
             }
             continue;
         }
+        KPN_H2_STAMP(0);
         // ---- layers1.0 as ONE 16-step chain (HSEG_G1_0A and HSEG_G1_0B are adjacent, same step size): steps 0-11 one
         //      keypoint each (7 encoding values + a zero slot), steps 12-15 eight geo0 channels each ----
-        kpn_f32x16 a0[2][4];
+        static_assert(kpn_hseg_off(HSEG_G1_0B) == kpn_hseg_off(HSEG_G1_0A) + 12 * kpn_hseg_step_floats(HSEG_G1_0A), "adjacent segments");
+        kpn_f32x16 a0[2][4], a1[2][4];
+        kpn_bf16x8 xa[2][3], xb[2][3];                      // step-0 operands handed from one layer to the next
         {
-            static_assert(kpn_hseg_off(HSEG_G1_0B) == kpn_hseg_off(HSEG_G1_0A) + 12 * kpn_hseg_step_floats(HSEG_G1_0A), "adjacent segments");
             const float* E = tb + KPN_TBL_EXT;
             float cx[2], cy[2], cz[2];
             kpn_taps tp[2];
@@ -249,112 +303,190 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
                 cz[t] = RADD(kpn_dot3(P[t][0], P[t][1], P[t][2], E[8], E[9], E[10]), E[11]);
                 kpn_load_bias<4>(bias_s[0], h, a0[t]);
                 tp[t] = kpn_make_taps(q[t].xn, q[t].yn, sc.g0h, sc.g0w);
+#ifdef KPN_DBG_H2_SAMETAP   // timing experiment (wrong results): every lane gathers the same texels -> two cache lines per load
+                tp[t].o00 = 0; tp[t].o01 = 1; tp[t].o10 = 2; tp[t].o11 = 3;
+#endif
             }
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
-            const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64 + 32 * h;
-            float pw[2], ps1[2], pc1[2], ps2[2], pc2[2];   // the keypoint in flight: weight, sin/cos of pi z and of 2 pi z
-            float4 raw[2][8], gf[2];                       // geo0: the four taps of two float4 of channels; the blended float4
-            kpn_mfma16_layer2<KPN_H2_L0_STEPS, 4>(wp + kpn_hseg_off(HSEG_G1_0A), lane, [&](auto si, auto ti, auto ei) -> float {
-                constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
-                if constexpr (s < 12) {
-                    if constexpr (e == 0) {
-                        const float dx = RSUB(cx[t], kc[s * 3 + 0]), dy = RSUB(cy[t], kc[s * 3 + 1]), dz = RSUB(cz[t], kc[s * 3 + 2]);
-                        const float d2 = RADD(RADD(RMUL(dx, dx), RMUL(dy, dy)), RMUL(dz, dz));
-                        pw[t] = kpn_fast_exp(-d2 / sc.two_sigma2);
-                        kpn_sincos(RMUL(dz, pe_pi), ps1[t], pc1[t]);
-                        return dz * pw[t];
-                    } else if constexpr (e == 1) { return ps1[t] * pw[t];
-                    } else if constexpr (e == 2) { return pc1[t] * pw[t];
-                    } else if constexpr (e == 3) {
-                        ps2[t] = 2.0f * ps1[t] * pc1[t]; pc2[t] = 1.0f - 2.0f * ps1[t] * ps1[t];
-                        return ps2[t] * pw[t];
-                    } else if constexpr (e == 4) { return pc2[t] * pw[t];
-                    } else if constexpr (e == 5) { return (2.0f * ps2[t] * pc2[t]) * pw[t];
-                    } else if constexpr (e == 6) { return (1.0f - 2.0f * ps2[t] * ps2[t]) * pw[t];
-                    } else { return 0.0f; }
+            const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64 + 8 * h;
+            // The keypoint encoding of step n (weight w = exp(-d^2 / 2 sigma^2), sin/cos of pi z, doubled twice) is computed ONE
+            // STEP AHEAD in ten small stages that ride in the nearly empty slices of the step before (an encoding step has no
+            // activation to compute): [parity of the step][tile] holds the finished dz, w, sin, cos.
+            float fdz[2][2], fw[2][2], fs1[2][2], fc1[2][2];
+            float kcv[2][3] = {{kc[0], kc[1], kc[2]}, {kc[3], kc[4], kc[5]}};   // keypoints of steps 0 and 1 (this half's 12)
+            float tdx[2], tdy[2], ty[2], targ[2], tk[2], tr[2], tr2[2], tsp[2], tcp[2], tg[2], ts2[2], tc2[2];
+            float4 raw[2][8];                               // geo0: the four taps of two float4 of channels
+            auto pe_stage = [&](auto ni, auto ti, auto gi) {   // stage gi (0..9) of the encoding of keypoint step ni, tile ti
+                constexpr int n = decltype(ni)::value, t = decltype(ti)::value, g = decltype(gi)::value, b = n & 1;
+                if constexpr (g == 0) {
+                    // the keypoint's camera-frame coordinates were fetched two steps ago (a load followed by its use costs a full
+                    // L2 round trip when no other wave shares the SIMD); tile 1 is the last user: it refills the slot for step n+2
+                    tdx[t] = RSUB(cx[t], kcv[b][0]); tdy[t] = RSUB(cy[t], kcv[b][1]); fdz[b][t] = RSUB(cz[t], kcv[b][2]);
+                    ty[t] = RMUL(fdz[b][t], pe_pi);
+                    if constexpr (t == 1 && n + 2 < 12) { kcv[b][0] = kc[(n + 2) * 3 + 0]; kcv[b][1] = kc[(n + 2) * 3 + 1]; kcv[b][2] = kc[(n + 2) * 3 + 2]; }
+                } else if constexpr (g == 1) {
+                    const float d2 = RADD(RADD(RMUL(tdx[t], tdx[t]), RMUL(tdy[t], tdy[t])), RMUL(fdz[b][t], fdz[b][t]));
+                    targ[t] = d2 * neg_inv_two_sigma2;
+                } else if constexpr (g == 2) {
+                    fw[b][t] = kpn_fast_exp(targ[t]);
+                    tk[t] = rintf(ty[t] * 0.636619772367581343f);
+                } else if constexpr (g == 3) {              // Cody-Waite reduction by pi/2 (kpn_sincos, kpn_device.h)
+                    float r = fmaf(tk[t], -1.5703125f, ty[t]);
+                    r = fmaf(tk[t], -4.837512969970703125e-4f, r);
+                    tr[t] = fmaf(tk[t], -7.54978995489188216e-8f, r);
+                    tr2[t] = tr[t] * tr[t];
+                } else if constexpr (g == 4) {
+                    tsp[t] = fmaf(tr2[t], fmaf(tr2[t], -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+                    tg[t] = tr2[t] * tr[t];
+                } else if constexpr (g == 5) {
+                    tsp[t] = fmaf(tg[t], tsp[t], tr[t]);
+                    tcp[t] = fmaf(tr2[t], fmaf(tr2[t], 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+                } else if constexpr (g == 6) {
+                    tcp[t] = fmaf(tr2[t] * tr2[t], tcp[t], fmaf(tr2[t], -0.5f, 1.0f));
+                } else if constexpr (g == 7) {              // quadrant: swap for odd k
+                    const int qd = (int)tk[t];
+                    const float ss = (qd & 1) ? tcp[t] : tsp[t], cc = (qd & 1) ? tsp[t] : tcp[t];
+                    tsp[t] = ss; tcp[t] = cc;
+                } else if constexpr (g == 8) {
+                    const int qd = (int)tk[t];
+                    fs1[b][t] = (qd & 2) ? -tsp[t] : tsp[t];
                 } else {
-                    if constexpr (e % 4 == 0) {               // blend one float4 of channels: same tap order as ATen (nw, ne, sw, se)
-                        const float4 a = raw[t][e], b = raw[t][e + 1], c = raw[t][e + 2], d = raw[t][e + 3];
+                    const int qd = (int)tk[t];
+                    fc1[b][t] = ((qd + 1) & 2) ? -tcp[t] : tcp[t];
+                }
+            };
+            auto geo_loads = [&](auto si, auto ti, auto fi) {   // the taps of float4 f (0/1) of geo step s: channels 16(s-12) + 8h + 4f ..
+                constexpr int s = decltype(si)::value, t = decltype(ti)::value, f = decltype(fi)::value;
+                const float* gp = g0 + 16 * (s - 12) + 4 * f;
+                const kpn_taps& w = tp[t];
+                raw[t][4 * f + 0] = *reinterpret_cast<const float4*>(gp + (size_t)w.o00 * 64);
+                raw[t][4 * f + 1] = *reinterpret_cast<const float4*>(gp + (size_t)w.o01 * 64);
+                raw[t][4 * f + 2] = *reinterpret_cast<const float4*>(gp + (size_t)w.o10 * 64);
+                raw[t][4 * f + 3] = *reinterpret_cast<const float4*>(gp + (size_t)w.o11 * 64);
+            };
+            // prologue of the work item: the encoding of step 0 (that of step 1 rides in the production of step 0's operands)
+            kpn_static_for<0, 10>([&](auto gi) {
+                pe_stage(kpn_ic<0>{}, kpn_ic<0>{}, gi); pe_stage(kpn_ic<0>{}, kpn_ic<1>{}, gi);
+            });
+            kpn_mfma16_layer2<KPN_H2_L0_STEPS, 4, 0, false, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_0A), lane,
+                [&](auto si, auto ti, auto ei) -> float {
+                    constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value, b = s & 1;
+                    if constexpr (s < 12) {
+                        if constexpr (e == 0) { return fdz[b][t] * fw[b][t];
+                        } else if constexpr (e == 1) { return fs1[b][t] * fw[b][t];
+                        } else if constexpr (e == 2) { return fc1[b][t] * fw[b][t];
+                        } else if constexpr (e == 3) {
+                            ts2[t] = 2.0f * fs1[b][t] * fc1[b][t]; tc2[t] = 1.0f - 2.0f * fs1[b][t] * fs1[b][t];
+                            return ts2[t] * fw[b][t];
+                        } else if constexpr (e == 4) { return tc2[t] * fw[b][t];
+                        } else if constexpr (e == 5) { return (2.0f * ts2[t] * tc2[t]) * fw[b][t];
+                        } else if constexpr (e == 6) { return (1.0f - 2.0f * ts2[t] * ts2[t]) * fw[b][t];
+                        } else { return 0.0f; }
+                    } else {                                   // one blended channel: same tap order as ATen (nw, ne, sw, se)
+                        constexpr int f = e / 4, c = e % 4;
                         const kpn_taps& w = tp[t];
-                        gf[t].x = RADD(RADD(RADD(RMUL(a.x, w.w00), RMUL(b.x, w.w01)), RMUL(c.x, w.w10)), RMUL(d.x, w.w11));
-                        gf[t].y = RADD(RADD(RADD(RMUL(a.y, w.w00), RMUL(b.y, w.w01)), RMUL(c.y, w.w10)), RMUL(d.y, w.w11));
-                        gf[t].z = RADD(RADD(RADD(RMUL(a.z, w.w00), RMUL(b.z, w.w01)), RMUL(c.z, w.w10)), RMUL(d.z, w.w11));
-                        gf[t].w = RADD(RADD(RADD(RMUL(a.w, w.w00), RMUL(b.w, w.w01)), RMUL(c.w, w.w10)), RMUL(d.w, w.w11));
-                        return gf[t].x;
-                    } else if constexpr (e % 4 == 1) { return gf[t].y;
-                    } else if constexpr (e % 4 == 2) { return gf[t].z;
-                    } else { return gf[t].w; }
-                }
-            }, [&](auto si, auto ti) {                        // the taps of geo step s - 12: channels 32h + 8(s-12) .. +7
-                constexpr int s = decltype(si)::value, t = decltype(ti)::value;
-                if constexpr (s >= 12) {
-                    const float* gp = g0 + 8 * (s - 12);
-                    const kpn_taps& w = tp[t];
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        raw[t][4 * f + 0] = *reinterpret_cast<const float4*>(gp + (size_t)w.o00 * 64 + 4 * f);
-                        raw[t][4 * f + 1] = *reinterpret_cast<const float4*>(gp + (size_t)w.o01 * 64 + 4 * f);
-                        raw[t][4 * f + 2] = *reinterpret_cast<const float4*>(gp + (size_t)w.o10 * 64 + 4 * f);
-                        raw[t][4 * f + 3] = *reinterpret_cast<const float4*>(gp + (size_t)w.o11 * 64 + 4 * f);
+                        auto comp = [](const float4& x) { return c == 0 ? x.x : (c == 1 ? x.y : (c == 2 ? x.z : x.w)); };
+                        return RADD(RADD(RADD(RMUL(comp(raw[t][4 * f + 0]), w.w00), RMUL(comp(raw[t][4 * f + 1]), w.w01)),
+                                         RMUL(comp(raw[t][4 * f + 2]), w.w10)), RMUL(comp(raw[t][4 * f + 3]), w.w11));
                     }
-                }
-            }, a0);
+                },
+                [&](auto si, auto ti, auto ji, auto qi) {      // the slices an encoding / geometry step leaves nearly empty
+                    constexpr int s = decltype(si)::value, t = decltype(ti)::value, j = decltype(ji)::value, qq = decltype(qi)::value;
+                    constexpr int g = 3 * j + qq - 2;          // slices (j,q) = (0,2) .. (3,2) -> stages 0 .. 9
+                    if constexpr (s + 1 < 12 && g >= 0) pe_stage(kpn_ic<s + 1>{}, ti, kpn_ic<g>{});
+                    // geo step s+1: its first float4 of channels may be fetched once values 0..3 of step s exist, the second
+                    // after values 4..7
+                    if constexpr (s + 1 > 12 && s + 1 < 16 && qq == 2 && j == 1) geo_loads(kpn_ic<s + 1>{}, ti, kpn_ic<0>{});
+                    if constexpr (s + 1 > 12 && s + 1 < 16 && qq == 2 && j == 3) geo_loads(kpn_ic<s + 1>{}, ti, kpn_ic<1>{});
+                    // the FIRST geometry step's taps are gathers from the feature maps (HBM / far L2: several thousand cycles) —
+                    // fetched nine steps ahead, while the encoding steps leave the registers free; the later geometry steps read
+                    // other 32-byte pieces of the same cache lines, which these loads have brought close
+                    if constexpr (s == 3 && qq == 2 && j == 1) geo_loads(kpn_ic<12>{}, ti, kpn_ic<0>{});
+                    if constexpr (s == 3 && qq == 2 && j == 3) geo_loads(kpn_ic<12>{}, ti, kpn_ic<1>{});
+                },
+                [&](auto mi) {                                 // last step of layers1.0: the biases of layers1.1
+                    constexpr int m = decltype(mi)::value;
+                    if constexpr (m < 2) kpn_load_bias<4>(bias_s[1], h, a1[m]);
+                },
+                [&](auto ti, auto ei) -> float { return a0[decltype(ti)::value][0][decltype(ei)::value]; },
+                a0, xa, xb);
         }
+        KPN_H2_STAMP(1);
         // chained step s of a 128-vector: registers 8(s%2)..+7 of block s/2
-        kpn_f32x16 a1[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) kpn_load_bias<4>(bias_s[1], h, a1[t]);
-        kpn_mfma16_layer2<KPN_H2_L1_STEPS, 4>(wp + kpn_hseg_off(HSEG_G1_1), lane, [&](auto si, auto ti, auto ei) -> float {
-            constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
-            return kpn_h2_softplus100(a0[t][s / 2][(s % 2) * 8 + e]);
-        }, no_hook, a1);
         kpn_f32x16 a2[2][4];
-        {
-            float4 f[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const kpn_taps tp = kpn_make_taps(q[t].xn, q[t].yn, sc.g1h, sc.g1w);
-                f[t] = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
-                kpn_load_bias<4>(bias_s[2], h, a2[t]);
-            }
-            kpn_mfma16_layer2<9, 4>(wp + kpn_hseg_off(HSEG_G1_2), lane, [&](auto si, auto ti, auto ei) -> float {
+        float4 hraw[2][4];                                  // the four taps of the 4 hd channels of this half (layers1.2, step 8)
+        float hd[2][4];
+        kpn_taps tp1[2];
+        kpn_mfma16_layer2<KPN_H2_L1_STEPS, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_1), lane,
+            [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
-                if constexpr (s < 8) return kpn_h2_softplus100(a1[t][s / 2][(s % 2) * 8 + e]);
-                else if constexpr (e == 0) return f[t].x;
-                else if constexpr (e == 1) return f[t].y;
-                else if constexpr (e == 2) return f[t].z;
-                else if constexpr (e == 3) return f[t].w;
+                return a0[t][s / 2][(s % 2) * 8 + e];
+            },
+            [](auto, auto, auto, auto) {},
+            [&](auto mi) {                                     // last step: biases of layers1.2, the hd taps
+                constexpr int m = decltype(mi)::value;
+                if constexpr (m < 2) {
+                    kpn_load_bias<4>(bias_s[2], h, a2[m]);
+                    tp1[m] = kpn_make_taps(q[m].xn, q[m].yn, sc.g1h, sc.g1w);
+                } else if constexpr (m < 4) {
+                    constexpr int t = m - 2;
+                    const float* gp = sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8 + 4 * h;
+                    hraw[t][0] = *reinterpret_cast<const float4*>(gp + (size_t)tp1[t].o00 * 8);
+                    hraw[t][1] = *reinterpret_cast<const float4*>(gp + (size_t)tp1[t].o01 * 8);
+                    hraw[t][2] = *reinterpret_cast<const float4*>(gp + (size_t)tp1[t].o10 * 8);
+                    hraw[t][3] = *reinterpret_cast<const float4*>(gp + (size_t)tp1[t].o11 * 8);
+                } else if constexpr (m >= 20 && m < 22) {
+                    constexpr int t = m - 20;
+                    const kpn_taps& w = tp1[t];
+                    hd[t][0] = RADD(RADD(RADD(RMUL(hraw[t][0].x, w.w00), RMUL(hraw[t][1].x, w.w01)), RMUL(hraw[t][2].x, w.w10)), RMUL(hraw[t][3].x, w.w11));
+                    hd[t][1] = RADD(RADD(RADD(RMUL(hraw[t][0].y, w.w00), RMUL(hraw[t][1].y, w.w01)), RMUL(hraw[t][2].y, w.w10)), RMUL(hraw[t][3].y, w.w11));
+                } else if constexpr (m >= 22 && m < 24) {
+                    constexpr int t = m - 22;
+                    const kpn_taps& w = tp1[t];
+                    hd[t][2] = RADD(RADD(RADD(RMUL(hraw[t][0].z, w.w00), RMUL(hraw[t][1].z, w.w01)), RMUL(hraw[t][2].z, w.w10)), RMUL(hraw[t][3].z, w.w11));
+                    hd[t][3] = RADD(RADD(RADD(RMUL(hraw[t][0].w, w.w00), RMUL(hraw[t][1].w, w.w01)), RMUL(hraw[t][2].w, w.w10)), RMUL(hraw[t][3].w, w.w11));
+                }
+            },
+            [&](auto ti, auto ei) -> float { return a1[decltype(ti)::value][0][decltype(ei)::value]; },
+            a1, xb, xa);
+        KPN_H2_STAMP(2);
+        kpn_f32x16 acc[2][2];
+        float4 rec0[2], rec1[2];
+        kpn_mfma16_layer2<9, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_2), lane,
+            [&](auto si, auto ti, auto ei) -> float {
+                constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
+                if constexpr (s < 8) return a1[t][s / 2][(s % 2) * 8 + e];
+                else if constexpr (e < 4) return hd[t][e];
                 else return 0.0f;
-            }, no_hook, a2);
-        }
-        {
-            kpn_f32x16 acc[2][2];
-            float4 rec0[2], rec1[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                rec0[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rec1[t] = rec0[t];
-                kpn_load_bias<2>(bias_s[3], h, acc[t]);
-            }
-            kpn_mfma16_layer2<8, 2>(wp + kpn_hseg_off(HSEG_G1_3), lane, [&](auto si, auto ti, auto ei) -> float {
+            },
+            [](auto, auto, auto, auto) {},
+            [&](auto mi) {                                     // last step: biases of layers1.3, the colour head's gather record
+                constexpr int m = decltype(mi)::value;
+                if constexpr (m < 2) kpn_load_bias<2>(bias_s[3], h, acc[m]);
+                else if constexpr (m == 4) kpn_row_record(sc, tb, v, h, q[0], P[0], D[0], rec0[0], rec1[0]);
+                else if constexpr (m == 14) kpn_row_record(sc, tb, v, h, q[1], P[1], D[1], rec0[1], rec1[1]);
+            },
+            [&](auto ti, auto ei) -> float { return a2[decltype(ti)::value][0][decltype(ei)::value]; },
+            a2, xa, xb);
+        KPN_H2_STAMP(3);
+        kpn_mfma16_layer2<8, 2, 8, KPN_H2_LOOKAHEAD, false>(wp + kpn_hseg_off(HSEG_G1_3), lane,
+            [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
-                return kpn_h2_softplus100(a2[t][s / 2][(s % 2) * 8 + e]);
-            }, [&](auto si, auto ti) {                        // the colour head's gather record, under this layer's MFMAs
-                constexpr int s = decltype(si)::value, t = decltype(ti)::value;
-                if constexpr (s == 2) kpn_row_record(sc, tb, v, h, q[t], P[t], D[t], rec0[t], rec1[t]);
-            }, acc);
+                return a2[t][s / 2][(s % 2) * 8 + e];
+            },
+            [](auto, auto, auto, auto) {}, [](auto) {}, [](auto, auto) -> float { return 0.0f; }, acc, xb, xa);
+        KPN_H2_STAMP(4);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t == 1 && !has1) break;
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && !has1) break;
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd)
-                        dst[t][(b * 4 + qd) * 64] =
-                            make_float4(acc[t][b][4 * qd + 0], acc[t][b][4 * qd + 1], acc[t][b][4 * qd + 2], acc[t][b][4 * qd + 3]);
-                dst[t][8 * 64] = rec0[t];
-                dst[t][9 * 64] = rec1[t];
-            }
+                for (int qd = 0; qd < 4; ++qd)
+                    dst[t][(b * 4 + qd) * 64] =
+                        make_float4(acc[t][b][4 * qd + 0], acc[t][b][4 * qd + 1], acc[t][b][4 * qd + 2], acc[t][b][4 * qd + 3]);
+            dst[t][8 * 64] = rec0[t];
+            dst[t][9 * 64] = rec1[t];
         }
     }
 }

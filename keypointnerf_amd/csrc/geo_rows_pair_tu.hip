@@ -13,3 +13,12 @@ extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_geo_ro
     int* tickets, float* xscr, int batch_index, int tiles_cap) {
     KPN_LAUNCH(k_geo_rows_h2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, kpn_batch{batch_index, tiles_cap});
 }
+
+#ifdef KPN_H2_TIMING
+// debug builds only: read (and clear) the per-phase cycle sums of k_geo_rows_h2
+extern "C" int kpn_h2_timing(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kpn_h2_cycles), 64) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kpn_h2_cycles), z, 64) != hipSuccess;
+}
+#endif

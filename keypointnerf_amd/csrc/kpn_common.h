@@ -213,7 +213,7 @@ constexpr int kpn_bwd_end() { return kpn_brow_off(BROW_COUNT); }
 // the B operand supply 8 values, the h = 1 lanes 8 — for chained inputs a lane's registers 8j..8j+7 of block b (step
 // 2b + j), i.e. features 32b + rowmap(8j + e, h).  Stream per step: [ob][piece h,m,l][64 lanes] x 16 B (8 bf16 =
 // A[i = lane&31][k = 8(lane>>5) + e]); the fp32 bias blocks of the forward segments are reused.
-//   HSEG_G1_0A: step j = keypoints j (h=0) and j+12 (h=1): 7 encoding values + 1 pad;  HSEG_G1_0B: 8 geometry channels per half
+//   HSEG_G1_0A: step j = keypoints j (h=0) and j+12 (h=1): 7 encoding values + 1 pad;  HSEG_G1_0B: step s = geometry channels 16 s + 8 h + 0..7
 //   HSEG_G1_2 : 8 chained steps + 1 step with the 4+4 hd channels (+ pads)
 enum { HSEG_G1_0A, HSEG_G1_0B, HSEG_G1_1, HSEG_G1_2, HSEG_G1_3, HSEG_COUNT };
 struct kpn_hseg_shape { int ks16, nob; };

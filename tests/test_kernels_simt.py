@@ -450,8 +450,9 @@ def test_device_weight_packer(env):
 def test_split_bf16_geo_rows(env):
     """k_geo_rows_h (split-bf16 operands on the emulated v_mfma_f32_32x32x16_bf16) vs the reference's recorded query
     outputs and vs the fp32-MFMA kernel: fp32-class (three bf16 pieces, six products).  k_geo_rows_h2 (two tiles per wave,
-    mode 2) feeds every accumulator the same products in the same order: bit-equal to mode 1, with an even and an odd number
-    of tiles (the last pair's second tile is computed and not stored)."""
+    mode 2) feeds every accumulator the same products in the same order (its keypoint weight is one multiply by a reciprocal
+    instead of a division: last-bit differences), with an even and an odd number of tiles (the last pair's second tile is
+    computed and not stored)."""
     lib, packed, wflat = env
     scene, cfg, g = load_case(CASES[0])
     hs = sh.HostScene(lib, scene)
@@ -471,7 +472,7 @@ def test_split_bf16_geo_rows(env):
         assert np.array_equal(v0, v1) and np.array_equal(v0, v2) and v1.sum() == n_valid
         assert np.abs(o1 - ref)[v1].max() < 1e-5
         assert np.abs(o1 - o0)[v1].max() < 5e-6
-        assert np.array_equal(o1, o2)
+        assert np.abs(o2 - ref)[v2].max() < 1e-5 and np.abs(o2 - o1)[v2].max() < 2e-6     # same products; exp(-d2 * (1 / 2 sigma^2))
     assert lib.kpn_set_geo_rows_mode(3) != 0
 
 
