@@ -30,7 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# --geo-rows-mode 1: six bf16 MFMAs (2.5 PFLOP/s dense peak) per fp32 product term set -> fp32-equivalent roof
+# --geo-rows-mode 1 / 2: six bf16 MFMAs (2.5 PFLOP/s dense peak) per fp32 product term set -> fp32-equivalent roof
 BF16_SPLIT_PEAK_TFLOPS = 2500.0 / 6.0
 
 
@@ -52,8 +52,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (dense mask / round-1 scene / training) results")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
-    ap.add_argument("--geo-rows-mode", type=int, default=0, choices=[0, 1, 2],
-                    help="0 = fp32 MFMA (default); 1 = split-bf16 operands on the bf16 MFMA (opt-in, fp32-class results)")
+    ap.add_argument("--geo-rows-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="rows kernel of the field's first MLP: 2 = split-bf16 operands on the bf16 MFMA, two tiles per wave, one wave "
+                         "per SIMD (the library's default: fp32-class results); 0 = fp32 MFMA; 1 = the earlier split-bf16 kernel "
+                         "(experimental, DESIGN.md section 9.2)")
     ap.add_argument("--no-coarse-reuse", action="store_true",
                     help="evaluate the field at all Sc+Sf merged samples in the fine pass, as the reference does (default: the "
                          "coarse samples' values are taken from the coarse pass: bit-identical outputs, Sc+Sf instead of "
@@ -95,7 +97,7 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
                       f"samples/ray, {dt:.1f} s of wall time, C oracle with OpenMP over points on {os.cpu_count()} hardware threads"}
 
 
-def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1):
+def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1, with_kernel=False):
     """ms per frame + valid (point, view) rows per frame of one more workload (secondary results)."""
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
                            scene["src_foreground_mask"])
@@ -115,6 +117,8 @@ def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1):
     L.check(L.kpn_profile_collect(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows)))
     L.check(L.kpn_profile_enable(0))
     del plan, ps
+    if with_kernel:
+        return dt * 1e3, rows.value / steps, ms.value / max(1, launches.value), rows.value * L.kpn_flops_per_row() / max(1e-9, ms.value * 1e-3) / 1e12
     return dt * 1e3, rows.value / steps
 
 
@@ -282,7 +286,9 @@ def main():
             "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.geo_rows_mode == 0 else "f32 (three bf16 pieces per operand, bf16 MFMA)",
+            "vs_baseline": None,
+            "dtype": "f32" if args.geo_rows_mode == 0 else "f32 (dominant kernel: every fp32 operand as three bf16 pieces, six bf16-MFMA products per "
+                                                           "term set, fp32 accumulation: all terms above 2^-24 relative kept; everything else fp32)",
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if (fine and args.views == 3 and args.samples == 64 and res == 512) else 'custom'}: "
                                    f"{res}x{res} novel view, {args.views} source views {res}x{res}, "
@@ -308,7 +314,7 @@ def main():
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "surplus_launches": surplus.value,
-                         "note": "the row scratch between k_geo_rows and k_fuse_color is capped ("
+                         "note": "achieved = algorithmic fp32 FLOP (140,160 per row) / kernel time; in the split-bf16 modes the matrix pipe executes 6 bf16 products per fp32 product term set, so the roof is the dense bf16 peak / 6; the row scratch between the rows kernel and k_fuse_color is capped ("
                                  + f"{L.kpn_row_scratch_cap_bytes() / 2**30:.1f} GiB) and reused by batches of a pass; the worst-case "
                                  "number of batches is launched and the surplus ones return at once (a few us each): "
                                  "`launches` / `avg_launch_ms` cover the launches that processed rows, a rocprofv3 average "
@@ -339,7 +345,16 @@ def main():
                     sec[f"partly_empty_hull_density_bias_{int(db)}"] = {
                         "ms_per_frame": ms2, "ms_per_frame_without_the_zero_density_short_path": ms3,
                         "rays_per_sec": rays_per_step / (ms2 * 1e-3)}
-            if args.views == 3 and args.geo_rows_mode == 0:
+            if args.geo_rows_mode != 0:
+                # the same frame with the fp32-MFMA rows kernel (kpn_set_geo_rows_mode(0)): roof 157.3 TFLOP/s
+                L.check(L.kpn_set_geo_rows_mode(0))
+                ms2, rows2, kms, ktf = time_frames(L, ops, torch, scene, w, res, args.samples, fine, steps=max(2, min(args.steps, 5)), with_kernel=True)
+                L.check(L.kpn_set_geo_rows_mode(args.geo_rows_mode))
+                sec["fp32_mfma_rows_kernel_mode0"] = {"ms_per_frame": ms2, "rays_per_sec": rays_per_step / (ms2 * 1e-3),
+                                                      "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": ktf,
+                                                                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                                   "frac": ktf / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": kms}}
+            if args.views == 3:
                 sec["training_step_configs3"] = time_training(ops, torch, dev, sd)
             line["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only

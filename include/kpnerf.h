@@ -160,11 +160,14 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
                        float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1, float* d_tex,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* Arithmetic of the dominant kernel (MLPUNet.layers1 per (point, view) row):
- *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands);
- *   1 = v_mfma_f32_32x32x16_bf16 with every fp32 operand carried as three bf16 pieces and six products per term set
- *       (all terms above 2^-24 relative: fp32-class results, about twice the matrix rate).
- * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 0). */
+/* Rows kernel of the dominant stage (MLPUNet.layers1 per (point, view) row, reference src/utils.py:691-720):
+ *   2 = v_mfma_f32_32x32x16_bf16 with every fp32 operand carried as three bf16 pieces and six products per term set (all
+ *       terms above 2^-24 relative: fp32-class results), two 32-point tiles per wavefront, one wavefront per SIMD
+ *       (k_geo_rows_h2).  The default: same parity bar as mode 0 against the reference goldens, 1.5x its rate.
+ *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands, k_geo_rows).
+ *   1 = the earlier split-bf16 kernel (one tile per wavefront, two wavefronts per SIMD): experimental, rare wrong
+ *       half-tiles on some builds; kept for comparison.
+ * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 2). */
 int kpn_set_geo_rows_mode(int32_t mode);
 int kpn_get_geo_rows_mode(void);
 

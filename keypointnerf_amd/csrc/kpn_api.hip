@@ -597,10 +597,18 @@ struct ProfState {
 static ProfState g_prof;
 #endif
 
-// 0: fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy)
+// 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, k_geo_rows)
+// 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16, one tile per wave, two waves per SIMD (k_geo_rows_h): experimental,
+//    unexplained rare wrong tiles
+// 2: the same arithmetic with two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): the default — fp32-class results
+//    (every product term above 2^-24 relative is kept), 1.5x the fp32 kernel's rate, soaked over 1.1e11 row evaluations and
+//    twelve code placements without a differing value (profiles/r02_soak_mode2_*.jsonl)
+#ifndef KPN_DEFAULT_GEO_ROWS_MODE
+#define KPN_DEFAULT_GEO_ROWS_MODE 2
+#endif
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
-    if (g_geo_rows_mode < 0) { const char* e = getenv("KPN_GEO_ROWS_MODE"); g_geo_rows_mode = e ? atoi(e) : 0; }
+    if (g_geo_rows_mode < 0) { const char* e = getenv("KPN_GEO_ROWS_MODE"); g_geo_rows_mode = e ? atoi(e) : KPN_DEFAULT_GEO_ROWS_MODE; }
     return g_geo_rows_mode;
 }
 int pair_grid_blocks() {   // k_geo_rows_h2: one 256-thread workgroup per CU = one wave per SIMD

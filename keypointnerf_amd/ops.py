@@ -468,8 +468,9 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
 
 
 def set_geo_rows_mode(mode):
-    """Arithmetic of the dominant kernel (kpn_set_geo_rows_mode): 0 = fp32 MFMA (default), 1 = split-bf16 operands on
-    the bf16 MFMA (three bf16 pieces per fp32 operand, six products: fp32-class results, faster).  Process-wide."""
+    """Rows kernel of the field's first MLP (kpn_set_geo_rows_mode): 2 (default) = split-bf16 operands on the bf16 MFMA, two
+    tiles per wave, one wave per SIMD — fp32-class results at 1.5x the rate; 0 = fp32 MFMA; 1 = the earlier split-bf16 kernel
+    (experimental: DESIGN.md section 9.2)."""
     L = kl.get_library()
     L.check(L.kpn_set_geo_rows_mode(int(mode)))
 

@@ -579,51 +579,76 @@ def test_device_weight_packer(ops, golden_weights):
     assert torch.equal(va, vb) and (a - b).abs().max() <= 1e-6
 
 
-def test_split_bf16_mode(ops, golden_weights):
-    """kpn_set_geo_rows_mode(1): the dominant kernel on the bf16 MFMA with split operands.  Same parity bar against the
-    reference goldens (query and rendered images), reproducible run to run at two waves per SIMD (an earlier schedule of
-    this kernel was not: see kpn_mfma16_layer), and fp32-class against mode 0."""
+def _golden_parity_in_current_mode(ops, w):
+    for case in CASES:
+        scene, cfg, g = load_case(case)
+        s, ps = _prep(ops, scene)
+        out, valid = ops.query(ps, w, torch.from_numpy(g["query.0.pts"]).cuda(), torch.from_numpy(g["query.0.view"]).cuda())
+        v = g["query.0.valid"][0].reshape(-1)
+        assert (valid.cpu().numpy() == g["query.0.valid"]).all()
+        assert np.abs(out.cpu().numpy()[0] - g["query.0.out"][0])[v].max() < 2e-5
+        pix, (ny, nx) = pixel_list(cfg, scene["cam_tar"])
+        step = 2 ** (cfg["level"] - 1)
+        res = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny),
+                              n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+        for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+            assert np.abs(res[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, (case, k)
+
+
+def _soak_points(ops, n=400_000):
+    from keypointnerf_amd.synthetic import make_scene
+    big = make_scene(n_views=3, src_hw=(256, 256), tar_hw=(64, 64), mask="dense", seed=1)
+    sb, pb = _prep(ops, big)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    lo, hi = sb["bounds"].reshape(2, 3)[0], sb["bounds"].reshape(2, 3)[1]
+    P = (lo + (hi - lo) * (0.2 + 0.6 * torch.rand(n, 3, device="cuda", generator=gen)))[None]
+    V = torch.nn.functional.normalize(torch.randn(n, 3, device="cuda", generator=gen), dim=-1)[None]
+    return pb, P, V
+
+
+def test_rows_kernel_modes(ops, golden_weights):
+    """kpn_set_geo_rows_mode: 2 (default) = split-bf16 operands on v_mfma_f32_32x32x16_bf16, two tiles per wave, one wave per
+    SIMD; 0 = fp32 MFMA.  Both: the reference goldens (query and rendered images) at the parity bar, bit-identical run to run,
+    and fp32-class agreement with each other on 400,000 random points — no tolerated outliers (the long soak over code
+    placements is scripts/soak_mode2.py, profiles/r02_soak_mode2_*.jsonl)."""
     sd, w = golden_weights
+    default_mode = ops.get_geo_rows_mode()
+    assert default_mode == 2
+    try:
+        results = {}
+        for mode in (2, 0):
+            ops.set_geo_rows_mode(mode)
+            assert ops.get_geo_rows_mode() == mode
+            _golden_parity_in_current_mode(ops, w)
+            pb, P, V = _soak_points(ops)
+            runs = [ops.query(pb, w, P, V, mode=1)[0].clone() for _ in range(6)]
+            assert all(torch.equal(r, runs[0]) for r in runs[1:]), mode
+            results[mode] = runs[0]
+        scale = results[0].abs().amax(dim=(0, 1))
+        off = ((results[2] - results[0]).abs() > 2e-5 * scale + 1e-6).any(-1)
+        assert int(off.sum()) == 0
+    finally:
+        ops.set_geo_rows_mode(default_mode)
+
+
+def test_split_bf16_one_tile_per_wave_mode_is_reported_not_trusted(ops, golden_weights):
+    """kpn_set_geo_rows_mode(1): the earlier split-bf16 kernel (one tile per wave, two waves per SIMD).  It meets the parity bar
+    on the goldens, but some builds of it emit a wrong half-tile once per 1e6-1e7 evaluations for a reason that was never
+    isolated; it is kept for comparison only, so isolated differing tiles are reported, not failed."""
+    sd, w = golden_weights
+    default_mode = ops.get_geo_rows_mode()
     try:
         ops.set_geo_rows_mode(1)
-        assert ops.get_geo_rows_mode() == 1
-        for case in CASES:
-            scene, cfg, g = load_case(case)
-            s, ps = _prep(ops, scene)
-            out, valid = ops.query(ps, w, torch.from_numpy(g["query.0.pts"]).cuda(), torch.from_numpy(g["query.0.view"]).cuda())
-            v = g["query.0.valid"][0].reshape(-1)
-            assert (valid.cpu().numpy() == g["query.0.valid"]).all()
-            assert np.abs(out.cpu().numpy()[0] - g["query.0.out"][0])[v].max() < 2e-5
-            pix, (ny, nx) = pixel_list(cfg, scene["cam_tar"])
-            step = 2 ** (cfg["level"] - 1)
-            res = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny),
-                                  n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
-            for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
-                assert np.abs(res[k].cpu().numpy() - g["out." + k]).max() <= RGBA_TOL, (case, k)
-        from keypointnerf_amd.synthetic import make_scene
-        big = make_scene(n_views=3, src_hw=(256, 256), tar_hw=(64, 64), mask="dense", seed=1)
-        sb, pb = _prep(ops, big)
-        N = 400_000
-        gen = torch.Generator(device="cuda").manual_seed(4)
-        lo, hi = sb["bounds"].reshape(2, 3)[0], sb["bounds"].reshape(2, 3)[1]
-        P = (lo + (hi - lo) * (0.2 + 0.6 * torch.rand(N, 3, device="cuda", generator=gen)))[None]
-        V = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=gen), dim=-1)[None]
+        _golden_parity_in_current_mode(ops, w)
+        pb, P, V = _soak_points(ops)
         runs = [ops.query(pb, w, P, V, mode=1)[0].clone() for _ in range(6)]
-        # Expected: bit-equal runs (0 differing points in 5.6e8 soaked evaluations of the shipped build).  The margins around
-        # v_mfma_f32_32x32x16_bf16 are empirical (DESIGN §9.2) — one build whose code placement differed showed one differing
-        # tile in this test — so an isolated tile is reported, not failed; the mode is opt-in for this reason.
         differing = [int((r != runs[0]).any(-1).sum()) for r in runs[1:]]
         assert max(differing) <= 64, differing
         if any(differing):
             import warnings
-            warnings.warn(f"split-bf16 mode: runs differ in {differing} of {N} points (hazard margin, DESIGN 9.2)")
-        ops.set_geo_rows_mode(0)
-        ref = ops.query(pb, w, P, V, mode=1)[0]
-        scale = ref.abs().amax(dim=(0, 1))
-        off = ((runs[0] - ref).abs() > 2e-5 * scale + 1e-6).any(-1)
-        assert int(off.sum()) <= 64, int(off.sum())
+            warnings.warn(f"rows mode 1: runs differ in {differing} of {P.shape[1]} points (DESIGN 9.2)")
     finally:
-        ops.set_geo_rows_mode(0)
+        ops.set_geo_rows_mode(default_mode)
 
 
 def test_query_backward_four_views(ops):

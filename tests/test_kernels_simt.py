@@ -457,6 +457,8 @@ def test_split_bf16_geo_rows(env):
     scene, cfg, g = load_case(CASES[0])
     hs = sh.HostScene(lib, scene)
     valid = g["query.0.valid"][0].reshape(-1)
+    default_mode = lib.kpn_get_geo_rows_mode()
+    assert default_mode == 2                                         # the library's default rows kernel
     for n_valid in (704, 660):                                       # 22 and 21 tiles
         idx = np.concatenate([np.where(valid)[0][:n_valid], np.where(~valid)[0][:60]])
         pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
@@ -466,10 +468,12 @@ def test_split_bf16_geo_rows(env):
             o1, v1 = sh.query(lib, hs, packed, pts, view)
             lib.check(lib.kpn_set_geo_rows_mode(2))
             o2, v2 = sh.query(lib, hs, packed, pts, view)
-        finally:
             lib.check(lib.kpn_set_geo_rows_mode(0))
-        o0, v0 = sh.query(lib, hs, packed, pts, view)
+            o0, v0 = sh.query(lib, hs, packed, pts, view)
+        finally:
+            lib.check(lib.kpn_set_geo_rows_mode(default_mode))
         assert np.array_equal(v0, v1) and np.array_equal(v0, v2) and v1.sum() == n_valid
+        assert np.abs(o0 - ref)[v1].max() < 1e-5                     # the fp32-MFMA kernel (mode 0)
         assert np.abs(o1 - ref)[v1].max() < 1e-5
         assert np.abs(o1 - o0)[v1].max() < 5e-6
         assert np.abs(o2 - ref)[v2].max() < 1e-5 and np.abs(o2 - o1)[v2].max() < 2e-6     # same products; exp(-d2 * (1 / 2 sigma^2))
