@@ -275,7 +275,9 @@ def main():
         traffic = None
         tj = os.path.join(ROOT, "profiles", "geo_rows_traffic.json")
         if os.path.exists(tj) and launches.value > 0:
-            traffic = json.load(open(tj))["hbm_bytes_per_row"] * rows.value / launches.value
+            tr = json.load(open(tj))
+            per_row = tr.get("k_geo_rows_h2", tr)["hbm_bytes_per_row"] if args.geo_rows_mode == 2 else tr["hbm_bytes_per_row"]
+            traffic = per_row * rows.value / launches.value
         alpha_mean = float(out["alpha_fine" if fine else "alpha"].mean())
         rows_per_step = rows.value / max(1, args.steps)
         valid_frac = rows_per_step / (args.views * rays_per_step * evals_per_ray)
