@@ -313,6 +313,7 @@ def main():
                        "dist_backend": (args.dist_backend if world > 1 else None)},
             "roofline": {"kernel": ("k_geo_rows", "k_geo_rows_h", "k_geo_rows_h2")[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "surplus_launches": surplus.value,
