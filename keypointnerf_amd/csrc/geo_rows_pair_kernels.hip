@@ -235,7 +235,14 @@ __device__ unsigned long long kpn_h2_cycles[8];
 #define KPN_H2_STAMP(i) ((void)0)
 #endif
 #ifndef KPN_SIMT_EMU
+#ifdef KPN_H2_NUM_VGPR   // experiment: fewer registers -> heavy scratch spills at one wave per SIMD
+#ifndef KPN_H2_WAVES_PER_SIMD
+#define KPN_H2_WAVES_PER_SIMD 1
+#endif
+#define KPN_H2_BOUNDS __launch_bounds__(256, KPN_H2_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(KPN_H2_NUM_VGPR)))
+#else
 #define KPN_H2_BOUNDS __launch_bounds__(256, 1)
+#endif
 #else
 #define KPN_H2_BOUNDS
 #endif
