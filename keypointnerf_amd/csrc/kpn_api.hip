@@ -615,7 +615,13 @@ int pair_grid_blocks() {   // k_geo_rows_h2: one 256-thread workgroup per CU = o
 #ifdef KPN_SIMT_EMU
     return 8;
 #else
-    static int blocks = [] { const char* e = getenv("KPN_H2_BLOCKS"); return e ? atoi(e) : 256; }();
+    static int blocks = [] {
+        const char* e = getenv("KPN_H2_BLOCKS");
+        if (e) return atoi(e);
+        int dev = 0, cus = 0;   // one workgroup per compute unit of the current device (256 on an MI355X)
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
     return blocks;
 #endif
 }
