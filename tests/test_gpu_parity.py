@@ -633,6 +633,29 @@ def test_rows_kernel_modes(ops, golden_weights):
         ops.set_geo_rows_mode(default_mode)
 
 
+def test_default_rows_kernel_soak(ops, golden_weights):
+    """A short version of scripts/soak_mode2.py inside the suite: 2,000,000 random points x 3 views evaluated 41 times with the
+    default rows kernel (2.5e8 row evaluations, about a second) — every repeat bit-identical to the first, and the first within
+    fp32-class distance of the fp32-MFMA kernel at every point.  The long soak (1.1e11 row evaluations over 12 code placements) is
+    profiles/r02_soak_mode2_1e11_row_evaluations.jsonl."""
+    sd, w = golden_weights
+    default_mode = ops.get_geo_rows_mode()
+    try:
+        pb, P, V = _soak_points(ops, n=2_000_000)
+        ops.set_geo_rows_mode(0)
+        ref = ops.query(pb, w, P, V, mode=1)[0].clone()
+        ops.set_geo_rows_mode(default_mode)
+        first = ops.query(pb, w, P, V, mode=1)[0].clone()
+        scale = ref.abs().amax(dim=(0, 1))
+        assert int((((first - ref).abs() > 2e-5 * scale + 1e-6).any(-1)).sum()) == 0
+        differing = 0
+        for _ in range(40):
+            differing += int((ops.query(pb, w, P, V, mode=1)[0] != first).any(-1).sum())
+        assert differing == 0
+    finally:
+        ops.set_geo_rows_mode(default_mode)
+
+
 def test_split_bf16_one_tile_per_wave_mode_is_reported_not_trusted(ops, golden_weights):
     """kpn_set_geo_rows_mode(1): the earlier split-bf16 kernel (one tile per wave, two waves per SIMD).  It meets the parity bar
     on the goldens, but some builds of it emit a wrong half-tile once per 1e6-1e7 evaluations for a reason that was never
