@@ -1,8 +1,8 @@
 // k_geo_rows_h2: the rows of layers1 on v_mfma_f32_32x32x16_bf16 with split-bf16 operands, TWO 32-point tiles per wavefront
-// and ONE wavefront per SIMD (512 registers).  Included by kpn_api.hip after field_kernels.hip; same rows, same row scratch,
+// and ONE wavefront per SIMD (512 registers).  Its own translation unit on the device (geo_rows_pair_tu.hip); same rows, same row scratch,
 // same arithmetic as k_geo_rows_h (every accumulator receives the same six products per step in the same order).
 //
-// Why this shape (DESIGN.md sections 4.3 and 9.2):
+// Why this shape (DESIGN.md sections 4.6 and 9.2):
 //  * the split-bf16 chain needs 888 MFMAs of 32 cycles per (tile, view) against 1,120 of 64 cycles on the fp32 pipe: the
 //    matrix time drops 2.5x, and the VALU work that produces the B operands (activation + three-way split, ~13 instructions
 //    per value) becomes comparable to it.  With one 32-point tile per wave the two only overlap across the two waves of a
@@ -18,39 +18,15 @@
 // kernel): every MFMA of step s is followed by one slice of the work that produces step s+1's B operands, and a scheduling
 // barrier after each (MFMA, slice) keeps that order.  A step has 12·NOB MFMAs and 8 operand pairs (2 tiles x 4 pairs of
 // values: v_cvt_pk_bf16_f32 converts two values at once), i.e. 6 (NOB = 4) or 3 (NOB = 2) MFMAs per pair:
-//     NOB = 4:  value 2j | value 2j+1 | hi piece + residual | mid piece + residual | lo piece | hook (loads for step s+2)
-//     NOB = 2:  both values | hi + mid | lo + hook
+//     NOB = 4:  six slices of 3-5 instructions, one per MFMA (kpn_h2_slice)
+//     NOB = 2:  two slices per MFMA
 //
 // A work item is (tile pair, view): tiles 2j and 2j+1 of the batch.  Lane l holds point p = l & 31 of BOTH tiles, half
 // h = l >> 5 of the K slots / output rows, exactly like k_geo_rows_h.
 
-#ifndef KPN_H2_REGIONS
-#define KPN_H2_REGIONS 8
-#endif
-#ifndef KPN_H2_GV
-#define KPN_H2_GV 5
-#endif
 #ifndef KPN_H2_LOOKAHEAD
 #define KPN_H2_LOOKAHEAD true   // the next layer's step-0 operands are produced under the last step
 #endif
-#ifndef KPN_H2_L0_STEPS
-#define KPN_H2_L0_STEPS 16   // timing experiments shorten the chain (wrong results)
-#endif
-#ifndef KPN_H2_L1_STEPS
-#define KPN_H2_L1_STEPS 8
-#endif
-// Softplus(beta=100, threshold=20) as kpn_softplus100, with the threshold taken on x itself (x > 0.2 instead of 100 x > 20:
-// the two differ for the one or two floats next to 0.2, where both branches agree to 2e-11) - one VALU instruction less
-__device__ __forceinline__ float kpn_h2_softplus100(float x) {
-#if defined(KPN_ABLATE_ACT)
-    return x;
-#elif defined(KPN_H2_OLD_SOFTPLUS)
-    return kpn_softplus100(x);
-#else
-    const float sp = kpn_log2(1.0f + kpn_exp2(x * 144.269504088896341f)) * 6.93147180559945309e-3f;
-    return x > 0.2f ? x : sp;
-#endif
-}
 // Empty volatile asm statements keep their program order and anchor the (side-effect free) MFMAs and VALU slices between the
 // scheduling barriers: without them instruction selection is free to sink a whole layer's MFMAs below all of its slices —
 // it did, for layers1.1 — and the barriers then fence nothing.  Accumulators live in AGPRs ("a"), the rest in VGPRs.
@@ -451,7 +427,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         float4 hraw[2][4];                                  // the four taps of the 4 hd channels of this half (layers1.2, step 8)
         float hd[2][4];
         kpn_taps tp1[2];
-        kpn_mfma16_layer2<KPN_H2_L1_STEPS, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_1), lane,
+        kpn_mfma16_layer2<8, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_1), lane,
             [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
                 return a0[t][s / 2][(s % 2) * 8 + e];
