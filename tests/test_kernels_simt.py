@@ -383,11 +383,11 @@ def test_train_forward_kept_for_the_backward(env, chunk):
     args = (scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"], g["u_c"], g["noise_c"], g["noise_f"], g["u_f"],
             keep_bits(g["keep_c"]), keep_bits(g["keep_f"]), float(g["noise_std"]))
     out, got = sh.render_train_keep_and_backward(lib, hs, packed, *args, train_grad_inputs(g), chunk_rays=chunk)
-    plain = sh.render_train(lib, hs, packed, *args, chunk_rays=chunk)
-    for k in plain:
-        assert np.array_equal(out[k], plain[k]), k
     assert_train_grads_vs_golden(got, g, load_weights(), 1e-4)
     if chunk == 0:
+        plain = sh.render_train(lib, hs, packed, *args, chunk_rays=chunk)
+        for k in plain:
+            assert np.array_equal(out[k], plain[k]), k
         ref = sh.render_train_backward(lib, hs, packed, *args, train_grad_inputs(g))
         # not bit-equal: the valid list's order (atomic compaction) differs from call to call, and with it the tiles the
         # per-tile partial sums are formed over
