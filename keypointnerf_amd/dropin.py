@@ -152,11 +152,14 @@ def _draw_keep_bits(n_views, dev):
     return int(sum(1 << i for i, x in enumerate(k.tolist()) if x > 0.5))
 
 
-def install(net):
+def install(net, rows_mode=None):
     """Rebinds the hot-path attributes of a reference ``KeypointNeRF`` instance to the HIP operators.
-    Returns ``net``.  ``uninstall(net)`` restores the reference's methods."""
+    Returns ``net``.  ``uninstall(net)`` restores the reference's methods.  ``rows_mode`` (optional) selects the rows
+    kernel process-wide (``ops.set_geo_rows_mode``: 2 = default split-bf16 pair tiles, 0 = fp32 MFMA)."""
     from . import torch_ops  # noqa: F401  (registers torch.ops.kpnerf.*)
     check_supported(net)
+    if rows_mode is not None:
+        ops.set_geo_rows_mode(rows_mode)
     st = _State(net)
     cls = type(net)
     ref = {k: getattr(cls, k) for k in _SEAMS if hasattr(cls, k)}
