@@ -498,6 +498,12 @@ __device__ __forceinline__ void kpn_stage_lds_streams(const float* __restrict__ 
 // Any V <= KPN_MAXV: the per-view x' vectors are recomputed in each of the three passes over the views (two for the
 // weighted mean / variance, one for the head).  A V <= 3 variant that kept them in registers was measured slower: this
 // kernel is register-bound, and every spilled VGPR costs more than re-running the 624-MAC ray encoder.
+#ifdef KPN_FUSE_TIMING   // debug builds: cycles (s_memtime) per phase of one wave's tiles, summed (scripts/fuse_timing.py)
+__device__ unsigned long long kpn_fuse_cycles[8];
+#define KPN_FUSE_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 3 && threadIdx.x == 64) atomicAdd(&kpn_fuse_cycles[i], now_ - fstamp_); fstamp_ = now_; } while (0)
+#else
+#define KPN_FUSE_STAMP(i) ((void)0)
+#endif
 __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
@@ -520,7 +526,11 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
     const float ani = wl[kpn_scalar_off() + 0];  // |ani_al|
 
     (void)wave; (void)nwaves;
+#ifdef KPN_FUSE_TIMING
+    unsigned long long fstamp_ = clock64();
+#endif
     for (;;) {
+        KPN_FUSE_STAMP(7);
         int t = 0;
         if (lane == 0) t = atomicAdd(tickets + 1, 1);
         t = __shfl(t, 0);
@@ -529,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         const int ci = ci_raw < count ? ci_raw : count - 1;
         const int64_t n = list[ci];
 
+        KPN_FUSE_STAMP(0);
         // ---- pooled mean / var over views of the 64-vector ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
@@ -556,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                     }
                 }
             }
+        KPN_FUSE_STAMP(1);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
         {
@@ -592,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                 continue;
             }
         }
+        KPN_FUSE_STAMP(2);
         // ---- ibr_compress_gfeat 128 -> 24 (model.py:819), rows already in x' order ----
         float lat0[16];
         {
@@ -601,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }
+        KPN_FUSE_STAMP(3);
         // ---- IBR head (model.py:1267-1302) ----
         // blend weights (model.py:1287-1289): w_v = (e_v - min_v e) / (sum + 1e-8), e_v = exp(|a|(dot_v - 1))
         kpn_view_gather gv;
@@ -659,6 +673,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                     stats(pass, rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w, iv);
                 }
             }
+        KPN_FUSE_STAMP(4);
         // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
         kpn_f32x16 base[2];
         kpn_load_bias<2>(wl + kpn_seg_boff(SEG_BL_0A), h, base);
@@ -731,6 +746,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             else kpn_encode_view(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }
+        KPN_FUSE_STAMP(5);
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;
             if (mode == 1) {  // eval_func with mask = 1 (model.py:981-996)

@@ -1506,3 +1506,12 @@ extern "C" int kpn_selftest_mfma(float* scratch, void* stream, float* max_err_ho
     }
     return KPN_OK;
 }
+
+#if defined(KPN_FUSE_TIMING) && !defined(KPN_SIMT_EMU)
+// debug builds only: read (and clear) the per-phase cycle sums of k_fuse_color
+extern "C" int kpn_fuse_timing(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(kpn_fuse_cycles), 64) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kpn_fuse_cycles), z, 64) != hipSuccess;
+}
+#endif
