@@ -191,13 +191,11 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     });
 }
 
-// OPTION: layers1.0's 16 steps executed with a geometry step (stream steps 12..15: bilinear gathers, 32-64 distinct cache lines per
-// load instruction) after every three encoding steps (stream steps 0..11): the four waves of a CU run in near lockstep and share
-// one L1, so four consecutive geometry steps queue all their gathers behind each other (measured 5 k cycles per geometry step
-// against 2.2 k for an encoding step); spread out, the gathers of one geometry step have three steps to drain.
-// Measured: layers1.0 41.2 k instead of 45.2 k cycles per work item, the launch 1.3 % faster — and the different summation order
-// moves one ray of the V = 16 oracle comparison (tests/test_gpu_parity.py::test_render_vs_oracle, tiny densities) from below to
-// 1.3e-4, above the 1e-4 bar.  Not worth it: off by default (-DKPN_H2_L0_INTERLEAVE=1 to switch it on).
+// OPTION: layers1.0's 16 steps executed with a geometry step (stream steps 12..15: bilinear gathers) after every three encoding
+// steps (stream steps 0..11), so that the gathers of the four waves of a CU, which run in near lockstep and share one L1, are
+// spread out.  Measured: layers1.0 41.2 k instead of 45.2 k cycles per work item, the launch 1.3 % faster — and the different
+// summation order moves one ray of the V = 16 oracle comparison (tests/test_gpu_parity.py::test_render_vs_oracle, tiny
+// densities) from below to 1.3e-4, above the 1e-4 bar.  Not worth it: off by default (-DKPN_H2_L0_INTERLEAVE=1 switches it on).
 #ifndef KPN_H2_L0_INTERLEAVE
 #define KPN_H2_L0_INTERLEAVE 0
 #endif

@@ -145,8 +145,8 @@ void walk_hsegments(const size_t (&w_off)[4], Emit emit) {
     auto chain16 = [](int s, int h, int e) { return 32 * (s / 2) + KPN_ROWMAP(8 * (s % 2) + e, h); };
     walk_hsegment(HSEG_G1_0A, w_off[0], 128, 232, [](int s, int h, int e) { return e < 7 ? e * 24 + s + 12 * h : -1; },
                   [&](size_t el, int64_t src) { emit(HSEG_G1_0A, el, src); });
-    // geo0 channels of step s: 16 s + 8 h + e — the two halves of a point read the SAME 64-byte piece of one cache line (a
-    // bilinear gather is bound by the number of distinct lines per load instruction: 32 this way instead of 64)
+    // geo0 channels of step s: 16 s + 8 h + e — the two halves of a point read the same 64-byte piece of one cache line (32
+    // distinct lines per gather instruction instead of 64)
     walk_hsegment(HSEG_G1_0B, w_off[0], 128, 232, [](int s, int h, int e) { return 168 + 16 * s + 8 * h + e; },
                   [&](size_t el, int64_t src) { emit(HSEG_G1_0B, el, src); });
     walk_hsegment(HSEG_G1_1, w_off[1], 128, 128, chain16, [&](size_t el, int64_t src) { emit(HSEG_G1_1, el, src); });
