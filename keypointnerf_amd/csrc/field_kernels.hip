@@ -231,6 +231,11 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
 // ---------------------------------------------------------------------------------------------
 // k_geo_rows with split-bf16 operands on v_mfma_f32_32x32x16_bf16 (kpn_mfma16_layer): same rows, same row scratch,
 // fp32-class arithmetic (every product term above 2^-24 relative is kept), about twice the matrix rate.
+// NOT PART OF THE SHIPPED LIBRARY since round 3: the kernel emits a wrong half-tile about once per 1e6-1e7 evaluations at
+// two waves per SIMD for a reason that was never isolated; k_geo_rows_h2 superseded it.  It is kept
+// for that investigation only and builds with -DKPN_WITH_MODE1 -DKPN_H2_LOG2ACT=0 (it reads the unfolded split-bf16 streams).
+#ifdef KPN_WITH_MODE1
+static_assert(!KPN_H2_LOG2ACT, "k_geo_rows_h reads split-bf16 streams without the folded activation scale");
 #ifndef KPN_GEOH_OCC
 #define KPN_GEOH_OCC 2
 #endif
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
         }
     }
 }
+#endif  // KPN_WITH_MODE1
 
 // ---------------------------------------------------------------------------------------------
 // Per-view inputs of the IBR head for this lane's point (query_color, model.py:806-832), in two steps:

@@ -32,59 +32,139 @@
 // it did, for layers1.1 — and the barriers then fence nothing.  Accumulators live in AGPRs ("a"), the rest in VGPRs.
 #ifdef KPN_SIMT_EMU
 #define KPN_H2_PIN_ACC(v) ((void)0)
-#define KPN_H2_PIN(v) ((void)0)
 #else
 #define KPN_H2_PIN_ACC(v) asm volatile("" : "+a"(v))
-#define KPN_H2_PIN(v) asm volatile("" : "+v"(v))
 #endif
 constexpr int kpn_h2_pa(int pr) { return pr == 2 || pr == 3 ? 1 : (pr == 5 ? 2 : 0); }   // A piece of product pr: h h m m h l
 constexpr int kpn_h2_pb(int pr) { return pr == 1 || pr == 3 ? 1 : (pr == 4 ? 2 : 0); }   // B piece:                h m h m l h
 
-// ---- staged production of one operand pair (two fp32 values -> three bf16 pieces each), in SIX slices of 3-5 instructions.
-// With ACT the values go through Softplus(beta 100, threshold 20 taken on x itself: x > 0.2) first; its two transcendentals
-// (8 issue cycles each against 4.4 of a plain VALU instruction: scripts/mfma16_filler_probe.hip) land in different slices:
-//   0: read x0 x1, scale both, exp x0        1: exp x1, 1 + e0, log, 1 + e1       2: log, scale both, select x0
-//   3: select x1, hi piece, residual 0       4: residual 1, mid piece, residual 0  5: residual 1, lo piece
-// Without ACT: 0: x0 = v0()   1: x1 = v1()   2: -   3..5 as above.
-struct kpn_h2_pair { float x0, x1, u0, u1; kpn_bf16_t h0, h1; };
+// ---- the operand production: one volatile asm BLOCK per slice ----
+// The VALU work between two MFMAs is budgeted in issue slots (five hide under one v_mfma_f32_32x32x16_bf16 at one wave per
+// SIMD, a transcendental counts about two: scripts/mfma16_filler_probe.hip), so what hipcc selects matters as much as where it
+// puts it.  Written in C++ with pin statements (round 2) the three-way split came out as one v_cvt_pk_bf16_f32 PER VALUE
+// (second source zero) plus v_mov copies: 7.5 instructions per value instead of the 5.5 of
+//     pk = cvt_pk(x0, x1);  t0 = pk << 16;  t1 = pk & 0xffff0000;  x0 -= t0;  x1 -= t1        (twice, then one more cvt_pk),
+// and every pin ("+v" in an empty asm) made hipcc's hazard recogniser assume a partial-register write and put an s_nop in
+// front of the next reader: 1,088 of them per work item.  A slice is therefore ONE asm statement holding its 2-5 instructions:
+// they are selected as written, stay in program order (volatile statements are not reordered against each other), need no
+// pins, and the recogniser — which neither looks inside an asm statement nor counts it as a wait state — sees each
+// statement's results consumed only behind the next MFMA.  The one software hazard such a stream can meet on gfx950, a
+// transcendental's result read by a non-transcendental VALU instruction in the very next issue slot (one wait state), is
+// excluded by construction: inside a block another instruction always sits between a v_exp_f32 / v_log_f32 and the first
+// use of its result, and across blocks the MFMA does.  The accumulators are read by the blocks themselves
+// (v_accvgpr_read_b32 from an "a" operand; left to the compiler every value was read twice): an accumulator block is final
+// at least three MFMA issues (96 cycles) before its first read (static_assert in kpn_mfma16_layer2).
+typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef KPN_SIMT_EMU
+__device__ __forceinline__ kpn_bf16x8 kpn_as_bf16x8(kpn_u32x4 v) { return __builtin_bit_cast(kpn_bf16x8, v); }
+#define KPN_H2_USE(v) asm volatile("" ::"v"(v))      // the value exists before this point; defines nothing (no assumed hazard)
+#else
+static inline kpn_bf16x8 kpn_as_bf16x8(kpn_u32x4 v) { kpn_bf16x8 r; memcpy(&r, &v, 16); return r; }
+#define KPN_H2_USE(v) ((void)0)
+static inline uint32_t kpn_emu_cvt_pk(float lo, float hi) { return (uint32_t)kpn_f2bf(lo) | ((uint32_t)kpn_f2bf(hi) << 16); }
+static inline float kpn_emu_bf_lo(uint32_t pk) { return kpn_bf2f((uint16_t)(pk & 0xffffu)); }
+static inline float kpn_emu_bf_hi(uint32_t pk) { return kpn_bf2f((uint16_t)(pk >> 16)); }
+#endif
+
+// Softplus(beta 100, threshold 20) in LOG2 UNITS (KPN_H2_LOG2ACT, kpn_common.h; the default): the packer folds 100 log2(e)
+// into the weights and biases of the layer that PRODUCES a pre-activation and ln(2)/100 into the weights of the layer that
+// CONSUMES the activation (kpn_hseg_factor), so that the accumulators hold u = 100 log2(e) x and the next layer wants
+// y' = 100 log2(e) softplus(x) = log2(1 + 2^u): v_exp_f32, +1, v_log_f32 and nothing else.  The reference's threshold branch
+// (x if 100 x > 20, src/utils.py:523-524) is max(u, .): beyond the threshold 1 + 2^u = 2^u in fp32 and below it the two
+// differ by less than an ulp; the clamp at 126 keeps 2^u finite for any u (the max then returns u itself).
+// With KPN_H2_LOG2ACT=0 (A/B builds) the same blocks carry the two multiplications per value of the natural-unit form.
+
+// ---- staged production of one operand pair (two fp32 values -> three bf16 pieces each = one dword per piece), in SIX slices.
+// With ACT the values go through the activation first; issue slots per slice (transcendental = 2): 6 6 5 4 4 2
+//   0: read u0 u1, clamp both, exp 0     1: exp 1, 1 + e0, 1 + e1, log 0     2: log 1, max 0, max 1, hi pieces
+//   3: unpack hi 0/1, residual 0/1       4: mid pieces, unpack 0/1, residual 0   5: residual 1, lo pieces
+// Without ACT: 0: x0 = v0()   1: x1 = v1()   2: hi pieces   3..5 as above.
+struct kpn_h2_pair { float x0, x1, e0, e1; uint32_t pk; };
 template <bool ACT, int Q, int J, class V0, class V1>
-__device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_bf16x8 (&dst)[3], V0&& v0, V1&& v1) {
+__device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[3], V0&& v0, V1&& v1) {
     if constexpr (Q == 0) {
-        p.x0 = v0();
         if constexpr (ACT) {
-            p.x1 = v1();
-            p.u0 = p.x0 * 144.269504088896341f; p.u1 = p.x1 * 144.269504088896341f;
-            p.u0 = kpn_exp2(p.u0);
-        }
+            const float a0 = v0(), a1 = v1();             // two accumulator elements (AGPRs)
+#ifndef KPN_SIMT_EMU
+#if KPN_H2_LOG2ACT
+            asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\t"
+                         "v_min_f32 %2, 0x42fc0000, %0\n\tv_min_f32 %3, 0x42fc0000, %1\n\tv_exp_f32 %2, %2"
+                         : "=&v"(p.x0), "=&v"(p.x1), "=&v"(p.e0), "=&v"(p.e1) : "a"(a0), "a"(a1));
+#else
+            asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\t"
+                         "v_mul_f32 %2, 0x431044fe, %0\n\tv_mul_f32 %3, 0x431044fe, %1\n\t"
+                         "v_min_f32 %2, 0x42fc0000, %2\n\tv_min_f32 %3, 0x42fc0000, %3\n\tv_exp_f32 %2, %2"
+                         : "=&v"(p.x0), "=&v"(p.x1), "=&v"(p.e0), "=&v"(p.e1) : "a"(a0), "a"(a1));
+#endif
+#else
+            p.x0 = a0; p.x1 = a1;
+            const float s = KPN_H2_LOG2ACT ? 1.0f : KPN_H2_ACT_SCALE;
+            p.e0 = fminf(p.x0 * s, 126.0f); p.e1 = fminf(p.x1 * s, 126.0f);
+            p.e0 = kpn_exp2(p.e0);
+#endif
+        } else { p.x0 = v0(); KPN_H2_USE(p.x0); }
     } else if constexpr (Q == 1) {
-        if constexpr (ACT) { p.u1 = kpn_exp2(p.u1); p.u0 = kpn_log2(1.0f + p.u0); p.u1 = 1.0f + p.u1; }
-        else p.x1 = v1();
+        if constexpr (ACT) {
+#ifndef KPN_SIMT_EMU
+            asm volatile("v_exp_f32 %1, %1\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_log_f32 %0, %0" : "+v"(p.e0), "+v"(p.e1));
+#else
+            p.e1 = kpn_exp2(p.e1); p.e0 = 1.0f + p.e0; p.e1 = 1.0f + p.e1; p.e0 = kpn_log2(p.e0);
+#endif
+        } else { p.x1 = v1(); KPN_H2_USE(p.x1); }
     } else if constexpr (Q == 2) {
         if constexpr (ACT) {
-            p.u1 = kpn_log2(p.u1);
-            p.u0 *= 6.93147180559945309e-3f; p.u1 *= 6.93147180559945309e-3f;   // ln2 / 100
-#ifndef KPN_ABLATE_ACT
-            p.x0 = p.x0 > 0.2f ? p.x0 : p.u0;
+#ifndef KPN_SIMT_EMU
+#ifdef KPN_ABLATE_ACT   // timing experiment (wrong results): the activation's instructions without its effect
+            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %2, %2, %2\n\tv_max_f32 %3, %3, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
+                         : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
+#elif KPN_H2_LOG2ACT
+            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
+                         : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
+#else
+            asm volatile("v_log_f32 %3, %3\n\tv_mul_f32 %2, 0x3be32166, %2\n\tv_max_f32 %0, %0, %2\n\t"
+                         "v_mul_f32 %3, 0x3be32166, %3\n\tv_max_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
+                         : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
+#endif
+#else
+            p.e1 = kpn_log2(p.e1);
+            const float s = KPN_H2_LOG2ACT ? 1.0f : KPN_H2_ACT_UNSCALE;
+            p.x0 = fmaxf(p.x0, p.e0 * s); p.x1 = fmaxf(p.x1, p.e1 * s);
+            p.pk = kpn_emu_cvt_pk(p.x0, p.x1);
+#endif
+        } else {
+#ifndef KPN_SIMT_EMU
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p.pk) : "v"(p.x0), "v"(p.x1));
+#else
+            p.pk = kpn_emu_cvt_pk(p.x0, p.x1);
 #endif
         }
+        dst[0][J] = p.pk;
     } else if constexpr (Q == 3) {
-#ifndef KPN_ABLATE_ACT
-        if constexpr (ACT) p.x1 = p.x1 > 0.2f ? p.x1 : p.u1;
+#ifndef KPN_SIMT_EMU
+        asm volatile("v_lshlrev_b32 %2, 16, %4\n\tv_and_b32 %3, 0xffff0000, %4\n\tv_sub_f32 %0, %0, %2\n\tv_sub_f32 %1, %1, %3"
+                     : "+v"(p.x0), "+v"(p.x1), "=&v"(p.e0), "=&v"(p.e1) : "v"(p.pk));
+#else
+        p.x0 = p.x0 - kpn_emu_bf_lo(p.pk); p.x1 = p.x1 - kpn_emu_bf_hi(p.pk);
 #endif
-        p.h0 = kpn_to_bf(p.x0); p.h1 = kpn_to_bf(p.x1);
-        dst[0][2 * J] = p.h0; dst[0][2 * J + 1] = p.h1;
-        p.x0 = p.x0 - kpn_bf_to_f(p.h0);
     } else if constexpr (Q == 4) {
-        p.x1 = p.x1 - kpn_bf_to_f(p.h1);
-        p.h0 = kpn_to_bf(p.x0); p.h1 = kpn_to_bf(p.x1);
-        dst[1][2 * J] = p.h0; dst[1][2 * J + 1] = p.h1;
-        p.x0 = p.x0 - kpn_bf_to_f(p.h0);
+#ifndef KPN_SIMT_EMU
+        asm volatile("v_cvt_pk_bf16_f32 %2, %0, %3\n\tv_lshlrev_b32 %1, 16, %2\n\tv_sub_f32 %0, %0, %1\n\tv_and_b32 %1, 0xffff0000, %2"
+                     : "+v"(p.x0), "=&v"(p.e1), "=&v"(p.pk) : "v"(p.x1));
+#else
+        p.pk = kpn_emu_cvt_pk(p.x0, p.x1);
+        p.x0 = p.x0 - kpn_emu_bf_lo(p.pk); p.e1 = kpn_emu_bf_hi(p.pk);
+#endif
+        dst[1][J] = p.pk;
     } else {
-        p.x1 = p.x1 - kpn_bf_to_f(p.h1);
-        dst[2][2 * J] = kpn_to_bf(p.x0); dst[2][2 * J + 1] = kpn_to_bf(p.x1);
+#ifndef KPN_SIMT_EMU
+        uint32_t lo;
+        asm volatile("v_sub_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %0, %2, %1" : "=&v"(lo), "+v"(p.x1) : "v"(p.x0), "v"(p.e1));
+        dst[2][J] = lo;
+#else
+        p.x1 = p.x1 - p.e1;
+        dst[2][J] = kpn_emu_cvt_pk(p.x0, p.x1);
+#endif
     }
-    if constexpr (Q < 5) { KPN_H2_PIN(p.x0); KPN_H2_PIN(p.x1); }
-    if constexpr (ACT && Q < 3) { KPN_H2_PIN(p.u0); KPN_H2_PIN(p.u1); }
 }
 
 // One Linear layer for two tiles.  The instruction stream is laid out by hand: every MFMA is followed by one slice (NOB = 4;
@@ -103,22 +183,30 @@ struct kpn_h2_identity { static constexpr int at(int p) { return p; } };
 template <int KS16, int NOB, int ACT, bool HAVE0, bool NEXT, class SMAP = kpn_h2_identity, class ValFn, class StageFn, class TailFn, class NextFn>
 __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg, int lane, ValFn&& val_fn, StageFn&& stage_fn,
                                                   TailFn&& tail_fn, NextFn&& next_fn, kpn_f32x16 (&acc)[2][NOB],
-                                                  kpn_bf16x8 (&x0)[2][3], kpn_bf16x8 (&xn)[2][3]) {
+                                                  kpn_u32x4 (&x0)[2][3], kpn_u32x4 (&xn)[2][3]) {
     static_assert(NOB == 4 || NOB == 2, "6 or 3 MFMAs per operand pair");
     static_assert(!NEXT || NOB == 4, "the look-ahead needs blocks 0/1 in the first half of a step");
     constexpr int H0 = NOB / 2, H1 = NOB - H0;
     constexpr int MF = 12 * NOB, PP = MF / 8;
-    kpn_bf16x8 xp[2][2][3];                              // [buffer][tile][piece]
+    kpn_u32x4 xp[2][2][3];                               // [buffer][tile][piece]: four dwords = eight bf16
     kpn_bf16x8 wa[3][H0], wb[3][H1];                     // the A pieces of the two halves of the output blocks
-    kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, kpn_to_bf(0.f), kpn_to_bf(0.f)};
+    kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, 0u};
+    // A half's pieces are contiguous ([step][block][piece][lane]): one scalar base in its middle, immediate offsets of
+    // -3..+2 KB (the 13-bit signed range of global_load), the lane offset in one register for the whole kernel.  The base is
+    // a RUNNING pointer advanced from one half to the next (s_add_u32 + s_addc_u32, then re-defined through an empty asm so
+    // that the loads cannot rise above it): computed as `segment + constant` every one of the 82 bases of a work item is
+    // loop-invariant, and hipcc hoisted them all out of the work loop into SGPRs it then had to spill — each use cost two
+    // v_readlane_b32 and the five wait states a VALU-written SGPR needs before a memory instruction may read it.
+    int prev_pos = 0;
+    const float* gp = hseg;
     auto load_half = [&](int s, int ob0, int n, auto& w) {
-        // a half's pieces are contiguous ([step][block][piece][lane]): one scalar base in its middle, immediate offsets
-        // of -3..+2 KB (the 13-bit signed range of global_load), the lane offset in one register for the whole kernel
 #ifdef KPN_DBG_H2_SAMEW   // timing experiment (wrong results): every step reads the weights of step 0 -> the stream stays in L1
-        const float* gp = hseg + (size_t)(s * 0) * (3 * NOB * 64 * 4) + (size_t)(ob0 * 3 + 3) * (64 * 4);
+        const int pos = (ob0 * 3 + 3) * (64 * 4);
 #else
-        const float* gp = hseg + (size_t)s * (3 * NOB * 64 * 4) + (size_t)(ob0 * 3 + 3) * (64 * 4);   // s: stream step
+        const int pos = s * (3 * NOB * 64 * 4) + (ob0 * 3 + 3) * (64 * 4);   // s: stream step
 #endif
+        gp += pos - prev_pos;
+        prev_pos = pos;
         KPN_PIN_POINTER(gp);
         const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
 #pragma unroll
@@ -128,15 +216,15 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     };
     // MFMA number m of a step: half, then product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi — the order k_geo_rows_h
     // uses per accumulator), then block, then tile: the accumulators of a half rotate, consecutive MFMAs are independent
-    auto mfma = [&](auto mi, const kpn_bf16x8 (&x)[2][3]) {
+    auto mfma = [&](auto mi, const kpn_u32x4 (&x)[2][3]) {
         constexpr int m = decltype(mi)::value;
         if constexpr (m < 12 * H0) {
             constexpr int prd = m / (2 * H0), k = (m / 2) % H0, t = m % 2;
-            acc[t][k] = KPN_MFMA16(wa[kpn_h2_pa(prd)][k], x[t][kpn_h2_pb(prd)], acc[t][k]);
+            acc[t][k] = KPN_MFMA16(wa[kpn_h2_pa(prd)][k], kpn_as_bf16x8(x[t][kpn_h2_pb(prd)]), acc[t][k]);
             KPN_H2_PIN_ACC(acc[t][k]);
         } else {
             constexpr int mm = m - 12 * H0, prd = mm / (2 * H1), k = (mm / 2) % H1, t = mm % 2;
-            acc[t][H0 + k] = KPN_MFMA16(wb[kpn_h2_pa(prd)][k], x[t][kpn_h2_pb(prd)], acc[t][H0 + k]);
+            acc[t][H0 + k] = KPN_MFMA16(wb[kpn_h2_pa(prd)][k], kpn_as_bf16x8(x[t][kpn_h2_pb(prd)]), acc[t][H0 + k]);
             KPN_H2_PIN_ACC(acc[t][H0 + k]);
         }
     };
@@ -242,7 +330,9 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
         for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
             const int sg = i >> 7, k = i & 127;
-            bias_s[sg][k] = k < kpn_seg_bfloats(segs[sg]) ? wp[kpn_seg_boff(segs[sg]) + k] : 0.0f;
+            // log2-unit activations: the pre-activations of layers1.0-1.2 are kept scaled by 100 log2(e), biases included
+            const float bscale = (KPN_H2_LOG2ACT && sg < 3) ? KPN_H2_ACT_SCALE : 1.0f;
+            bias_s[sg][k] = k < kpn_seg_bfloats(segs[sg]) ? wp[kpn_seg_boff(segs[sg]) + k] * bscale : 0.0f;
         }
     }
     __syncthreads();
@@ -288,7 +378,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         //      keypoint each (7 encoding values + a zero slot), steps 12-15 eight geo0 channels each ----
         static_assert(kpn_hseg_off(HSEG_G1_0B) == kpn_hseg_off(HSEG_G1_0A) + 12 * kpn_hseg_step_floats(HSEG_G1_0A), "adjacent segments");
         kpn_f32x16 a0[2][4], a1[2][4];
-        kpn_bf16x8 xa[2][3], xb[2][3];                      // step-0 operands handed from one layer to the next
+        kpn_u32x4 xa[2][3], xb[2][3];                       // step-0 operands handed from one layer to the next
         {
             const float* E = tb + KPN_TBL_EXT;
             float cx[2], cy[2], cz[2];
@@ -312,6 +402,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
             float fdz[2][2], fw[2][2], fs1[2][2], fc1[2][2];
             float kcv[2][3] = {{kc[0], kc[1], kc[2]}, {kc[3], kc[4], kc[5]}};   // keypoints of steps 0 and 1 (this half's 12)
             float tdx[2], tdy[2], ty[2], targ[2], tk[2], tr[2], tr2[2], tsp[2], tcp[2], tg[2], ts2[2], tc2[2];
+            int tqi[2];
             float4 raw[2][8];                               // geo0: the four taps of two float4 of channels
             auto pe_stage = [&](auto ni, auto ti, auto gi) {   // stage gi (0..9) of the encoding of keypoint step ni, tile ti
                 constexpr int n = decltype(ni)::value, t = decltype(ti)::value, g = decltype(gi)::value, b = n & 1;
@@ -340,16 +431,18 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
                     tcp[t] = fmaf(tr2[t], fmaf(tr2[t], 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
                 } else if constexpr (g == 6) {
                     tcp[t] = fmaf(tr2[t] * tr2[t], tcp[t], fmaf(tr2[t], -0.5f, 1.0f));
-                } else if constexpr (g == 7) {              // quadrant: swap for odd k
+                } else if constexpr (g == 7) {              // quadrant k mod 4 without compares (a v_cmp result needs two wait
+                    // states before v_cndmask may read it, and nothing else is in these slices): swap sin and cos for odd k
                     const int qd = (int)tk[t];
-                    const float ss = (qd & 1) ? tcp[t] : tsp[t], cc = (qd & 1) ? tsp[t] : tcp[t];
-                    tsp[t] = ss; tcp[t] = cc;
-                } else if constexpr (g == 8) {
-                    const int qd = (int)tk[t];
-                    fs1[b][t] = (qd & 2) ? -tsp[t] : tsp[t];
-                } else {
-                    const int qd = (int)tk[t];
-                    fc1[b][t] = ((qd + 1) & 2) ? -tcp[t] : tcp[t];
+                    tqi[t] = qd;
+                    const uint32_t m = (uint32_t)(-(qd & 1));
+                    const uint32_t sb = __builtin_bit_cast(uint32_t, tsp[t]), cb = __builtin_bit_cast(uint32_t, tcp[t]);
+                    tsp[t] = __builtin_bit_cast(float, (cb & m) | (sb & ~m));
+                    tcp[t] = __builtin_bit_cast(float, (sb & m) | (cb & ~m));
+                } else if constexpr (g == 8) {              // sin: negative in quadrants 2, 3
+                    fs1[b][t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, tsp[t]) ^ (((uint32_t)tqi[t] << 30) & 0x80000000u));
+                } else {                                    // cos: negative in quadrants 1, 2
+                    fc1[b][t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, tcp[t]) ^ (((uint32_t)(tqi[t] + 1) << 30) & 0x80000000u));
                 }
             };
             auto geo_loads = [&](auto si, auto ti, auto fi) {   // the taps of float4 f (0/1) of geo step s: channels 16(s-12) + 8h + 4f ..

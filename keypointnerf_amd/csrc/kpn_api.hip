@@ -161,6 +161,13 @@ inline size_t hseg_slot(int hseg, size_t el, int pc) {
     const size_t e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, s = el / (512 * (size_t)NOB);
     return (size_t)kpn_hseg_off(hseg) * 2 + ((((s * NOB + ob) * 3 + pc) * 64 + lane) * 8 + e);   // [step][block][piece][lane][8]
 }
+// factor folded into the weight at plain index `src` of segment `hseg` (log2-unit activations, kpn_common.h kpn_hseg_factor)
+inline float hseg_weight_factor(int hseg, int64_t src, const size_t (&w_off)[4]) {
+    static const int layer_of[HSEG_COUNT] = {0, 0, 1, 2, 3}, in_dim[4] = {232, 128, 136, 120};
+    if (src < 0) return 1.0f;
+    const int l = layer_of[hseg];
+    return kpn_hseg_factor(hseg, (int)((src - (int64_t)w_off[l]) % in_dim[l]));
+}
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
 }  // namespace
 
@@ -266,7 +273,7 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
         for (int l = 0; l < 4; ++l) w_off[l] = (size_t)(pl.w[P_G1_0 + l] - plain_host);
         uint16_t* P16 = reinterpret_cast<uint16_t*>(P);
         walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
-            const float w = src >= 0 ? plain_host[src] : 0.0f;
+            const float w = src >= 0 ? plain_host[src] * hseg_weight_factor(hseg, src, w_off) : 0.0f;
             const uint16_t ph = host_f2bf(w);
             const float r1 = w - host_bf2f(ph);
             const uint16_t pm = host_f2bf(r1);
@@ -300,10 +307,11 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
 // taken once (by packing a ramp) and applied on the device — a training loop re-packs after every optimizer step
 // split-bf16 region: element t of the concatenated segments -> three bf16 pieces at their slots
 __global__ void k_pack_hseg(const float* __restrict__ plain, const int32_t* __restrict__ src, const int32_t* __restrict__ slot0,
-                            const int32_t* __restrict__ pstride, int n, uint16_t* __restrict__ packed16) {
+                            const int32_t* __restrict__ pstride, const float* __restrict__ factor, int n,
+                            uint16_t* __restrict__ packed16) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const float w = src[t] >= 0 ? plain[src[t]] : 0.0f;
+    const float w = src[t] >= 0 ? kpn_mul_nofma(plain[src[t]], factor[t]) : 0.0f;   // the host packer's product, bit for bit
     float one[8] = {w, 0, 0, 0, 0, 0, 0, 0};
     kpn_bf16x8 h, m, l;
     kpn_split3(one, h, m, l);
@@ -342,48 +350,67 @@ __global__ void k_pack_scalars(const float* __restrict__ plain, size_t w0, size_
     (void)w0;
 }
 
+// The gather maps of the device packer live in device memory, so they are kept PER DEVICE (a process that renders on two
+// GPUs packs on both); built on first use for the device that is current at the call.
+namespace {
+struct DevicePackMaps {
+    int32_t* map = nullptr;
+    int32_t *hsrc = nullptr, *hslot = nullptr, *hstride = nullptr;
+    float* hfactor = nullptr;
+    int n_helem = 0;
+    int rc = KPN_OK;
+};
+DevicePackMaps* device_pack_maps() {
+    static std::mutex mtx;
+    static std::vector<DevicePackMaps*> per_device;   // index = HIP device ordinal
+    int dev = 0;
+#ifndef KPN_SIMT_EMU
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+#endif
+    std::lock_guard<std::mutex> lock(mtx);
+    if ((size_t)dev >= per_device.size()) per_device.resize((size_t)dev + 1, nullptr);
+    if (per_device[dev]) return per_device[dev];
+    DevicePackMaps* M = per_device[dev] = new DevicePackMaps();
+    const size_t np = kpn_plain_weight_floats(), nk = kpn_packed_weight_floats();
+    std::vector<float> ramp(np), pk(nk, 0.0f);
+    for (size_t i = 0; i < np; ++i) ramp[i] = (float)(i + 1);  // exact in fp32 (np < 2^24)
+    if (kpn_pack_weights(ramp.data(), pk.data()) != KPN_OK) { M->rc = KPN_EINVAL; return M; }
+    std::vector<int32_t> map(nk);
+    // (the four derived scalars are not gathers: k_pack_scalars writes them; the split-bf16 region has its own maps)
+    for (size_t i = 0; i < nk; ++i) map[i] = (pk[i] >= 1.0f && pk[i] <= (float)np) ? (int32_t)pk[i] - 1 : -1;
+    for (int i = 0; i < 4; ++i) map[kpn_scalar_off() + i] = -1;
+    auto up = [&](auto** d, const auto& h) {
+        if (hipMalloc((void**)d, h.size() * sizeof(h[0])) != hipSuccess ||
+            hipMemcpy(*d, h.data(), h.size() * sizeof(h[0]), hipMemcpyHostToDevice) != hipSuccess) M->rc = KPN_ELAUNCH;
+    };
+    up(&M->map, map);
+    // split-bf16 region: per element its source weight, the folded factor, the u16 slot of its first piece and the piece stride
+    std::vector<int32_t> hsrc, hslot, hstride;
+    std::vector<float> hfactor;
+    size_t w_off[4];
+    for (int l = 0; l < 4; ++l) { size_t o = 0; for (int k = 0; k < P_G1_0 + l; ++k) o += (size_t)plain_dims[k][0] * plain_dims[k][1] + plain_dims[k][0]; w_off[l] = o; }
+    walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
+        hsrc.push_back((int32_t)src);
+        hfactor.push_back(hseg_weight_factor(hseg, src, w_off));
+        hslot.push_back((int32_t)hseg_slot(hseg, el, 0));
+        hstride.push_back((int32_t)(hseg_slot(hseg, el, 1) - hseg_slot(hseg, el, 0)));
+    });
+    M->n_helem = (int)hsrc.size();
+    up(&M->hsrc, hsrc); up(&M->hslot, hslot); up(&M->hstride, hstride); up(&M->hfactor, hfactor);
+    return M;
+}
+}  // namespace
+
 extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev, void* stream) {
     KPN_REQUIRE(plain_dev && packed_dev, "null pointer");
-    static int32_t* map_dev = nullptr;
-    static int32_t *hsrc_dev = nullptr, *hslot_dev = nullptr, *hstride_dev = nullptr;
-    static int n_helem = 0;
-    static std::mutex mtx;
-    static bool built = false;
-    static int rc = KPN_OK;
-    const size_t np = kpn_plain_weight_floats(), nk = kpn_packed_weight_floats();
-    std::lock_guard<std::mutex> lock(mtx);
-    if (!built) [&] {
-        built = true;
-        std::vector<float> ramp(np), pk(nk, 0.0f);
-        for (size_t i = 0; i < np; ++i) ramp[i] = (float)(i + 1);  // exact in fp32 (np < 2^24)
-        if (kpn_pack_weights(ramp.data(), pk.data()) != KPN_OK) { rc = KPN_EINVAL; return; }
-        std::vector<int32_t> map(nk);
-        // (the four derived scalars are not gathers: k_pack_scalars writes them)
-        for (size_t i = 0; i < nk; ++i) map[i] = (pk[i] >= 1.0f && pk[i] <= (float)np) ? (int32_t)pk[i] - 1 : -1;
-        for (int i = 0; i < 4; ++i) map[kpn_scalar_off() + i] = -1;
-        if (hipMalloc((void**)&map_dev, nk * sizeof(int32_t)) != hipSuccess ||
-            hipMemcpy(map_dev, map.data(), nk * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = KPN_ELAUNCH;
-        // split-bf16 region: per element its source weight, the u16 slot of its first piece and the piece stride
-        std::vector<int32_t> hsrc, hslot, hstride;
-        size_t w_off[4];
-        for (int l = 0; l < 4; ++l) { size_t o = 0; for (int k = 0; k < P_G1_0 + l; ++k) o += (size_t)plain_dims[k][0] * plain_dims[k][1] + plain_dims[k][0]; w_off[l] = o; }
-        walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
-            hsrc.push_back((int32_t)src);
-            hslot.push_back((int32_t)hseg_slot(hseg, el, 0));
-            hstride.push_back((int32_t)(hseg_slot(hseg, el, 1) - hseg_slot(hseg, el, 0)));
-        });
-        n_helem = (int)hsrc.size();
-        auto up = [&](int32_t** d, const std::vector<int32_t>& h) {
-            if (hipMalloc((void**)d, h.size() * sizeof(int32_t)) != hipSuccess ||
-                hipMemcpy(*d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = KPN_ELAUNCH;
-        };
-        up(&hsrc_dev, hsrc); up(&hslot_dev, hslot); up(&hstride_dev, hstride);
-    }();
-    if (rc != KPN_OK || !map_dev) return fail(KPN_ELAUNCH, "could not build the device pack map");
+    const size_t np = kpn_plain_weight_floats();
+    const DevicePackMaps* M = device_pack_maps();
+    if (!M || M->rc != KPN_OK || !M->map) return fail(KPN_ELAUNCH, "could not build the device pack map");
     const int n_gather = kpn_bwd_end();  // everything before the split-bf16 region is a gather
-    KPN_LAUNCH(k_pack_gather, grid1d((int64_t)n_gather, 256), dim3(256), stream, plain_dev, (const int32_t*)map_dev, n_gather, packed_dev);
-    KPN_LAUNCH(k_pack_hseg, grid1d((int64_t)n_helem, 256), dim3(256), stream, plain_dev, (const int32_t*)hsrc_dev,
-               (const int32_t*)hslot_dev, (const int32_t*)hstride_dev, n_helem, reinterpret_cast<uint16_t*>(packed_dev));
+    KPN_LAUNCH(k_pack_gather, grid1d((int64_t)n_gather, 256), dim3(256), stream, plain_dev, (const int32_t*)M->map, n_gather, packed_dev);
+    KPN_LAUNCH(k_pack_hseg, grid1d((int64_t)M->n_helem, 256), dim3(256), stream, plain_dev, (const int32_t*)M->hsrc,
+               (const int32_t*)M->hslot, (const int32_t*)M->hstride, (const float*)M->hfactor, M->n_helem,
+               reinterpret_cast<uint16_t*>(packed_dev));
     auto woff = [](int layer) { size_t o = 0; for (int l = 0; l < layer; ++l) o += (size_t)plain_dims[l][0] * plain_dims[l][1] + plain_dims[l][0]; return o; };
     auto boff = [&](int layer) { return woff(layer) + (size_t)plain_dims[layer][0] * plain_dims[layer][1]; };
     KPN_LAUNCH(k_pack_scalars, dim3(1), dim3(64), stream, plain_dev, woff(P_G2_0), boff(P_G2_0), woff(P_G2_1), boff(P_G2_1),
@@ -598,17 +625,22 @@ static ProfState g_prof;
 #endif
 
 // 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, k_geo_rows)
-// 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16, one tile per wave, two waves per SIMD (k_geo_rows_h): experimental,
-//    unexplained rare wrong tiles
-// 2: the same arithmetic with two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): the default — fp32-class results
-//    (every product term above 2^-24 relative is kept), 1.5x the fp32 kernel's rate, soaked over 1.1e11 row evaluations and
-//    twelve code placements without a differing value (profiles/r02_soak_mode2_*.jsonl)
+// 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16, one tile per wave, two waves per SIMD (k_geo_rows_h): NOT in the
+//    shipped library (unexplained rare wrong tiles); investigation builds only (-DKPN_WITH_MODE1)
+// 2: split-bf16 operands with two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): the default — fp32-class results
+//    (every product term above 2^-24 relative is kept), soaked without a differing value (profiles/*soak*)
 #ifndef KPN_DEFAULT_GEO_ROWS_MODE
 #define KPN_DEFAULT_GEO_ROWS_MODE 2
 #endif
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
-    if (g_geo_rows_mode < 0) { const char* e = getenv("KPN_GEO_ROWS_MODE"); g_geo_rows_mode = e ? atoi(e) : KPN_DEFAULT_GEO_ROWS_MODE; }
+    if (g_geo_rows_mode < 0) {
+        const char* e = getenv("KPN_GEO_ROWS_MODE");
+        g_geo_rows_mode = e ? atoi(e) : KPN_DEFAULT_GEO_ROWS_MODE;
+#ifndef KPN_WITH_MODE1
+        if (g_geo_rows_mode != 0) g_geo_rows_mode = 2;
+#endif
+    }
     return g_geo_rows_mode;
 }
 int pair_grid_blocks() {   // k_geo_rows_h2: one 256-thread workgroup per CU = one wave per SIMD
@@ -670,8 +702,10 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 #else
             kpn_internal_launch_geo_rows_h2(pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, batch.index, batch.tiles_cap);
 #endif
+#ifdef KPN_WITH_MODE1
         else if (geo_rows_mode() == 1)
             KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+#endif
         else
             KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
 #ifndef KPN_SIMT_EMU
@@ -715,7 +749,11 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 }  // namespace
 
 extern "C" int kpn_set_geo_rows_mode(int32_t mode) {
+#ifdef KPN_WITH_MODE1
     KPN_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (fp32 MFMA), 1 (split-bf16 MFMA) or 2 (split-bf16 MFMA, two tiles per wave)");
+#else
+    KPN_REQUIRE(mode == 0 || mode == 2, "mode must be 0 (fp32 MFMA) or 2 (split-bf16 MFMA, two tiles per wave); mode 1 is not part of this build");
+#endif
     g_geo_rows_mode = mode;
     return KPN_OK;
 }

@@ -226,6 +226,22 @@ constexpr int kpn_hseg_off(int seg) {
     return o;
 }
 constexpr int kpn_packed_floats() { return kpn_hseg_off(HSEG_COUNT); }
+// The split-bf16 streams carry the Softplus(beta = 100) of layers1 in log2 units (geo_rows_pair_kernels.hip, KPN_H2_LOG2ACT):
+// a layer whose OUTPUT goes through the activation is scaled by 100 log2(e) (weights here, biases when the kernel stages
+// them), a layer whose INPUT is an activation by ln(2)/100; for layers1.1 and the chained columns of layers1.2 the two cancel.
+#ifndef KPN_H2_LOG2ACT
+#define KPN_H2_LOG2ACT 1
+#endif
+#define KPN_H2_ACT_SCALE 144.269504088896341f      // 100 log2(e)
+#define KPN_H2_ACT_UNSCALE 6.93147180559945309e-3f // ln(2) / 100
+// factor applied to the weight of input column `col` of the layer behind segment `hseg` before it is split into bf16 pieces
+constexpr float kpn_hseg_factor(int hseg, int col) {
+    if (!KPN_H2_LOG2ACT) return 1.0f;
+    if (hseg == HSEG_G1_0A || hseg == HSEG_G1_0B) return KPN_H2_ACT_SCALE;
+    if (hseg == HSEG_G1_1) return 1.0f;
+    if (hseg == HSEG_G1_2) return col < 128 ? 1.0f : KPN_H2_ACT_SCALE;   // columns 128..135: the sampled hd channels
+    return KPN_H2_ACT_UNSCALE;                                           // HSEG_G1_3: no activation behind it
+}
 
 // Row scratch written by k_geo_rows and read by k_fuse_color: per work item (tile, view) KPN_ROW_SLABS
 // slabs of [64 lanes] float4.  Slabs 0..7: the lane's 32 registers of the 64-vector (block b = slab/4);

@@ -469,8 +469,8 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
 
 def set_geo_rows_mode(mode):
     """Rows kernel of the field's first MLP (kpn_set_geo_rows_mode): 2 (default) = split-bf16 operands on the bf16 MFMA, two
-    tiles per wave, one wave per SIMD — fp32-class results at 1.5x the rate; 0 = fp32 MFMA; 1 = the earlier split-bf16 kernel
-    (experimental: DESIGN.md section 9.2)."""
+    tiles per wave, one wave per SIMD — fp32-class results; 0 = fp32 MFMA.  (1, the earlier one-tile split-bf16 kernel, is not
+    part of the shipped library: DESIGN.md section 9.2.)"""
     L = kl.get_library()
     L.check(L.kpn_set_geo_rows_mode(int(mode)))
 
