@@ -30,8 +30,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# --geo-rows-mode 1 / 2: six bf16 MFMAs (2.5 PFLOP/s dense peak) per fp32 product term set -> fp32-equivalent roof
-BF16_SPLIT_PEAK_TFLOPS = 2500.0 / 6.0
+# split-operand rows kernels: N 16-bit MFMAs (2.5 PFLOP/s dense peak, bf16 and fp16 alike) per fp32 product term set ->
+# fp32-equivalent roof = 2500 / N: mode 2 (three bf16 pieces) N = 6, mode 3 (two fp16 pieces, the default) N = 4
+SPLIT_PRODUCTS = {2: 6, 3: 4}
+ROWS_KERNEL = {0: "k_geo_rows", 2: "k_geo_rows_h2", 3: "k_geo_rows_f2"}
+ROWS_DTYPE = {0: "f32",
+              2: "f32 (dominant kernel: every fp32 operand as three bf16 pieces, six bf16-MFMA products per term set, fp32 accumulation: "
+                 "all terms above 2^-24 relative kept; everything else fp32)",
+              3: "f32 (dominant kernel: every fp32 operand as two fp16 pieces (22 bits, the residual formed exactly), four fp16-MFMA "
+                 "products per term set, fp32 accumulation: measured as close to fp64 as an fp32 fma chain; everything else fp32)"}
+
+
+def rows_peak_tflops(mode):
+    return FP32_MFMA_PEAK_TFLOPS if mode == 0 else 2500.0 / SPLIT_PRODUCTS[mode]
 
 
 def parse():
@@ -52,10 +63,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (dense mask / round-1 scene / training) results")
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
-    ap.add_argument("--geo-rows-mode", type=int, default=2, choices=[0, 1, 2],
-                    help="rows kernel of the field's first MLP: 2 = split-bf16 operands on the bf16 MFMA, two tiles per wave, one wave "
-                         "per SIMD (the library's default: fp32-class results); 0 = fp32 MFMA; 1 = the earlier split-bf16 kernel "
-                         "(experimental, DESIGN.md section 9.2)")
+    ap.add_argument("--geo-rows-mode", type=int, default=3, choices=[0, 2, 3],
+                    help="rows kernel of the field's first MLP: 3 = two fp16 pieces per operand, four products on the fp16 MFMA, two "
+                         "tiles per wave, one wave per SIMD (the library's default: fp32-class results); 2 = three bf16 pieces, six "
+                         "products (fp32's exponent range); 0 = fp32 MFMA")
     ap.add_argument("--no-coarse-reuse", action="store_true",
                     help="evaluate the field at all Sc+Sf merged samples in the fine pass, as the reference does (default: the "
                          "coarse samples' values are taken from the coarse pass: bit-identical outputs, Sc+Sf instead of "
@@ -276,21 +287,21 @@ def main():
         tj = os.path.join(ROOT, "profiles", "geo_rows_traffic.json")
         if os.path.exists(tj) and launches.value > 0:
             tr = json.load(open(tj))
-            per_row = tr.get("k_geo_rows_h2", tr)["hbm_bytes_per_row"] if args.geo_rows_mode == 2 else tr["hbm_bytes_per_row"]
-            traffic = per_row * rows.value / launches.value
+            entry = tr.get(ROWS_KERNEL[args.geo_rows_mode]) if args.geo_rows_mode != 0 else tr
+            if entry:
+                traffic = entry["hbm_bytes_per_row"] * rows.value / launches.value
         alpha_mean = float(out["alpha_fine" if fine else "alpha"].mean())
         rows_per_step = rows.value / max(1, args.steps)
         valid_frac = rows_per_step / (args.views * rays_per_step * evals_per_ray)
         torch.cuda.synchronize()
         peak_alloc = torch.cuda.max_memory_allocated(dev)
-        peak = BF16_SPLIT_PEAK_TFLOPS if args.geo_rows_mode >= 1 else FP32_MFMA_PEAK_TFLOPS
+        peak = rows_peak_tflops(args.geo_rows_mode)
         line = {
             "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.geo_rows_mode == 0 else "f32 (dominant kernel: every fp32 operand as three bf16 pieces, six bf16-MFMA products per "
-                                                           "term set, fp32 accumulation: all terms above 2^-24 relative kept; everything else fp32)",
+            "dtype": ROWS_DTYPE[args.geo_rows_mode],
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if (fine and args.views == 3 and args.samples == 64 and res == 512) else 'custom'}: "
                                    f"{res}x{res} novel view, {args.views} source views {res}x{res}, "
@@ -311,13 +322,14 @@ def main():
                                       + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
                        "dist_world_size": (dist.get_world_size() if world > 1 else 1),
                        "dist_backend": (args.dist_backend if world > 1 else None)},
-            "roofline": {"kernel": ("k_geo_rows", "k_geo_rows_h", "k_geo_rows_h2")[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "surplus_launches": surplus.value,
-                         "note": "achieved = algorithmic fp32 FLOP (140,160 per row) / kernel time; in the split-bf16 modes the matrix pipe executes 6 bf16 products per fp32 product term set, so the roof is the dense bf16 peak / 6; the row scratch between the rows kernel and k_fuse_color is capped ("
+                         "traffic_source": "profiles/geo_rows_traffic.json: PMC (FETCH_SIZE, WRITE_SIZE) bytes per row from separate rocprofv3 --pmc passes of this kernel, times this run's rows per launch" if traffic is not None else None,
+                         "note": "achieved = algorithmic fp32 FLOP (140,160 per row) / kernel time; in the split-operand modes the matrix pipe executes N 16-bit products per fp32 product term set (mode 3: N = 4, mode 2: N = 6), so the roof is the dense 16-bit peak / N; the row scratch between the rows kernel and k_fuse_color is capped ("
                                  + f"{L.kpn_row_scratch_cap_bytes() / 2**30:.1f} GiB) and reused by batches of a pass; the worst-case "
                                  "number of batches is launched and the surplus ones return at once (a few us each): "
                                  "`launches` / `avg_launch_ms` cover the launches that processed rows, a rocprofv3 average "
@@ -348,15 +360,16 @@ def main():
                     sec[f"partly_empty_hull_density_bias_{int(db)}"] = {
                         "ms_per_frame": ms2, "ms_per_frame_without_the_zero_density_short_path": ms3,
                         "rays_per_sec": rays_per_step / (ms2 * 1e-3)}
-            if args.geo_rows_mode != 0:
-                # the same frame with the fp32-MFMA rows kernel (kpn_set_geo_rows_mode(0)): roof 157.3 TFLOP/s
-                L.check(L.kpn_set_geo_rows_mode(0))
+            # the same frame with the other rows kernels: three bf16 pieces (mode 2, roof 2500 / 6) and fp32 MFMA (mode 0, roof 157.3)
+            for m, key in ((2, "bf16x3_rows_kernel_mode2"), (0, "fp32_mfma_rows_kernel_mode0"), (3, "fp16x2_rows_kernel_mode3")):
+                if m == args.geo_rows_mode:
+                    continue
+                L.check(L.kpn_set_geo_rows_mode(m))
                 ms2, rows2, kms, ktf = time_frames(L, ops, torch, scene, w, res, args.samples, fine, steps=max(2, min(args.steps, 5)), with_kernel=True)
                 L.check(L.kpn_set_geo_rows_mode(args.geo_rows_mode))
-                sec["fp32_mfma_rows_kernel_mode0"] = {"ms_per_frame": ms2, "rays_per_sec": rays_per_step / (ms2 * 1e-3),
-                                                      "roofline": {"kernel": "k_geo_rows", "bound": "mfma", "achieved": ktf,
-                                                                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                                   "frac": ktf / FP32_MFMA_PEAK_TFLOPS, "avg_launch_ms": kms}}
+                sec[key] = {"ms_per_frame": ms2, "rays_per_sec": rays_per_step / (ms2 * 1e-3),
+                            "roofline": {"kernel": ROWS_KERNEL[m], "bound": "mfma", "achieved": ktf, "peak": rows_peak_tflops(m),
+                                         "unit": "TFLOP/s", "frac": ktf / rows_peak_tflops(m), "avg_launch_ms": kms}}
             if args.views == 3:
                 sec["training_step_configs3"] = time_training(ops, torch, dev, sd)
             line["secondary"] = sec

@@ -160,16 +160,21 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
                        float noise_std, const float* d_out, float* d_plain, float* d_geo0, float* d_geo1, float* d_tex,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* Rows kernel of the dominant stage (MLPUNet.layers1 per (point, view) row, reference src/utils.py:691-720):
- *   2 = v_mfma_f32_32x32x16_bf16 with every fp32 operand carried as three bf16 pieces and six products per term set (all
- *       terms above 2^-24 relative: fp32-class results), two 32-point tiles per wavefront, one wavefront per SIMD
- *       (k_geo_rows_h2).  The default: same parity bar as mode 0 against the reference goldens, 1.5x its rate.
+/* Rows kernel of the dominant stage (MLPUNet.layers1 per (point, view) row, reference src/utils.py:691-720), all with
+ * fp32 accumulation and the same parity bar against the reference goldens:
+ *   3 = v_mfma_f32_32x32x16_f16 with every fp32 operand carried as two fp16 pieces (x - fp16(x) is formed exactly by one
+ *       v_fma_mix_f32) and four products per term set; two 32-point tiles per wavefront, one wavefront per SIMD
+ *       (k_geo_rows_f2).  The default.  Operands must stay within fp16's range: a pre-activation beyond 454 (natural units)
+ *       or a packed weight beyond 65504 makes the row NaN (never silently wrong); kpn_packed_f16_range_check counts such weights.
+ *   2 = v_mfma_f32_32x32x16_bf16, three bf16 pieces, six products (k_geo_rows_h2): the same structure in fp32's exponent range.
  *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands, k_geo_rows).
- *   1 = the earlier split-bf16 kernel (one tile per wavefront, two wavefronts per SIMD): experimental, rare wrong
- *       half-tiles on some builds; kept for comparison.
- * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 2). */
+ *   (1, an earlier one-tile-per-wavefront kernel, is refused: not part of the shipped library.)
+ * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 3). */
 int kpn_set_geo_rows_mode(int32_t mode);
 int kpn_get_geo_rows_mode(void);
+/* *beyond = number of packed layers1 weights that fp16 cannot hold (0 = rows mode 3 is usable with these weights).
+ * Reads four floats back from the device and synchronises `stream`. */
+int kpn_packed_f16_range_check(const float* packed_weights_dev, void* stream, int32_t* beyond);
 
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).

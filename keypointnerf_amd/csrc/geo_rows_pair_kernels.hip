@@ -35,9 +35,38 @@
 #else
 #define KPN_H2_PIN_ACC(v) asm volatile("" : "+a"(v))
 #endif
-constexpr int kpn_h2_pa(int pr) { return pr == 2 || pr == 3 ? 1 : (pr == 5 ? 2 : 0); }   // A piece of product pr: h h m m h l
-constexpr int kpn_h2_pb(int pr) { return pr == 1 || pr == 3 ? 1 : (pr == 4 ? 2 : 0); }   // B piece:                h m h m l h
+typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- two operand schemes (SC) ----
+//   kpn_sc_bf16x3 (rows mode 2): x = h + m + l in bf16 (8 + 8 + 8 significant bits), six products per term set
+//                 hh hm mh mm hl lh (everything above 2^-24 relative), v_mfma_f32_32x32x16_bf16.  fp32's exponent range.
+//   kpn_sc_f16x2  (rows mode 3, the default): x = h + l in fp16 (11 + 11 bits; the residual x - h is formed exactly by ONE
+//                 v_fma_mix_f32 per value, which reads the fp16 half in place), four products hh hl lh ll,
+//                 v_mfma_f32_32x32x16_f16: 1.5x fewer MFMAs and 2 instead of 5.5 split instructions per value.  Measured
+//                 (scripts/f16_split_probe.hip, MI355X): the residual is always exact, |x - (h + l)| <= 2^-23 |x| with an
+//                 absolute floor of 2^-24 (fp16's subnormal quantum; the f16 MFMA honours subnormal inputs), a K = 256 dot
+//                 product is as close to fp64 as the bf16x3 form and the fp32 fma chain (1.6e-7 / 1.8e-7 / 2.0e-7 of the
+//                 sum of |terms|) — EXCEPT for operands far below 1e-2, where the floor shows: layers1.3's weights, scaled
+//                 by ln(2)/100 for the log2-unit activation, are therefore packed times 2^10 and the rows multiplied by 2^-10
+//                 when they are stored.  The price is fp16's range: an operand beyond 65504 (a pre-activation beyond 454 in
+//                 natural units, a packed weight beyond 65504) becomes inf and the row NaN — loudly wrong, never silently;
+//                 kpn_set_geo_rows_mode(2) is the range-safe alternative.
+struct kpn_sc_bf16x3 {
+    static constexpr int NP = 3, NPROD = 6, NSLICE = 6;
+    static constexpr int pa(int pr) { return pr == 2 || pr == 3 ? 1 : (pr == 5 ? 2 : 0); }   // A piece of product pr: h h m m h l
+    static constexpr int pb(int pr) { return pr == 1 || pr == 3 ? 1 : (pr == 4 ? 2 : 0); }   // B piece:                h m h m l h
+    static constexpr int hseg_base() { return kpn_hseg_off(0); }
+    static constexpr float out_up = 1.0f, out_down = 1.0f;
+    static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
+};
+struct kpn_sc_f16x2 {
+    static constexpr int NP = 2, NPROD = 4, NSLICE = 4;
+    static constexpr int pa(int pr) { return pr >> 1; }                                        // h h l l
+    static constexpr int pb(int pr) { return pr & 1; }                                         // h l h l
+    static constexpr int hseg_base() { return kpn_fseg_off(0); }
+    static constexpr float out_up = KPN_F16_ROW_SCALE, out_down = 1.0f / KPN_F16_ROW_SCALE;    // layers1.3 is packed times 2^10
+    static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
+};
 // ---- the operand production: one volatile asm BLOCK per slice ----
 // The VALU work between two MFMAs is budgeted in issue slots (five hide under one v_mfma_f32_32x32x16_bf16 at one wave per
 // SIMD, a transcendental counts about two: scripts/mfma16_filler_probe.hip), so what hipcc selects matters as much as where it
@@ -54,16 +83,33 @@ constexpr int kpn_h2_pb(int pr) { return pr == 1 || pr == 3 ? 1 : (pr == 4 ? 2 :
 // use of its result, and across blocks the MFMA does.  The accumulators are read by the blocks themselves
 // (v_accvgpr_read_b32 from an "a" operand; left to the compiler every value was read twice): an accumulator block is final
 // at least three MFMA issues (96 cycles) before its first read (static_assert in kpn_mfma16_layer2).
-typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef KPN_SIMT_EMU
 __device__ __forceinline__ kpn_bf16x8 kpn_as_bf16x8(kpn_u32x4 v) { return __builtin_bit_cast(kpn_bf16x8, v); }
 #define KPN_H2_USE(v) asm volatile("" ::"v"(v))      // the value exists before this point; defines nothing (no assumed hazard)
+typedef _Float16 kpn_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ kpn_f32x16 kpn_sc_bf16x3::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kpn_bf16x8, a), __builtin_bit_cast(kpn_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ kpn_f32x16 kpn_sc_f16x2::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(kpn_f16x8, a), __builtin_bit_cast(kpn_f16x8, b), c, 0, 0, 0);
+}
 #else
 static inline kpn_bf16x8 kpn_as_bf16x8(kpn_u32x4 v) { kpn_bf16x8 r; memcpy(&r, &v, 16); return r; }
 #define KPN_H2_USE(v) ((void)0)
 static inline uint32_t kpn_emu_cvt_pk(float lo, float hi) { return (uint32_t)kpn_f2bf(lo) | ((uint32_t)kpn_f2bf(hi) << 16); }
 static inline float kpn_emu_bf_lo(uint32_t pk) { return kpn_bf2f((uint16_t)(pk & 0xffffu)); }
 static inline float kpn_emu_bf_hi(uint32_t pk) { return kpn_bf2f((uint16_t)(pk >> 16)); }
+static inline uint32_t kpn_emu_cvt_pk_f16(float lo, float hi) { return (uint32_t)kpn_f2h(lo) | ((uint32_t)kpn_f2h(hi) << 16); }
+static inline float kpn_emu_h_lo(uint32_t pk) { return kpn_h2f((uint16_t)(pk & 0xffffu)); }
+static inline float kpn_emu_h_hi(uint32_t pk) { return kpn_h2f((uint16_t)(pk >> 16)); }
+inline kpn_f32x16 kpn_sc_bf16x3::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
+    kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);
+    return simt_mfma_f32_32x32x16_bf16(av, bv, c);
+}
+inline kpn_f32x16 kpn_sc_f16x2::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
+    kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);   // eight 16-bit patterns
+    return simt_mfma_f32_32x32x16_f16(av, bv, c);
+}
 #endif
 
 // Softplus(beta 100, threshold 20) in LOG2 UNITS (KPN_H2_LOG2ACT, kpn_common.h; the default): the packer folds 100 log2(e)
@@ -79,10 +125,43 @@ static inline float kpn_emu_bf_hi(uint32_t pk) { return kpn_bf2f((uint16_t)(pk >
 //   0: read u0 u1, clamp both, exp 0     1: exp 1, 1 + e0, 1 + e1, log 0     2: log 1, max 0, max 1, hi pieces
 //   3: unpack hi 0/1, residual 0/1       4: mid pieces, unpack 0/1, residual 0   5: residual 1, lo pieces
 // Without ACT: 0: x0 = v0()   1: x1 = v1()   2: hi pieces   3..5 as above.
+// fp16 double split (kpn_sc_f16x2), FOUR slices, issue slots 6 6 5 3 (measured: a pair's 4 MFMAs + these slices run at 32.1
+// cycles per MFMA, scripts/f16_split_probe.hip):
+//   0, 1: as above     2: log 1, max 0, max 1, hi pieces (v_cvt_pk_f16_f32)     3: x0 - h0, x1 - h1 (v_fma_mix_f32), lo pieces
 struct kpn_h2_pair { float x0, x1, e0, e1; uint32_t pk; };
-template <bool ACT, int Q, int J, class V0, class V1>
-__device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[3], V0&& v0, V1&& v1) {
-    if constexpr (Q == 0) {
+template <class SC, bool ACT, int Q, int J, class V0, class V1>
+__device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC::NP], V0&& v0, V1&& v1) {
+    constexpr bool F16 = SC::NP == 2;
+    if constexpr (F16 && Q == 2) {
+        if constexpr (ACT) {
+#ifndef KPN_SIMT_EMU
+            static_assert(KPN_H2_LOG2ACT, "the fp16 scheme carries the activation in log2 units");
+            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3\n\tv_cvt_pk_f16_f32 %4, %0, %1"
+                         : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
+#else
+            p.e1 = kpn_log2(p.e1);
+            p.x0 = fmaxf(p.x0, p.e0); p.x1 = fmaxf(p.x1, p.e1);
+            p.pk = kpn_emu_cvt_pk_f16(p.x0, p.x1);
+#endif
+        } else {
+#ifndef KPN_SIMT_EMU
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p.pk) : "v"(p.x0), "v"(p.x1));
+#else
+            p.pk = kpn_emu_cvt_pk_f16(p.x0, p.x1);
+#endif
+        }
+        dst[0][J] = p.pk;
+    } else if constexpr (F16 && Q == 3) {
+#ifndef KPN_SIMT_EMU
+        uint32_t lo;
+        asm volatile("v_fma_mix_f32 %1, %3, -1.0, %1 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(lo), "+v"(p.x0), "+v"(p.x1) : "v"(p.pk));
+        dst[1][J] = lo;
+#else
+        p.x0 = p.x0 - kpn_emu_h_lo(p.pk); p.x1 = p.x1 - kpn_emu_h_hi(p.pk);
+        dst[1][J] = kpn_emu_cvt_pk_f16(p.x0, p.x1);
+#endif
+    } else if constexpr (Q == 0) {
         if constexpr (ACT) {
             const float a0 = v0(), a1 = v1();             // two accumulator elements (AGPRs)
 #ifndef KPN_SIMT_EMU
@@ -180,16 +259,19 @@ __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[3]
 struct kpn_h2_identity { static constexpr int at(int p) { return p; } };
 //   SMAP::at(position) = step of the weight stream executed at that position of the chain (the order of a layer's K steps is
 //   free; val_fn / stage_fn are called with positions)
-template <int KS16, int NOB, int ACT, bool HAVE0, bool NEXT, class SMAP = kpn_h2_identity, class ValFn, class StageFn, class TailFn, class NextFn>
+template <class SC, int KS16, int NOB, int ACT, bool HAVE0, bool NEXT, class SMAP = kpn_h2_identity, class ValFn, class StageFn, class TailFn, class NextFn>
 __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg, int lane, ValFn&& val_fn, StageFn&& stage_fn,
                                                   TailFn&& tail_fn, NextFn&& next_fn, kpn_f32x16 (&acc)[2][NOB],
-                                                  kpn_u32x4 (&x0)[2][3], kpn_u32x4 (&xn)[2][3]) {
-    static_assert(NOB == 4 || NOB == 2, "6 or 3 MFMAs per operand pair");
+                                                  kpn_u32x4 (&x0)[2][SC::NP], kpn_u32x4 (&xn)[2][SC::NP]) {
+    static_assert(NOB == 4 || NOB == 2, "NPROD * NOB / 4 MFMAs per operand pair");
     static_assert(!NEXT || NOB == 4, "the look-ahead needs blocks 0/1 in the first half of a step");
+    constexpr int NP = SC::NP, NPROD = SC::NPROD, NSLICE = SC::NSLICE;
     constexpr int H0 = NOB / 2, H1 = NOB - H0;
-    constexpr int MF = 12 * NOB, PP = MF / 8;
-    kpn_u32x4 xp[2][2][3];                               // [buffer][tile][piece]: four dwords = eight bf16
-    kpn_bf16x8 wa[3][H0], wb[3][H1];                     // the A pieces of the two halves of the output blocks
+    constexpr int MF = 2 * NPROD * NOB, PP = MF / 8;     // MFMAs per step; MFMA gaps per operand pair (8 pairs per step)
+    constexpr int SPG = NSLICE / PP;                     // slices per gap: 1 (NOB = 4) or 2 (NOB = 2)
+    static_assert(SPG * PP == NSLICE && (SPG == 1 || SPG == 2), "whole slices per gap");
+    kpn_u32x4 xp[2][2][NP];                              // [buffer][tile][piece]: four dwords = eight 16-bit values
+    kpn_f32x4 wa[NP][H0], wb[NP][H1];                    // the A pieces of the two halves of the output blocks (raw dwords)
     kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, 0u};
     // A half's pieces are contiguous ([step][block][piece][lane]): one scalar base in its middle, immediate offsets of
     // -3..+2 KB (the 13-bit signed range of global_load), the lane offset in one register for the whole kernel.  The base is
@@ -201,9 +283,9 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     const float* gp = hseg;
     auto load_half = [&](int s, int ob0, int n, auto& w) {
 #ifdef KPN_DBG_H2_SAMEW   // timing experiment (wrong results): every step reads the weights of step 0 -> the stream stays in L1
-        const int pos = (ob0 * 3 + 3) * (64 * 4);
+        const int pos = (ob0 * NP + NP) * (64 * 4);
 #else
-        const int pos = s * (3 * NOB * 64 * 4) + (ob0 * 3 + 3) * (64 * 4);   // s: stream step
+        const int pos = s * (NP * NOB * 64 * 4) + (ob0 * NP + NP) * (64 * 4);   // s: stream step
 #endif
         gp += pos - prev_pos;
         prev_pos = pos;
@@ -212,19 +294,19 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
 #pragma unroll
         for (int k = 0; k < n; ++k)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) w[pc][k] = kpn_as_bf16x8(src[(k * 3 + pc - 3) * 64]);
+            for (int pc = 0; pc < NP; ++pc) w[pc][k] = src[(k * NP + pc - NP) * 64];
     };
     // MFMA number m of a step: half, then product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi — the order k_geo_rows_h
     // uses per accumulator), then block, then tile: the accumulators of a half rotate, consecutive MFMAs are independent
-    auto mfma = [&](auto mi, const kpn_u32x4 (&x)[2][3]) {
+    auto mfma = [&](auto mi, const kpn_u32x4 (&x)[2][NP]) {
         constexpr int m = decltype(mi)::value;
-        if constexpr (m < 12 * H0) {
+        if constexpr (m < 2 * NPROD * H0) {
             constexpr int prd = m / (2 * H0), k = (m / 2) % H0, t = m % 2;
-            acc[t][k] = KPN_MFMA16(wa[kpn_h2_pa(prd)][k], kpn_as_bf16x8(x[t][kpn_h2_pb(prd)]), acc[t][k]);
+            acc[t][k] = SC::mfma(wa[SC::pa(prd)][k], x[t][SC::pb(prd)], acc[t][k]);
             KPN_H2_PIN_ACC(acc[t][k]);
         } else {
-            constexpr int mm = m - 12 * H0, prd = mm / (2 * H1), k = (mm / 2) % H1, t = mm % 2;
-            acc[t][H0 + k] = KPN_MFMA16(wb[kpn_h2_pa(prd)][k], kpn_as_bf16x8(x[t][kpn_h2_pb(prd)]), acc[t][H0 + k]);
+            constexpr int mm = m - 2 * NPROD * H0, prd = mm / (2 * H1), k = (mm / 2) % H1, t = mm % 2;
+            acc[t][H0 + k] = SC::mfma(wb[SC::pa(prd)][k], x[t][SC::pb(prd)], acc[t][H0 + k]);
             KPN_H2_PIN_ACC(acc[t][H0 + k]);
         }
     };
@@ -233,7 +315,7 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
         constexpr int t = decltype(ti)::value, j = decltype(ji)::value, q = decltype(qi)::value;
         constexpr bool act = decltype(sn)::value < ACT;
         if constexpr (!act && q < 3) stage_fn(sn, ti, ji, qi);
-        kpn_h2_slice<act, q, j>(pr, xp[b][t], [&]() { return val_fn(sn, ti, kpn_ic<2 * j>{}); }, [&]() { return val_fn(sn, ti, kpn_ic<2 * j + 1>{}); });
+        kpn_h2_slice<SC, act, q, j>(pr, xp[b][t], [&]() { return val_fn(sn, ti, kpn_ic<2 * j>{}); }, [&]() { return val_fn(sn, ti, kpn_ic<2 * j + 1>{}); });
     };
     load_half(SMAP::at(0), 0, H0, wa);
     load_half(SMAP::at(0), H0, H1, wb);
@@ -241,11 +323,11 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) xp[0][t][pc] = x0[t][pc];
+            for (int pc = 0; pc < NP; ++pc) xp[0][t][pc] = x0[t][pc];
     } else {   // prologue: nothing to hide the production of step 0 under
         kpn_static_for<0, 8>([&](auto pi) {
             constexpr int t = decltype(pi)::value % 2, j = decltype(pi)::value / 2;
-            kpn_static_for<0, 6>([&](auto qi) { slice(kpn_ic<0>{}, 0, kpn_ic<t>{}, kpn_ic<j>{}, qi); });
+            kpn_static_for<0, NSLICE>([&](auto qi) { slice(kpn_ic<0>{}, 0, kpn_ic<t>{}, kpn_ic<j>{}, qi); });
         });
     }
     KPN_SCHED_BARRIER();
@@ -258,20 +340,22 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
             if constexpr (s + 1 < KS16) {
                 constexpr int pair = m / PP, t = pair % 2, j = pair / 2, q = m % PP;
                 using SN = kpn_ic<s + 1>; using TI = kpn_ic<t>; using JI = kpn_ic<j>;
-                if constexpr (PP == 6) slice(SN{}, nxt, TI{}, JI{}, kpn_ic<q>{});
+                if constexpr (SPG == 1) slice(SN{}, nxt, TI{}, JI{}, kpn_ic<q>{});
                 else { slice(SN{}, nxt, TI{}, JI{}, kpn_ic<2 * q>{}); slice(SN{}, nxt, TI{}, JI{}, kpn_ic<2 * q + 1>{}); }
                 // each half's weight registers are reloaded right after that half's last MFMA has been issued (an MFMA
                 // captures its operands at issue: scripts/mfma16_war_probe.hip)
-                if constexpr (m == 12 * H0 - 1) load_half(SMAP::at(s + 1), 0, H0, wa);
+                if constexpr (m == 2 * NPROD * H0 - 1) load_half(SMAP::at(s + 1), 0, H0, wa);
                 if constexpr (m == MF - 1) load_half(SMAP::at(s + 1), H0, H1, wb);
             } else {
                 tail_fn(mi);
                 if constexpr (NEXT && m >= MF / 2) {      // two slices of the next layer's step 0 per MFMA of the second half
-                    constexpr int i = m - MF / 2, pair = i / 3, t = pair % 2, j = pair / 2, q = 2 * (i % 3);
+                    constexpr int GPP = MF / 16;          // gaps per pair in the second half: 3 (bf16x3) or 2 (fp16x2)
+                    static_assert(2 * GPP == NSLICE, "two slices per gap");
+                    constexpr int i = m - MF / 2, pair = i / GPP, t = pair % 2, j = pair / 2, q = 2 * (i % GPP);
                     auto v0 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j>{}); };
                     auto v1 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j + 1>{}); };
-                    kpn_h2_slice<true, q, j>(pr, xn[t], v0, v1);
-                    kpn_h2_slice<true, q + 1, j>(pr, xn[t], v0, v1);
+                    kpn_h2_slice<SC, true, q, j>(pr, xn[t], v0, v1);
+                    kpn_h2_slice<SC, true, q + 1, j>(pr, xn[t], v0, v1);
                 }
             }
             KPN_SCHED_BARRIER();
@@ -308,9 +392,11 @@ __device__ unsigned long long kpn_h2_cycles[8];
 #else
 #define KPN_H2_BOUNDS
 #endif
-__global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
-                                            const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                            int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
+template <class SC>
+__device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
+                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                       int* __restrict__ tickets, float* __restrict__ xscr, const kpn_batch& batch) {
+    constexpr int NP = SC::NP;
 #if defined(KPN_H2_PAD) && !defined(KPN_SIMT_EMU)   // soak builds: shift every instruction of the kernel by 4 * KPN_H2_PAD bytes
 #pragma unroll
     for (int i = 0; i < KPN_H2_PAD; ++i) asm volatile("s_nop 0");
@@ -331,7 +417,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
             const int sg = i >> 7, k = i & 127;
             // log2-unit activations: the pre-activations of layers1.0-1.2 are kept scaled by 100 log2(e), biases included
-            const float bscale = (KPN_H2_LOG2ACT && sg < 3) ? KPN_H2_ACT_SCALE : 1.0f;
+            const float bscale = (KPN_H2_LOG2ACT && sg < 3) ? KPN_H2_ACT_SCALE : (sg == 3 ? SC::out_up : 1.0f);
             bias_s[sg][k] = k < kpn_seg_bfloats(segs[sg]) ? wp[kpn_seg_boff(segs[sg]) + k] * bscale : 0.0f;
         }
     }
@@ -344,7 +430,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         int wi = 0;
         if (lane == 0) wi = atomicAdd(tickets + 0, 1);
         wi = __shfl(wi, 0);
-        if (wi >= nwork) break;
+        if (wi >= nwork) return;
         const int pair = wi / sc.V, v = wi - pair * sc.V;
         const bool has1 = 2 * pair + 1 < nbt;              // an odd batch ends in half a pair: tile 1 is computed, not stored
         const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
@@ -376,9 +462,9 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         KPN_H2_STAMP(0);
         // ---- layers1.0 as ONE 16-step chain (HSEG_G1_0A and HSEG_G1_0B are adjacent, same step size): steps 0-11 one
         //      keypoint each (7 encoding values + a zero slot), steps 12-15 eight geo0 channels each ----
-        static_assert(kpn_hseg_off(HSEG_G1_0B) == kpn_hseg_off(HSEG_G1_0A) + 12 * kpn_hseg_step_floats(HSEG_G1_0A), "adjacent segments");
+        static_assert(kpn_xseg_off(HSEG_G1_0B, NP) == kpn_xseg_off(HSEG_G1_0A, NP) + 12 * kpn_xseg_step_floats(HSEG_G1_0A, NP), "adjacent segments");
         kpn_f32x16 a0[2][4], a1[2][4];
-        kpn_u32x4 xa[2][3], xb[2][3];                       // step-0 operands handed from one layer to the next
+        kpn_u32x4 xa[2][NP], xb[2][NP];                       // step-0 operands handed from one layer to the next
         {
             const float* E = tb + KPN_TBL_EXT;
             float cx[2], cy[2], cz[2];
@@ -458,7 +544,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
             kpn_static_for<0, 10>([&](auto gi) {
                 pe_stage(kpn_ic<0>{}, kpn_ic<0>{}, gi); pe_stage(kpn_ic<0>{}, kpn_ic<1>{}, gi);
             });
-            kpn_mfma16_layer2<16, 4, 0, false, KPN_H2_LOOKAHEAD, kpn_h2_l0_order>(wp + kpn_hseg_off(HSEG_G1_0A), lane,
+            kpn_mfma16_layer2<SC, 16, 4, 0, false, KPN_H2_LOOKAHEAD, kpn_h2_l0_order>(wp + kpn_xseg_off(HSEG_G1_0A, NP), lane,
                 [&](auto pi, auto ti, auto ei) -> float {       // value e of the step at position p
                     constexpr int s = kpn_h2_l0_order::at(decltype(pi)::value), t = decltype(ti)::value, e = decltype(ei)::value, b = s & 1;
                     if constexpr (s < 12) {
@@ -518,7 +604,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         float4 hraw[2][4];                                  // the four taps of the 4 hd channels of this half (layers1.2, step 8)
         float hd[2][4];
         kpn_taps tp1[2];
-        kpn_mfma16_layer2<8, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_1), lane,
+        kpn_mfma16_layer2<SC, 8, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_xseg_off(HSEG_G1_1, NP), lane,
             [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
                 return a0[t][s / 2][(s % 2) * 8 + e];
@@ -553,7 +639,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
         KPN_H2_STAMP(2);
         kpn_f32x16 acc[2][2];
         float4 rec0[2], rec1[2];
-        kpn_mfma16_layer2<9, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_hseg_off(HSEG_G1_2), lane,
+        kpn_mfma16_layer2<SC, 9, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_xseg_off(HSEG_G1_2, NP), lane,
             [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
                 if constexpr (s < 8) return a1[t][s / 2][(s % 2) * 8 + e];
@@ -570,7 +656,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
             [&](auto ti, auto ei) -> float { return a2[decltype(ti)::value][0][decltype(ei)::value]; },
             a2, xa, xb);
         KPN_H2_STAMP(3);
-        kpn_mfma16_layer2<8, 2, 8, KPN_H2_LOOKAHEAD, false>(wp + kpn_hseg_off(HSEG_G1_3), lane,
+        kpn_mfma16_layer2<SC, 8, 2, 8, KPN_H2_LOOKAHEAD, false>(wp + kpn_xseg_off(HSEG_G1_3, NP), lane,
             [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
                 return a2[t][s / 2][(s % 2) * 8 + e];
@@ -584,10 +670,24 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd)
-                    dst[t][(b * 4 + qd) * 64] =
-                        make_float4(acc[t][b][4 * qd + 0], acc[t][b][4 * qd + 1], acc[t][b][4 * qd + 2], acc[t][b][4 * qd + 3]);
+                    dst[t][(b * 4 + qd) * 64] =   // (the fp16 scheme's layers1.3 is packed times 2^10: exact power-of-two unscale)
+                        make_float4(acc[t][b][4 * qd + 0] * SC::out_down, acc[t][b][4 * qd + 1] * SC::out_down,
+                                    acc[t][b][4 * qd + 2] * SC::out_down, acc[t][b][4 * qd + 3] * SC::out_down);
             dst[t][8 * 64] = rec0[t];
             dst[t][9 * 64] = rec1[t];
         }
     }
+}
+
+// rows mode 2: three bf16 pieces, six products (fp32's exponent range)
+__global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                            const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                            int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
+    kpn_geo_rows_pair_body<kpn_sc_bf16x3>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
+}
+// rows mode 3 (the default): two fp16 pieces, four products
+__global__ KPN_H2_BOUNDS void k_geo_rows_f2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                            const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                            int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
+    kpn_geo_rows_pair_body<kpn_sc_f16x2>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
 }

@@ -18,8 +18,8 @@
 #ifdef KPN_SIMT_EMU
 #include "geo_rows_pair_kernels.hip"   // the device build compiles this kernel as its own translation unit (geo_rows_pair_tu.hip)
 #else
-extern "C" void kpn_internal_launch_geo_rows_h2(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
-                                                const int* list, const int* count, int* tickets, float* xscr, int batch_index, int tiles_cap);
+extern "C" void kpn_internal_launch_geo_rows_pair(int mode, int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
+                                                  const int* list, const int* count, int* tickets, float* xscr, int batch_index, int tiles_cap);
 #endif
 #include "field_bwd_kernels.hip"
 #include "fuse_bwd_kernels.hip"
@@ -155,18 +155,22 @@ void walk_hsegments(const size_t (&w_off)[4], Emit emit) {
                   [&](size_t el, int64_t src) { emit(HSEG_G1_2, el, src); });
     walk_hsegment(HSEG_G1_3, w_off[3], 64, 120, chain16, [&](size_t el, int64_t src) { emit(HSEG_G1_3, el, src); });
 }
-// u16 slot of piece pc of element el of a segment, relative to the packed buffer viewed as uint16
-inline size_t hseg_slot(int hseg, size_t el, int pc) {
+// u16 slot of piece pc of element el of a segment, relative to the packed buffer viewed as uint16; np = pieces per value
+// (3: the bf16 streams, 2: the fp16 streams behind them)
+inline size_t hseg_slot(int hseg, size_t el, int pc, int np = 3) {
     const int NOB = kpn_hseg_shapes[hseg].nob;
     const size_t e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, s = el / (512 * (size_t)NOB);
-    return (size_t)kpn_hseg_off(hseg) * 2 + ((((s * NOB + ob) * 3 + pc) * 64 + lane) * 8 + e);   // [step][block][piece][lane][8]
+    return (size_t)kpn_xseg_off(hseg, np) * 2 + ((((s * NOB + ob) * np + pc) * 64 + lane) * 8 + e);   // [step][block][piece][lane][8]
 }
+inline uint16_t host_f2h(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }   // round to nearest even
+inline float host_h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 // factor folded into the weight at plain index `src` of segment `hseg` (log2-unit activations, kpn_common.h kpn_hseg_factor)
-inline float hseg_weight_factor(int hseg, int64_t src, const size_t (&w_off)[4]) {
+inline float hseg_weight_factor(int hseg, int64_t src, const size_t (&w_off)[4], int np = 3) {
     static const int layer_of[HSEG_COUNT] = {0, 0, 1, 2, 3}, in_dim[4] = {232, 128, 136, 120};
     if (src < 0) return 1.0f;
     const int l = layer_of[hseg];
-    return kpn_hseg_factor(hseg, (int)((src - (int64_t)w_off[l]) % in_dim[l]));
+    const int col = (int)((src - (int64_t)w_off[l]) % in_dim[l]);
+    return np == 3 ? kpn_hseg_factor(hseg, col) : kpn_fseg_factor(hseg, col);
 }
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
 }  // namespace
@@ -279,6 +283,16 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
             const uint16_t pm = host_f2bf(r1);
             P16[hseg_slot(hseg, el, 0)] = ph; P16[hseg_slot(hseg, el, 1)] = pm; P16[hseg_slot(hseg, el, 2)] = host_f2bf(r1 - host_bf2f(pm));
         });
+        // fp16 double-split streams of layers1 (k_geo_rows_f2) and the count of weights beyond fp16's range
+        int beyond = 0;
+        walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
+            const float w = src >= 0 ? plain_host[src] * hseg_weight_factor(hseg, src, w_off, 2) : 0.0f;
+            if (!(fabsf(w) <= 65504.0f)) ++beyond;
+            const uint16_t ph = host_f2h(w);
+            P16[hseg_slot(hseg, el, 0, 2)] = ph; P16[hseg_slot(hseg, el, 1, 2)] = host_f2h(w - host_h2f(ph));
+        });
+        float* fl = P + kpn_pack_flags_off();
+        fl[0] = (float)beyond; fl[1] = fl[2] = fl[3] = 0.0f;
     }
     // scalars: |ani_al| (model.py:1287) and layers2(0), the query() result of a fully masked point
     float* sc = P + kpn_scalar_off();
@@ -319,6 +333,23 @@ __global__ void k_pack_hseg(const float* __restrict__ plain, const int32_t* __re
     { const auto hv = h[0]; const auto mv = m[0]; const auto lv = l[0]; memcpy(&ph, &hv, 2); memcpy(&pm, &mv, 2); memcpy(&plo, &lv, 2); }
     packed16[slot0[t]] = ph; packed16[slot0[t] + pstride[t]] = pm; packed16[slot0[t] + 2 * pstride[t]] = plo;
 }
+// fp16 region: two pieces; flag[0] counts the weights beyond fp16's range
+__global__ void k_pack_fseg(const float* __restrict__ plain, const int32_t* __restrict__ src, const int32_t* __restrict__ slot0,
+                            const int32_t* __restrict__ pstride, const float* __restrict__ factor, int n,
+                            uint16_t* __restrict__ packed16, float* __restrict__ flags) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float w = src[t] >= 0 ? kpn_mul_nofma(plain[src[t]], factor[t]) : 0.0f;
+#ifndef KPN_SIMT_EMU
+    const _Float16 h = (_Float16)w;
+    const _Float16 l = (_Float16)(w - (float)h);
+    uint16_t ph, pl; memcpy(&ph, &h, 2); memcpy(&pl, &l, 2);
+#else
+    const uint16_t ph = kpn_f2h(w), pl = kpn_f2h(w - kpn_h2f(ph));
+#endif
+    if (!(fabsf(w) <= 65504.0f)) kpn_atomic_add(flags, 1.0f);
+    packed16[slot0[t]] = ph; packed16[slot0[t] + pstride[t]] = pl;
+}
 __global__ void k_pack_gather(const float* __restrict__ plain, const int32_t* __restrict__ map, int n, float* __restrict__ packed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -357,6 +388,8 @@ struct DevicePackMaps {
     int32_t* map = nullptr;
     int32_t *hsrc = nullptr, *hslot = nullptr, *hstride = nullptr;
     float* hfactor = nullptr;
+    int32_t *fslot = nullptr, *fstride = nullptr;   // the fp16 streams: same sources, their own slots and factors
+    float* ffactor = nullptr;
     int n_helem = 0;
     int rc = KPN_OK;
 };
@@ -397,6 +430,14 @@ DevicePackMaps* device_pack_maps() {
     });
     M->n_helem = (int)hsrc.size();
     up(&M->hsrc, hsrc); up(&M->hslot, hslot); up(&M->hstride, hstride); up(&M->hfactor, hfactor);
+    std::vector<int32_t> fslot, fstride;
+    std::vector<float> ffactor;
+    walk_hsegments(w_off, [&](int hseg, size_t el, int64_t src) {
+        ffactor.push_back(hseg_weight_factor(hseg, src, w_off, 2));
+        fslot.push_back((int32_t)hseg_slot(hseg, el, 0, 2));
+        fstride.push_back((int32_t)(hseg_slot(hseg, el, 1, 2) - hseg_slot(hseg, el, 0, 2)));
+    });
+    up(&M->fslot, fslot); up(&M->fstride, fstride); up(&M->ffactor, ffactor);
     return M;
 }
 }  // namespace
@@ -411,6 +452,10 @@ extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev
     KPN_LAUNCH(k_pack_hseg, grid1d((int64_t)M->n_helem, 256), dim3(256), stream, plain_dev, (const int32_t*)M->hsrc,
                (const int32_t*)M->hslot, (const int32_t*)M->hstride, (const float*)M->hfactor, M->n_helem,
                reinterpret_cast<uint16_t*>(packed_dev));
+    (void)hipMemsetAsync(packed_dev + kpn_pack_flags_off(), 0, KPN_PACK_FLAG_FLOATS * sizeof(float), (hipStream_t)stream);
+    KPN_LAUNCH(k_pack_fseg, grid1d((int64_t)M->n_helem, 256), dim3(256), stream, plain_dev, (const int32_t*)M->hsrc,
+               (const int32_t*)M->fslot, (const int32_t*)M->fstride, (const float*)M->ffactor, M->n_helem,
+               reinterpret_cast<uint16_t*>(packed_dev), packed_dev + kpn_pack_flags_off());
     auto woff = [](int layer) { size_t o = 0; for (int l = 0; l < layer; ++l) o += (size_t)plain_dims[l][0] * plain_dims[l][1] + plain_dims[l][0]; return o; };
     auto boff = [&](int layer) { return woff(layer) + (size_t)plain_dims[layer][0] * plain_dims[layer][1]; };
     KPN_LAUNCH(k_pack_scalars, dim3(1), dim3(64), stream, plain_dev, woff(P_G2_0), boff(P_G2_0), woff(P_G2_1), boff(P_G2_1),
@@ -627,10 +672,13 @@ static ProfState g_prof;
 // 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, k_geo_rows)
 // 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16, one tile per wave, two waves per SIMD (k_geo_rows_h): NOT in the
 //    shipped library (unexplained rare wrong tiles); investigation builds only (-DKPN_WITH_MODE1)
-// 2: split-bf16 operands with two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): the default — fp32-class results
-//    (every product term above 2^-24 relative is kept), soaked without a differing value (profiles/*soak*)
+// 2: three bf16 pieces per operand, six products, two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): fp32-class results
+//    (every product term above 2^-24 relative is kept) in fp32's exponent range
+// 3: two fp16 pieces per operand, four products, same kernel structure (k_geo_rows_f2): the default — the same accuracy class
+//    with 1.5x fewer MFMAs and a third of the split instructions; operands must stay within fp16's range (a pre-activation
+//    beyond 454 in natural units makes the row NaN, loudly; packed weights are checked: kpn_packed_f16_range_check)
 #ifndef KPN_DEFAULT_GEO_ROWS_MODE
-#define KPN_DEFAULT_GEO_ROWS_MODE 2
+#define KPN_DEFAULT_GEO_ROWS_MODE 3
 #endif
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
@@ -638,8 +686,9 @@ int geo_rows_mode() {
         const char* e = getenv("KPN_GEO_ROWS_MODE");
         g_geo_rows_mode = e ? atoi(e) : KPN_DEFAULT_GEO_ROWS_MODE;
 #ifndef KPN_WITH_MODE1
-        if (g_geo_rows_mode != 0) g_geo_rows_mode = 2;
+        if (g_geo_rows_mode == 1) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
 #endif
+        if (g_geo_rows_mode < 0 || g_geo_rows_mode > 3) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
     }
     return g_geo_rows_mode;
 }
@@ -696,11 +745,14 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
 #endif
-        if (geo_rows_mode() == 2)
+        if (geo_rows_mode() >= 2)
 #ifdef KPN_SIMT_EMU
-            KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+        {
+            if (geo_rows_mode() == 3) KPN_LAUNCH(k_geo_rows_f2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+            else KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+        }
 #else
-            kpn_internal_launch_geo_rows_h2(pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, batch.index, batch.tiles_cap);
+            kpn_internal_launch_geo_rows_pair(geo_rows_mode(), pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, batch.index, batch.tiles_cap);
 #endif
 #ifdef KPN_WITH_MODE1
         else if (geo_rows_mode() == 1)
@@ -750,14 +802,29 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 
 extern "C" int kpn_set_geo_rows_mode(int32_t mode) {
 #ifdef KPN_WITH_MODE1
-    KPN_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (fp32 MFMA), 1 (split-bf16 MFMA) or 2 (split-bf16 MFMA, two tiles per wave)");
+    KPN_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (fp32 MFMA), 1 (split-bf16, one tile per wave), 2 (three bf16 pieces) or 3 (two fp16 pieces)");
 #else
-    KPN_REQUIRE(mode == 0 || mode == 2, "mode must be 0 (fp32 MFMA) or 2 (split-bf16 MFMA, two tiles per wave); mode 1 is not part of this build");
+    KPN_REQUIRE(mode == 0 || mode == 2 || mode == 3, "mode must be 0 (fp32 MFMA), 2 (three bf16 pieces) or 3 (two fp16 pieces); mode 1 is not part of this build");
 #endif
     g_geo_rows_mode = mode;
     return KPN_OK;
 }
 extern "C" int kpn_get_geo_rows_mode(void) { return geo_rows_mode(); }
+
+// Number of packed layers1 weights whose magnitude (after the folded activation scale) is beyond fp16's range, i.e. that rows
+// mode 3 cannot represent (use mode 2 or 0 for such weights).  Reads four floats back from the device: synchronises `stream`.
+extern "C" int kpn_packed_f16_range_check(const float* packed_dev, void* stream, int32_t* beyond) {
+    KPN_REQUIRE(packed_dev && beyond, "null pointer");
+    float fl[KPN_PACK_FLAG_FLOATS] = {0};
+#ifndef KPN_SIMT_EMU
+    if (hipMemcpyAsync(fl, packed_dev + kpn_pack_flags_off(), sizeof(fl), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(KPN_ELAUNCH, "could not read the pack flags");
+#else
+    memcpy(fl, packed_dev + kpn_pack_flags_off(), sizeof(fl));
+#endif
+    *beyond = (int32_t)fl[0];
+    return KPN_OK;
+}
 
 extern "C" size_t kpn_query_workspace_bytes(int64_t N, int32_t V) {
     if (N <= 0 || V <= 0) return 0;

@@ -96,6 +96,8 @@ static inline void kpn_split3(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m,
     }
 }
 static inline kpn_bf16x8 kpn_as_bf16x8(kpn_f32x4 v) { kpn_bf16x8 r; memcpy(&r, &v, 16); return r; }
+static inline uint16_t kpn_f2h(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }   // RNE, as v_cvt_pk_f16_f32
+static inline float kpn_h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 typedef uint16_t kpn_bf16_t;
 static inline kpn_bf16_t kpn_to_bf(float f) { return kpn_f2bf(f); }
 static inline float kpn_bf_to_f(kpn_bf16_t b) { return kpn_bf2f(b); }
@@ -219,13 +221,25 @@ enum { HSEG_G1_0A, HSEG_G1_0B, HSEG_G1_1, HSEG_G1_2, HSEG_G1_3, HSEG_COUNT };
 struct kpn_hseg_shape { int ks16, nob; };
 #define KPN_HSEG_SHAPES {12, 4}, {4, 4}, {8, 4}, {9, 4}, {8, 2}
 static constexpr kpn_hseg_shape kpn_hseg_shapes[HSEG_COUNT] = {KPN_HSEG_SHAPES};
-constexpr int kpn_hseg_step_floats(int seg) { return 3 * kpn_hseg_shapes[seg].nob * 64 * 4; }
+// the same segments exist twice: with three bf16 pieces per value (np = 3, k_geo_rows_h2) and, behind them, with two fp16 pieces
+// (np = 2, k_geo_rows_f2: stream per step [ob][piece h,l][64 lanes] x 16 B)
+constexpr int kpn_xseg_step_floats(int seg, int np) { return np * kpn_hseg_shapes[seg].nob * 64 * 4; }
+constexpr int kpn_hseg_step_floats(int seg) { return kpn_xseg_step_floats(seg, 3); }
 constexpr int kpn_hseg_off(int seg) {
     int o = kpn_bwd_end();
-    for (int i = 0; i < seg; ++i) o += kpn_hseg_shapes[i].ks16 * kpn_hseg_step_floats(i);
+    for (int i = 0; i < seg; ++i) o += kpn_hseg_shapes[i].ks16 * kpn_xseg_step_floats(i, 3);
     return o;
 }
-constexpr int kpn_packed_floats() { return kpn_hseg_off(HSEG_COUNT); }
+constexpr int kpn_fseg_off(int seg) {
+    int o = kpn_hseg_off(HSEG_COUNT);
+    for (int i = 0; i < seg; ++i) o += kpn_hseg_shapes[i].ks16 * kpn_xseg_step_floats(i, 2);
+    return o;
+}
+constexpr int kpn_xseg_off(int seg, int np) { return np == 3 ? kpn_hseg_off(seg) : kpn_fseg_off(seg); }
+// behind the streams: [0] = number of fp16-stream weights whose magnitude is beyond fp16's range (as a float; 0 = usable)
+#define KPN_PACK_FLAG_FLOATS 4
+constexpr int kpn_pack_flags_off() { return kpn_fseg_off(HSEG_COUNT); }
+constexpr int kpn_packed_floats() { return kpn_pack_flags_off() + KPN_PACK_FLAG_FLOATS; }
 // The split-bf16 streams carry the Softplus(beta = 100) of layers1 in log2 units (geo_rows_pair_kernels.hip, KPN_H2_LOG2ACT):
 // a layer whose OUTPUT goes through the activation is scaled by 100 log2(e) (weights here, biases when the kernel stages
 // them), a layer whose INPUT is an activation by ln(2)/100; for layers1.1 and the chained columns of layers1.2 the two cancel.
@@ -242,6 +256,10 @@ constexpr float kpn_hseg_factor(int hseg, int col) {
     if (hseg == HSEG_G1_2) return col < 128 ? 1.0f : KPN_H2_ACT_SCALE;   // columns 128..135: the sampled hd channels
     return KPN_H2_ACT_UNSCALE;                                           // HSEG_G1_3: no activation behind it
 }
+// the fp16 streams: layers1.3's weights (~1e-3 after the factor above) would sit on fp16's subnormal floor (2^-24 absolute);
+// they are packed times 2^10 and k_geo_rows_f2 multiplies its rows by 2^-10 when it stores them (both exact)
+#define KPN_F16_ROW_SCALE 1024.0f
+constexpr float kpn_fseg_factor(int hseg, int col) { return kpn_hseg_factor(hseg, col) * (hseg == HSEG_G1_3 ? KPN_F16_ROW_SCALE : 1.0f); }
 
 // Row scratch written by k_geo_rows and read by k_fuse_color: per work item (tile, view) KPN_ROW_SLABS
 // slabs of [64 lanes] float4.  Slabs 0..7: the lane's 32 registers of the 64-vector (block b = slab/4);

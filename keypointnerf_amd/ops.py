@@ -57,6 +57,13 @@ class PackedWeights:
             raise ValueError("unexpected hot-path parameter count")
         packed = np.zeros(L.kpn_packed_weight_floats(), np.float32)
         L.check(L.kpn_pack_weights(plain.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p)))
+        # the packer's count of layers1 weights beyond fp16's range (include/kpnerf.h kpn_packed_f16_range_check): the default rows
+        # kernel (mode 3) would turn them into inf — say so here, where it costs nothing (device-side packing: packed_f16_range_check)
+        self.f16_beyond = int(packed[-4])
+        if self.f16_beyond and L.kpn_get_geo_rows_mode() == 3:
+            import warnings
+            warnings.warn(f"{self.f16_beyond} layers1 weights exceed fp16's range: the default rows kernel would return NaN rows; "
+                          "call keypointnerf_amd.ops.set_geo_rows_mode(2) (three bf16 pieces, fp32's exponent range) for these weights")
         self.tensor = torch.from_numpy(packed).to(device)
 
     @classmethod
@@ -468,11 +475,20 @@ def render_rays_train_backward(scene, weights, cam_tar, bounds, pix, u_coarse, u
 
 
 def set_geo_rows_mode(mode):
-    """Rows kernel of the field's first MLP (kpn_set_geo_rows_mode): 2 (default) = split-bf16 operands on the bf16 MFMA, two
-    tiles per wave, one wave per SIMD — fp32-class results; 0 = fp32 MFMA.  (1, the earlier one-tile split-bf16 kernel, is not
-    part of the shipped library: DESIGN.md section 9.2.)"""
+    """Rows kernel of the field's first MLP (kpn_set_geo_rows_mode): 3 (default) = two fp16 pieces per operand on the fp16 MFMA,
+    2 = three bf16 pieces on the bf16 MFMA (fp32's exponent range), both two tiles per wave and one wave per SIMD with fp32-class
+    results; 0 = fp32 MFMA.  (1, the earlier one-tile split-bf16 kernel, is not part of the shipped library: DESIGN.md 9.2.)"""
     L = kl.get_library()
     L.check(L.kpn_set_geo_rows_mode(int(mode)))
+
+
+def packed_f16_range_check(packed):
+    """Number of packed layers1 weights that fp16 cannot hold (rows mode 3 needs 0); synchronises the current stream."""
+    import ctypes
+    L = kl.get_library()
+    beyond = ctypes.c_int32(-1)
+    L.check(L.kpn_packed_f16_range_check(packed.data_ptr(), _stream(), ctypes.byref(beyond)))
+    return int(beyond.value)
 
 
 def get_geo_rows_mode():

@@ -165,6 +165,31 @@ def render_rays(oscene, wflat, cam_tar, bounds, pix, Sc=64, Sf=64, fine=True, st
     return o
 
 
+def set_perturbation(eps_z=0.0, eps_f=0.0, seed=0):
+    """Conditioning probe of render_rays (kpo_set_perturbation): new sample depths times (1 +- eps_z), field values times
+    (1 +- eps_f).  (0, 0) restores the exact oracle."""
+    lib().kpo_set_perturbation(ctypes.c_float(eps_z), ctypes.c_float(eps_f), ctypes.c_uint32(seed))
+
+
+def render_envelope(oscene, wflat, cam_tar, bounds, pix, Sc=64, Sf=64, fine=True, trials=6, eps_z=2.4e-7, eps_f=1e-6, ref=None):
+    """Per ray and output key, the largest movement of the oracle's OWN result over `trials` re-runs with its intermediate values
+    disturbed at fp32-rounding level (see kpo_set_perturbation): {key: (R,) array}.  Rays where this exceeds the parity bar are
+    ill-conditioned in the reference's formulation itself."""
+    if ref is None:
+        ref = render_rays(oscene, wflat, cam_tar, bounds, pix, Sc, Sf, fine=fine)
+    env = {k: np.zeros(len(ref["alpha"]), np.float32) for k in ref if k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")}
+    try:
+        for t in range(trials):
+            set_perturbation(eps_z, eps_f, 1000 + t)
+            o = render_rays(oscene, wflat, cam_tar, bounds, pix, Sc, Sf, fine=fine)
+            for k in env:
+                d = np.abs(o[k] - ref[k])
+                env[k] = np.maximum(env[k], d.max(-1) if d.ndim == 2 else d)
+    finally:
+        set_perturbation(0.0, 0.0, 0)
+    return env
+
+
 def frame_to_rgb8(chw, bgr=False):
     x = _f32(chw).reshape(3, *np.shape(chw)[-2:])
     H, W = x.shape[-2:]

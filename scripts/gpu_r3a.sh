@@ -6,4 +6,4 @@ cp keypointnerf_amd/_lib/libkpnerf_hip.so exp_libs/product.so
 (timeout 1200 python -m pytest tests -m gpu -q -x) > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu_$TAG.log
 shift
 bash scripts/gpu_libs_ab.sh $TAG "$@"
-for t in exp_libs/*t.so; do [ -f $t ] && timeout 300 python scripts/h2_timing.py $t 2>&1 | tail -1; done
+for t in exp_libs/*t.so; do [ -f $t ] && for m in 3 2; do timeout 300 python scripts/h2_timing.py $t $m 2>&1 | tail -1; done; done

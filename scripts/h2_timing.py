@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Per-phase cycles of k_geo_rows_h2 from a -DKPN_H2_TIMING build (exp_libs/<lib>.so): python scripts/h2_timing.py <lib.so>"""
+"""Per-phase cycles of the pair-tile rows kernels from a -DKPN_H2_TIMING build (exp_libs/<lib>.so):
+python scripts/h2_timing.py <lib.so> [rows mode: 3 (default) or 2]"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +16,8 @@ N = 4_000_000
 lo, hi = sc["bounds"].reshape(2, 3)[0], sc["bounds"].reshape(2, 3)[1]
 P = (lo + (hi - lo) * (0.2 + 0.6 * torch.rand(N, 3, device=dev)))[None]
 V = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)[None]
-ops.set_geo_rows_mode(2)
+MODE = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ops.set_geo_rows_mode(MODE)
 dll = ctypes.CDLL(sys.argv[1])
 buf = (ctypes.c_ulonglong * 8)()
 ops.query(ps, w, P, V, mode=1); torch.cuda.synchronize(); dll.kpn_h2_timing(buf)
@@ -24,4 +26,4 @@ c = list(buf)
 items = N * 3 / 64 / 1024
 names = ["prologue", "layers1.0", "layers1.1", "layers1.2", "layers1.3", "-", "epilogue+ticket", "-"]
 tot = sum(c)
-print(os.path.basename(sys.argv[1]), "cycles per work item (one wave, ~%.0f items):" % items, {n: round(x / items) for n, x in zip(names, c) if n != "-"}, "total", round(tot / items))
+print(os.path.basename(sys.argv[1]), "mode", MODE, "cycles per work item (one wave, ~%.0f items):" % items, {n: round(x / items) for n, x in zip(names, c) if n != "-"}, "total", round(tot / items))

@@ -196,6 +196,29 @@ static inline kpn_f32x16 simt_mfma_f32_32x32x16_bf16(simt_bf16x8 a, simt_bf16x8 
     simt::wave_sync();
     return d;
 }
+// v_mfma_f32_32x32x16_f16: same operand maps; fp16 carried as its 16-bit pattern (subnormal inputs are honoured by the
+// hardware: scripts/f16_split_probe.hip)
+static inline kpn_f32x16 simt_mfma_f32_32x32x16_f16(simt_bf16x8 a, simt_bf16x8 b, kpn_f32x16 c) {
+    auto& w = simt::wave_shared();
+    int l = simt::lane_id();
+    for (int e = 0; e < 8; ++e) {
+        _Float16 ha, hb; uint16_t ua = a[e], ub = b[e];
+        memcpy(&ha, &ua, 2); memcpy(&hb, &ub, 2);
+        w.a8[l][e] = (float)ha; w.b8[l][e] = (float)hb;
+    }
+    simt::wave_sync();
+    kpn_f32x16 d;
+    int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kh = 0; kh < 2; ++kh)
+            for (int e = 0; e < 8; ++e) acc = std::fmaf(w.a8[i + 32 * kh][e], w.b8[j + 32 * kh][e], acc);
+        d[r] = acc;
+    }
+    simt::wave_sync();
+    return d;
+}
 static inline kpn_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, kpn_f32x4 c, int, int, int) {
     auto& w = simt::wave_shared();
     int l = simt::lane_id();

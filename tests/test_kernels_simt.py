@@ -449,33 +449,61 @@ def test_device_weight_packer(env):
     assert np.array_equal(dev[nz][np.abs(host[nz]) > 1e-3] != 0, np.ones((np.abs(host[nz]) > 1e-3).sum(), bool))
 
 
-def test_split_bf16_geo_rows(env):
-    """k_geo_rows_h2 (split-bf16 operands on the emulated v_mfma_f32_32x32x16_bf16, two tiles per wave, Softplus in log2 units
-    with the scale folded into the packed streams) vs the reference's recorded query outputs and vs the fp32-MFMA kernel:
-    fp32-class (three bf16 pieces, six products), with an even and an odd number of tiles (the last pair's second tile is
-    computed and not stored).  Mode 1 (one tile per wave) is not part of the shipped library any more."""
+def test_split_operand_geo_rows(env):
+    """The pair-tile rows kernels on the emulated matrix instructions vs the reference's recorded query outputs and vs the
+    fp32-MFMA kernel: k_geo_rows_f2 (mode 3, the default: two fp16 pieces per operand, four products on
+    v_mfma_f32_32x32x16_f16) and k_geo_rows_h2 (mode 2: three bf16 pieces, six products on v_mfma_f32_32x32x16_bf16), both with
+    the Softplus in log2 units folded into the packed streams; an even and an odd number of tiles (the last pair's second tile
+    is computed and not stored).  Mode 1 (one tile per wave) is not part of the shipped library any more."""
     lib, packed, wflat = env
     scene, cfg, g = load_case(CASES[0])
     hs = sh.HostScene(lib, scene)
     valid = g["query.0.valid"][0].reshape(-1)
     default_mode = lib.kpn_get_geo_rows_mode()
-    assert default_mode == int(os.environ.get("KPN_GEO_ROWS_MODE", 2))   # the library's default rows kernel is mode 2
+    assert default_mode == int(os.environ.get("KPN_GEO_ROWS_MODE", 3))   # the library's default rows kernel is mode 3
     for n_valid in (704, 660):                                       # 22 and 21 tiles
         idx = np.concatenate([np.where(valid)[0][:n_valid], np.where(~valid)[0][:60]])
         pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
+        res = {}
         try:
-            lib.check(lib.kpn_set_geo_rows_mode(2))
-            o2, v2 = sh.query(lib, hs, packed, pts, view)
-            lib.check(lib.kpn_set_geo_rows_mode(0))
-            o0, v0 = sh.query(lib, hs, packed, pts, view)
+            for mode in (3, 2, 0):
+                lib.check(lib.kpn_set_geo_rows_mode(mode))
+                assert lib.kpn_get_geo_rows_mode() == mode
+                res[mode] = sh.query(lib, hs, packed, pts, view)
         finally:
             lib.check(lib.kpn_set_geo_rows_mode(default_mode))
-        assert np.array_equal(v0, v2) and v2.sum() == n_valid
-        assert np.abs(o0 - ref)[v0].max() < 1e-5                     # the fp32-MFMA kernel (mode 0)
-        assert np.abs(o2 - ref)[v2].max() < 1e-5 and np.abs(o2 - o0)[v2].max() < 5e-6
-    assert lib.kpn_set_geo_rows_mode(3) != 0
+        o0, v0 = res[0]
+        assert v0.sum() == n_valid and np.abs(o0 - ref)[v0].max() < 1e-5     # the fp32-MFMA kernel (mode 0)
+        for mode in (3, 2):
+            o, v = res[mode]
+            assert np.array_equal(v0, v)
+            assert np.abs(o - ref)[v].max() < 1e-5 and np.abs(o - o0)[v].max() < 5e-6, mode
+    assert lib.kpn_set_geo_rows_mode(4) != 0
     assert lib.kpn_set_geo_rows_mode(1) != 0                         # not in this build (-DKPN_WITH_MODE1 investigation builds only)
     assert lib.kpn_get_geo_rows_mode() == default_mode
+
+
+def test_fp16_stream_range_flag(env):
+    """The packers count the layers1 weights that fp16 cannot hold (rows mode 3 would turn them into inf): 0 for ordinary
+    weights, > 0 when a weight times the folded activation scale exceeds 65504 — host and device packer alike."""
+    import ctypes
+    from keypointnerf_amd.synthetic import random_hotpath_state_dict
+    from keypointnerf_amd.weights import effective_weights, flatten_plain
+    lib = env[0]
+    plain = flatten_plain(effective_weights(random_hotpath_state_dict(seed=21)))
+    for poison, want in ((None, 0), (500.0, 1)):
+        pl = plain.copy()
+        if poison is not None:
+            pl[7] = poison                                           # a layers1.0 weight: 500 x 100 log2(e) = 72,135 > 65,504
+        for device in (False, True):
+            packed = np.zeros(lib.kpn_packed_weight_floats(), np.float32)
+            if device:
+                lib.check(lib.kpn_pack_weights_device(sh.ptr(pl), sh.ptr(packed), None))
+            else:
+                lib.check(lib.kpn_pack_weights(sh.ptr(pl), sh.ptr(packed)))
+            beyond = ctypes.c_int32(-1)
+            lib.check(lib.kpn_packed_f16_range_check(sh.ptr(packed), None, ctypes.byref(beyond)))
+            assert (beyond.value > 0) == (want > 0), (poison, device, beyond.value)
 
 
 def test_ssim_kernel(env):
