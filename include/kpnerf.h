@@ -172,7 +172,13 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
  * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 3). */
 int kpn_set_geo_rows_mode(int32_t mode);
 int kpn_get_geo_rows_mode(void);
-/* *beyond = number of packed layers1 weights that fp16 cannot hold (0 = rows mode 3 is usable with these weights).
+/* The per-point kernel (MLPUNet.layers2 + ibr_compress_gfeat + IBRRenderingHead, reference src/utils.py:577-587,
+ * src/model.py:819,1267-1302): 1 = weights as two fp16 pieces per value, four products on v_mfma_f32_32x32x16_f16
+ * (k_fuse_color_h, the default: fp32-class results at a quarter of the matrix time); 0 = fp32 weights on
+ * v_mfma_f32_32x32x2_f32 (k_fuse_color).  Process-wide; initial value from the environment variable KPN_FUSE_MODE. */
+int kpn_set_fuse_mode(int32_t mode);
+int kpn_get_fuse_mode(void);
+/* *beyond = number of packed weights that fp16 cannot hold (0 = rows mode 3 / fuse mode 1 are usable with these weights).
  * Reads four floats back from the device and synchronises `stream`. */
 int kpn_packed_f16_range_check(const float* packed_weights_dev, void* stream, int32_t* beyond);
 

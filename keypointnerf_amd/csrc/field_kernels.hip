@@ -419,19 +419,55 @@ __device__ __forceinline__ void kpn_gather_view(const float* __restrict__ xscr, 
     o.rd[0] = a1.x; o.rd[1] = a1.y; o.rd[2] = a1.z; o.rd[3] = a1.w;
 }
 
+// The per-point kernel exists with two weight formats (template parameter F16 of its body):
+//   false: fp32 streams on v_mfma_f32_32x32x2_f32 (k_fuse_color; the region [kpn_k2_base(), + kpn_k2_floats()) of the packed buffer)
+//   true : two fp16 pieces per value, four products on v_mfma_f32_32x32x16_f16 (k_fuse_color_h; the kpn_cseg_* region) — the
+//          k_geo_rows_f2 arithmetic: a quarter of the matrix time for the same fp32-class results
+// kpn_fuse_w<F16> maps a segment / scalar / row vector to its offset in the packed buffer (the LDS pointer is biased by -base).
+template <bool F16> struct kpn_fuse_w;
+template <> struct kpn_fuse_w<false> {
+    static constexpr int base = kpn_k2_base(), floats = kpn_k2_floats();
+    static constexpr int woff(int seg) { return kpn_seg_woff(seg); }
+    static constexpr int boff(int seg) { return kpn_seg_boff(seg); }
+    static constexpr int scalars() { return kpn_scalar_off(); }
+    static constexpr int row(int r) { return kpn_row_off(r); }
+};
+template <> struct kpn_fuse_w<true> {
+    static constexpr int base = kpn_k2h_base(), floats = kpn_k2h_floats();
+    static constexpr int woff(int seg) { return kpn_cseg_woff(seg); }
+    static constexpr int boff(int seg) { return kpn_cseg_boff(seg); }
+    static constexpr int scalars() { return kpn_k2h_tail_off(); }
+    static constexpr int row(int r) { return kpn_k2h_tail_off() + (kpn_row_off(r) - kpn_scalar_off()); }
+};
+// one Linear layer of segment SEG from the LDS copy, either format; in_fn as kpn_mfma_layer with G = 4
+template <bool F16, int SEG, int KS, int NOB, class InFn>
+__device__ __forceinline__ void kpn_fuse_layer(const float* __restrict__ wl, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
+    static_assert(KS == kpn_seg_shapes[SEG].ks && NOB == kpn_seg_shapes[SEG].nob, "segment shape");
+    if constexpr (F16) kpn_hlayer<KS, NOB>(wl + kpn_fuse_w<true>::woff(SEG), lane, in_fn, acc);
+    else kpn_mfma_layer<KS, NOB, 4, 1>(wl + kpn_fuse_w<false>::woff(SEG), lane, in_fn, acc);
+}
+template <bool F16, int SEG, int KS, int NOB, int NSRC>
+__device__ __forceinline__ void kpn_fuse_layer_regs(const float* __restrict__ wl, int lane, const float (&src)[NSRC], kpn_f32x16 (&acc)[NOB]) {
+    static_assert(KS == kpn_seg_shapes[SEG].ks && NOB == kpn_seg_shapes[SEG].nob, "segment shape");
+    if constexpr (F16) kpn_hlayer_regs<KS, NOB>(wl + kpn_fuse_w<true>::woff(SEG), lane, src, acc);
+    else kpn_mfma_layer_regs<KS, NOB, 4, 1>(wl + kpn_fuse_w<false>::woff(SEG), lane, src, acc);
+}
+
 // ray_encoder: Linear(4,16) ELU Linear(16,35) ELU (model.py:1246,1279), then x' = rgb_feat' + dir' (:1281-1284)
+template <bool F16 = false>
 __device__ __forceinline__ void kpn_encode_view(const float* __restrict__ wl, int lane, int h, const kpn_view_gather& g,
                                                 const float (&lat0)[16], kpn_ibr_view& o) {
+    using W = kpn_fuse_w<F16>;
     const float in4[4] = {h ? g.rd[1] : g.rd[0], h ? g.rd[3] : g.rd[2], 0.0f, 0.0f};
     kpn_f32x16 a1[1];
-    kpn_load_bias<1>(wl + kpn_seg_boff(SEG_RE_0), h, a1);
-    kpn_mfma_layer_regs<4, 1, 4, 1>(wl + kpn_seg_woff(SEG_RE_0), lane, in4, a1);
+    kpn_load_bias<1>(wl + W::boff(SEG_RE_0), h, a1);
+    kpn_fuse_layer_regs<F16, SEG_RE_0, 4, 1>(wl, lane, in4, a1);
     float in8[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) in8[r] = kpn_elu(a1[0][r]);
     kpn_f32x16 a2[2];
-    kpn_load_bias<2>(wl + kpn_seg_boff(SEG_RE_1), h, a2);
-    kpn_mfma_layer_regs<8, 2, 4, 1>(wl + kpn_seg_woff(SEG_RE_1), lane, in8, a2);
+    kpn_load_bias<2>(wl + W::boff(SEG_RE_1), h, a2);
+    kpn_fuse_layer_regs<F16, SEG_RE_1, 8, 2>(wl, lane, in8, a2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o.xb0[r] = kpn_elu(a2[0][r]) + lat0[r];
     o.xb0[12] += g.fadd[0]; o.xb0[13] += g.fadd[1]; o.xb0[14] += g.fadd[2]; o.xb0[15] += g.fadd[3];
@@ -510,10 +546,12 @@ __device__ unsigned long long kpn_fuse_cycles[8];
 #else
 #define KPN_FUSE_STAMP(i) ((void)0)
 #endif
-__global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
-                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                       int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                       int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+template <bool F16>
+__device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
+                                                    const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                    int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
+                                                    int park_x, float* __restrict__ out, const kpn_batch& batch, int zero_skip) {
+    using W = kpn_fuse_w<F16>;
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -525,11 +563,17 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
     const int V = sc.V;
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
     // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
-    __shared__ __attribute__((aligned(16))) float wlds[kpn_k2_floats()];
-    kpn_stage_lds_streams(wp, wlds);
+    __shared__ __attribute__((aligned(16))) float wlds[W::floats];
+    if constexpr (F16) {   // the fp16 region needs no re-layout: its streams are packed lane-contiguous
+        const float4* src = reinterpret_cast<const float4*>(wp + W::base);
+        float4* dst = reinterpret_cast<float4*>(wlds);
+        for (int i = threadIdx.x; i < W::floats / 4; i += blockDim.x) dst[i] = src[i];
+    } else {
+        kpn_stage_lds_streams(wp, wlds);
+    }
     __syncthreads();
-    const float* wl = wlds - kpn_k2_base();
-    const float ani = wl[kpn_scalar_off() + 0];  // |ani_al|
+    const float* wl = wlds - W::base;
+    const float ani = wl[W::scalars() + 0];  // |ani_al|
 
     (void)wave; (void)nwaves;
 #ifdef KPN_FUSE_TIMING
@@ -540,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         int t = 0;
         if (lane == 0) t = atomicAdd(tickets + 1, 1);
         t = __shfl(t, 0);
-        if (t >= ntiles) break;             // t: tile relative to the batch = its slot in the row scratch
+        if (t >= ntiles) return;            // t: tile relative to the batch = its slot in the row scratch
         const int ci_raw = (t0 + t) * KPN_TILE + p;
         const int ci = ci_raw < count ? ci_raw : count - 1;
         const int64_t n = list[ci];
@@ -578,16 +622,16 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         float sdf_raw, rad;
         {
             kpn_f32x16 h0[2], h1[2], o2[1];
-            kpn_load_bias<2>(wl + kpn_seg_boff(SEG_G2_0), h, h0);
-            kpn_mfma_layer_regs<64, 2, 4, 1>(wl + kpn_seg_woff(SEG_G2_0), lane, pooled, h0);
-            kpn_load_bias<2>(wl + kpn_seg_boff(SEG_G2_1), h, h1);
-            kpn_mfma_layer<32, 2, 4, 1>(wl + kpn_seg_woff(SEG_G2_1), lane, [&](auto gi, float (&x)[4]) {
+            kpn_load_bias<2>(wl + W::boff(SEG_G2_0), h, h0);
+            kpn_fuse_layer_regs<F16, SEG_G2_0, 64, 2>(wl, lane, pooled, h0);
+            kpn_load_bias<2>(wl + W::boff(SEG_G2_1), h, h1);
+            kpn_fuse_layer<F16, SEG_G2_1, 32, 2>(wl, lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(h0[g / 4][(g % 4) * 4 + i]);
             }, h1);
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_G2_2), h, o2);
-            kpn_mfma_layer<32, 1, 4, 1>(wl + kpn_seg_woff(SEG_G2_2), lane, [&](auto gi, float (&x)[4]) {
+            kpn_load_bias<1>(wl + W::boff(SEG_G2_2), h, o2);
+            kpn_fuse_layer<F16, SEG_G2_2, 32, 1>(wl, lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(h1[g / 4][(g % 4) * 4 + i]);
@@ -615,8 +659,8 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         float lat0[16];
         {
             kpn_f32x16 acc[1];
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_CMP), h, acc);
-            kpn_mfma_layer_regs<64, 1, 4, 1>(wl + kpn_seg_woff(SEG_CMP), lane, pooled, acc);
+            kpn_load_bias<1>(wl + W::boff(SEG_CMP), h, acc);
+            kpn_fuse_layer_regs<F16, SEG_CMP, 64, 1>(wl, lane, pooled, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }
@@ -671,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
                 if (!((keep >> v) & 1u)) continue;
                 if (pass == 0 || !park_x) {
                     kpn_gather_view(xscr, t, V, v, lane, h, gv);
-                    kpn_encode_view(wl, lane, h, gv, lat0, iv);
+                    kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
                     if (park_x) park_store(v, iv);
                     stats(pass, gv.rd[3], iv);
                 } else {
@@ -682,8 +726,8 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
         KPN_FUSE_STAMP(4);
         // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
         kpn_f32x16 base[2];
-        kpn_load_bias<2>(wl + kpn_seg_boff(SEG_BL_0A), h, base);
-        kpn_mfma_layer_regs<40, 2, 4, 1>(wl + kpn_seg_woff(SEG_BL_0A), lane, mv, base);
+        kpn_load_bias<2>(wl + W::boff(SEG_BL_0A), h, base);
+        kpn_fuse_layer_regs<F16, SEG_BL_0A, 40, 2>(wl, lane, mv, base);
 
         // per view: rest of the head; online softmax over views of the colour logits, blending the
         // SOURCE colours (model.py:1300-1301)
@@ -695,10 +739,10 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             for (int i = 0; i < 19; ++i) xin[i] = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
             xin[19] = 0.0f;
             kpn_f32x16 a[2] = {base[0], base[1]};
-            kpn_mfma_layer_regs<20, 2, 4, 1>(wl + kpn_seg_woff(SEG_BL_0B), lane, xin, a);  // base_layer.0 (x part)
+            kpn_fuse_layer_regs<F16, SEG_BL_0B, 20, 2>(wl, lane, xin, a);  // base_layer.0 (x part)
             kpn_f32x16 xa[1];
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_BL_1), h, xa);
-            kpn_mfma_layer<32, 1, 4, 1>(wl + kpn_seg_woff(SEG_BL_1), lane, [&](auto gi, float (&x)[4]) {  // base_layer.2
+            kpn_load_bias<1>(wl + W::boff(SEG_BL_1), h, xa);
+            kpn_fuse_layer<F16, SEG_BL_1, 32, 1>(wl, lane, [&](auto gi, float (&x)[4]) {  // base_layer.2
                 constexpr int gq = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_elu(a[gq / 4][(gq % 4) * 4 + i]);
@@ -707,21 +751,21 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = kpn_elu(xa[0][r]); tin[r] = x[r] * wv; }  // :1292-1294
             kpn_f32x16 va[1], vb[1];
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_V1_0), h, va);
-            kpn_mfma_layer_regs<16, 1, 4, 1>(wl + kpn_seg_woff(SEG_V1_0), lane, tin, va);  // vis_layer1.0
+            kpn_load_bias<1>(wl + W::boff(SEG_V1_0), h, va);
+            kpn_fuse_layer_regs<F16, SEG_V1_0, 16, 1>(wl, lane, tin, va);  // vis_layer1.0
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_V1_1), h, vb);
-            kpn_mfma_layer_regs<16, 1, 4, 1>(wl + kpn_seg_woff(SEG_V1_1), lane, tin, vb);  // vis_layer1.2 rows 0..31 (res)
-            const float visr = kpn_elu(kpn_row_dot(wl + kpn_row_off(ROW_V1_VIS), h, tin));   // row 32 (vis)
+            kpn_load_bias<1>(wl + W::boff(SEG_V1_1), h, vb);
+            kpn_fuse_layer_regs<F16, SEG_V1_1, 16, 1>(wl, lane, tin, vb);  // vis_layer1.2 rows 0..31 (res)
+            const float visr = kpn_elu(kpn_row_dot(wl + W::row(ROW_V1_VIS), h, tin));   // row 32 (vis)
             const float sv = kpn_sigmoid(visr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = x[r] + kpn_elu(vb[0][r]); tin[r] = x[r] * sv; }  // :1295-1297 (mask = 1)
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_V2_0), h, va);
-            kpn_mfma_layer_regs<16, 1, 4, 1>(wl + kpn_seg_woff(SEG_V2_0), lane, tin, va);  // vis_layer2.0
+            kpn_load_bias<1>(wl + W::boff(SEG_V2_0), h, va);
+            kpn_fuse_layer_regs<F16, SEG_V2_0, 16, 1>(wl, lane, tin, va);  // vis_layer2.0
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
-            const float vis = kpn_sigmoid(kpn_row_dot(wl + kpn_row_off(ROW_V2_1), h, tin));  // vis_layer2.2 + Sigmoid
+            const float vis = kpn_sigmoid(kpn_row_dot(wl + W::row(ROW_V2_1), h, tin));  // vis_layer2.2 + Sigmoid
             float oin[20];  // out_layer.0 input [x32 | vis | ray_diff4]  (:1300)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oin[r] = x[r];
@@ -729,16 +773,16 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             oin[17] = h ? g.rd[2] : g.rd[1];
             oin[18] = h ? 0.0f : g.rd[3];
             oin[19] = 0.0f;
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_O_0), h, va);
-            kpn_mfma_layer_regs<20, 1, 4, 1>(wl + kpn_seg_woff(SEG_O_0), lane, oin, va);
+            kpn_load_bias<1>(wl + W::boff(SEG_O_0), h, va);
+            kpn_fuse_layer_regs<F16, SEG_O_0, 20, 1>(wl, lane, oin, va);
             float o8[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) o8[r] = kpn_elu(va[0][r]);
-            kpn_load_bias<1>(wl + kpn_seg_boff(SEG_O_1), h, va);
-            kpn_mfma_layer_regs<8, 1, 4, 1>(wl + kpn_seg_woff(SEG_O_1), lane, o8, va);
+            kpn_load_bias<1>(wl + W::boff(SEG_O_1), h, va);
+            kpn_fuse_layer_regs<F16, SEG_O_1, 8, 1>(wl, lane, o8, va);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
-            const float logit = kpn_row_dot(wl + kpn_row_off(ROW_O_2), h, tin);  // out_layer.4
+            const float logit = kpn_row_dot(wl + W::row(ROW_O_2), h, tin);  // out_layer.4
             const float nmax = fmaxf(lmax, logit);
             const float sc_old = kpn_fast_exp(lmax - nmax), pn = kpn_fast_exp(logit - nmax);
             lden = lden * sc_old + pn;
@@ -749,7 +793,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
             kpn_gather_view(xscr, t, V, v, lane, h, gv);
             if (park_x) park_load(v, iv);
-            else kpn_encode_view(wl, lane, h, gv, lat0, iv);
+            else kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }
         KPN_FUSE_STAMP(5);
@@ -763,6 +807,20 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_poi
             o[2] = c0 / lden; o[3] = c1 / lden; o[4] = c2 / lden;
         }
     }
+}
+
+__global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                       int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
+                                                       int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+    kpn_fuse_color_body<false>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
+}
+// the same per-point kernel with its weights as two fp16 pieces per value on v_mfma_f32_32x32x16_f16 (the default)
+__global__ __launch_bounds__(512, 2) void k_fuse_color_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                         const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                         int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
+                                                         int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+    kpn_fuse_color_body<true>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -35,8 +35,6 @@
 #else
 #define KPN_H2_PIN_ACC(v) asm volatile("" : "+a"(v))
 #endif
-typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
-
 // ---- two operand schemes (SC) ----
 //   kpn_sc_bf16x3 (rows mode 2): x = h + m + l in bf16 (8 + 8 + 8 significant bits), six products per term set
 //                 hh hm mh mm hl lh (everything above 2^-24 relative), v_mfma_f32_32x32x16_bf16.  fp32's exponent range.
@@ -86,12 +84,11 @@ struct kpn_sc_f16x2 {
 #ifndef KPN_SIMT_EMU
 __device__ __forceinline__ kpn_bf16x8 kpn_as_bf16x8(kpn_u32x4 v) { return __builtin_bit_cast(kpn_bf16x8, v); }
 #define KPN_H2_USE(v) asm volatile("" ::"v"(v))      // the value exists before this point; defines nothing (no assumed hazard)
-typedef _Float16 kpn_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ kpn_f32x16 kpn_sc_bf16x3::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kpn_bf16x8, a), __builtin_bit_cast(kpn_bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ kpn_f32x16 kpn_sc_f16x2::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(kpn_f16x8, a), __builtin_bit_cast(kpn_f16x8, b), c, 0, 0, 0);
+    return kpn_mfma_f16(a, b, c);
 }
 #else
 static inline kpn_bf16x8 kpn_as_bf16x8(kpn_u32x4 v) { kpn_bf16x8 r; memcpy(&r, &v, 16); return r; }
@@ -106,10 +103,7 @@ inline kpn_f32x16 kpn_sc_bf16x3::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
     kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);
     return simt_mfma_f32_32x32x16_bf16(av, bv, c);
 }
-inline kpn_f32x16 kpn_sc_f16x2::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
-    kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);   // eight 16-bit patterns
-    return simt_mfma_f32_32x32x16_f16(av, bv, c);
-}
+inline kpn_f32x16 kpn_sc_f16x2::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) { return kpn_mfma_f16(a, b, c); }
 #endif
 
 // Softplus(beta 100, threshold 20) in LOG2 UNITS (KPN_H2_LOG2ACT, kpn_common.h; the default): the packer folds 100 log2(e)

@@ -173,7 +173,74 @@ inline float hseg_weight_factor(int hseg, int64_t src, const size_t (&w_off)[4],
     return np == 3 ? kpn_hseg_factor(hseg, col) : kpn_fseg_factor(hseg, col);
 }
 float softplus100_host(float x) { float t = x * 100.0f; return t > 20.0f ? x : log1pf(expf(t)) / 100.0f; }
+// ---- the fp16 region of the per-point kernel (kpn_common.h kpn_cseg_*): every value is read from the ALREADY PACKED fp32
+// stream of the same segment — K slot (chunk c, e) of the half-h lanes = fp32 K-step 8c + e — so host and device packer need
+// no index maps of their own.  Element t of the region's stream part: ((c*NOB + ob)*64 + lane)*8 + e within its segment.
+struct K2hSeg { int seg, first; };   // first element index of the segment in the concatenated element space
+inline int k2h_elements(int seg) { return kpn_cseg_chunks(seg) * kpn_seg_shapes[seg].nob * 64 * 8; }
+inline int k2h_total_elements() { int n = 0; for (int sg = SEG_G2_0; sg < SEG_COUNT; ++sg) n += k2h_elements(sg); return n; }
+// (segment, element) -> float index of the fp32 packed weight (or -1: pad), u16 slot of the h piece; the l piece is 64*8 slots on
+__host__ __device__ inline void k2h_locate(int seg, int el, int& src, int& slot) {
+    const int NOB = kpn_seg_shapes[seg].nob, G = kpn_seg_shapes[seg].g, KS = kpn_seg_shapes[seg].ks;
+    const int e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, c = el / (512 * NOB);
+    const int s = 8 * c + e;
+    src = s < KS ? kpn_seg_woff(seg) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob : -1;
+    slot = kpn_cseg_woff(seg) * 2 + (((c * NOB + ob) * 2) * 64 + lane) * 8 + e;
+}
+int pack_k2h_host(float* P) {   // returns the number of weights beyond fp16's range
+    uint16_t* P16 = reinterpret_cast<uint16_t*>(P);
+    int beyond = 0;
+    for (int sg = SEG_G2_0; sg < SEG_COUNT; ++sg) {
+        for (int el = 0; el < k2h_elements(sg); ++el) {
+            int src, slot;
+            k2h_locate(sg, el, src, slot);
+            const float w = src >= 0 ? P[src] : 0.0f;
+            if (!(fabsf(w) <= 65504.0f)) ++beyond;
+            const uint16_t ph = host_f2h(w);
+            P16[slot] = ph; P16[slot + 512] = host_f2h(w - host_h2f(ph));
+        }
+        memcpy(P + kpn_cseg_boff(sg), P + kpn_seg_boff(sg), sizeof(float) * (size_t)kpn_seg_bfloats(sg));
+    }
+    return beyond;
+}
 }  // namespace
+// device side of the same: one thread per stream element, then the bias blocks and the scalar / row-vector tail
+__global__ void k_pack_k2h(float* __restrict__ packed, int n_elem, float* __restrict__ flags) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_elem) {
+        int sg = SEG_G2_0, el = t;
+        for (;;) {
+            const int n = kpn_cseg_chunks(sg) * kpn_seg_shapes[sg].nob * 64 * 8;
+            if (el < n) break;
+            el -= n; ++sg;
+        }
+        const int NOB = kpn_seg_shapes[sg].nob, G = kpn_seg_shapes[sg].g, KS = kpn_seg_shapes[sg].ks;
+        const int e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, c = el / (512 * NOB);
+        const int s = 8 * c + e;
+        const float w = s < KS ? packed[kpn_seg_woff(sg) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob] : 0.0f;
+        const int slot = kpn_cseg_woff(sg) * 2 + (((c * NOB + ob) * 2) * 64 + lane) * 8 + e;
+#ifndef KPN_SIMT_EMU
+        const _Float16 h = (_Float16)w;
+        const _Float16 l = (_Float16)(w - (float)h);
+        uint16_t ph, pl; memcpy(&ph, &h, 2); memcpy(&pl, &l, 2);
+#else
+        const uint16_t ph = kpn_f2h(w), pl = kpn_f2h(w - kpn_h2f(ph));
+#endif
+        if (!(fabsf(w) <= 65504.0f)) kpn_atomic_add(flags, 1.0f);
+        uint16_t* p16 = reinterpret_cast<uint16_t*>(packed);
+        p16[slot] = ph; p16[slot + 512] = pl;
+    }
+    // bias blocks + tail: plain copies inside the packed buffer
+    const int n_bias = kpn_k2h_tail_off() - kpn_cseg_boff(SEG_G2_0), n_tail = kpn_fwd_floats() - kpn_scalar_off();
+    if (t < n_bias) {
+        int sg = SEG_G2_0, k = t;
+        while (k >= kpn_seg_bfloats(sg)) { k -= kpn_seg_bfloats(sg); ++sg; }
+        packed[kpn_cseg_boff(sg) + k] = packed[kpn_seg_boff(sg) + k];
+    } else if (t < n_bias + n_tail) {
+        packed[kpn_k2h_tail_off() + (t - n_bias)] = packed[kpn_scalar_off() + (t - n_bias)];
+    }
+}
+
 
 extern "C" size_t kpn_plain_weight_floats(void) {
     size_t n = 1;
@@ -291,6 +358,8 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
             const uint16_t ph = host_f2h(w);
             P16[hseg_slot(hseg, el, 0, 2)] = ph; P16[hseg_slot(hseg, el, 1, 2)] = host_f2h(w - host_h2f(ph));
         });
+        // the per-point kernel's region with two fp16 pieces per value (k_fuse_color_h): derived from the fp32 streams packed above
+        beyond += pack_k2h_host(P);
         float* fl = P + kpn_pack_flags_off();
         fl[0] = (float)beyond; fl[1] = fl[2] = fl[3] = 0.0f;
     }
@@ -313,6 +382,8 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
         sc[1] = o2[0]; sc[2] = o2[1];
         sc[3] = pl.ani_al > 0.0f ? 1.0f : (pl.ani_al < 0.0f ? -1.0f : 0.0f);  // d|a|/da for the colour-head reverse
     }
+    // k_fuse_color_h's copy of the scalars and row vectors (the tail of its LDS region)
+    memcpy(P + kpn_k2h_tail_off(), P + kpn_scalar_off(), sizeof(float) * (size_t)(kpn_fwd_floats() - kpn_scalar_off()));
     return KPN_OK;
 }
 
@@ -460,6 +531,9 @@ extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev
     auto boff = [&](int layer) { return woff(layer) + (size_t)plain_dims[layer][0] * plain_dims[layer][1]; };
     KPN_LAUNCH(k_pack_scalars, dim3(1), dim3(64), stream, plain_dev, woff(P_G2_0), boff(P_G2_0), woff(P_G2_1), boff(P_G2_1),
                woff(P_G2_2), boff(P_G2_2), np - 1, packed_dev + kpn_scalar_off());
+    // the per-point kernel's fp16 region from the fp32 streams, biases, scalars and row vectors written above (same stream: ordered)
+    const int n_k2h = k2h_total_elements();
+    KPN_LAUNCH(k_pack_k2h, grid1d((int64_t)n_k2h, 256), dim3(256), stream, packed_dev, n_k2h, packed_dev + kpn_pack_flags_off());
     return check_launch("kpn_pack_weights_device");
 }
 
@@ -680,6 +754,13 @@ static ProfState g_prof;
 #ifndef KPN_DEFAULT_GEO_ROWS_MODE
 #define KPN_DEFAULT_GEO_ROWS_MODE 3
 #endif
+// The per-point kernel: 1 = k_fuse_color_h (weights as two fp16 pieces per value on v_mfma_f32_32x32x16_f16: the default),
+// 0 = k_fuse_color (fp32 weights on v_mfma_f32_32x32x2_f32).  Process-wide; initial value from KPN_FUSE_MODE.
+int g_fuse_mode = -1;
+int fuse_mode() {
+    if (g_fuse_mode < 0) { const char* e = getenv("KPN_FUSE_MODE"); g_fuse_mode = (e && atoi(e) == 0) ? 0 : 1; }
+    return g_fuse_mode;
+}
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
     if (g_geo_rows_mode < 0) {
@@ -792,8 +873,12 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
             // zero-density short path: render passes only (lean), never when a backward pass reads the rows again
             const char* zs = getenv("KPN_NO_ZERO_SKIP");   // A/B knob, read per call
             const int zero_skip = (lean && !keep_rows && !(zs && atoi(zs))) ? 1 : 0;
-            KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                       (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch, zero_skip);
+            if (fuse_mode() == 1)
+                KPN_LAUNCH(k_fuse_color_h, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                           (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch, zero_skip);
+            else
+                KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
+                           (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch, zero_skip);
         }
     }
     return check_launch("field query");
@@ -810,6 +895,12 @@ extern "C" int kpn_set_geo_rows_mode(int32_t mode) {
     return KPN_OK;
 }
 extern "C" int kpn_get_geo_rows_mode(void) { return geo_rows_mode(); }
+extern "C" int kpn_set_fuse_mode(int32_t mode) {
+    KPN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (fp32 MFMA) or 1 (two fp16 pieces per operand)");
+    g_fuse_mode = mode;
+    return KPN_OK;
+}
+extern "C" int kpn_get_fuse_mode(void) { return fuse_mode(); }
 
 // Number of packed layers1 weights whose magnitude (after the folded activation scale) is beyond fp16's range, i.e. that rows
 // mode 3 cannot represent (use mode 2 or 0 for such weights).  Reads four floats back from the device: synchronises `stream`.

@@ -78,6 +78,32 @@ typedef __bf16 kpn_bf16_t;
 __device__ __forceinline__ kpn_bf16_t kpn_to_bf(float f) { return (__bf16)f; }   // round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float kpn_bf_to_f(kpn_bf16_t b) { return (float)b; }
 #define KPN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_32x32x16_f16 on raw dwords (A: a weight stream's float4, B: four packed pairs); operand maps as the bf16 form
+typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 kpn_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ kpn_f32x16 kpn_mfma_f16(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(kpn_f16x8, a), __builtin_bit_cast(kpn_f16x8, b), c, 0, 0, 0);
+}
+// eight fp32 values -> two fp16 pieces each, x = h + l to 2^-23 relative (absolute floor 2^-24: fp16's subnormal quantum):
+// h = RNE(x) by v_cvt_pk_f16_f32, x - h formed exactly by ONE v_fma_mix_f32 that reads the fp16 half in place, l = RNE(x - h)
+// (scripts/f16_split_probe.hip).  Plain (movable) asm statements: hipcc has no builtin that selects these forms.
+// A VGPR written by a VALU instruction needs idle states before a v_mfma may read it as a source operand, and hipcc's hazard
+// recogniser only guards producers it can see: with these statements bare, k_fuse_color_h returned NaN colours on the MI355X
+// while the emulator and the compiler-selected form of the same arithmetic were right (bisected on the device: idle states
+// IN FRONT of the statements do not help, idle states BEHIND the two conversions whose results are MFMA operands do).  Hence
+// the "s_nop 1" inside those two statements.  (The pair-tile rows kernels produce their operands a whole step ahead.)
+__device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& h, kpn_u32x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t ph, pl;
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(ph) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x[2 * j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x[2 * j + 1]));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(pl) : "v"(r0), "v"(r1));
+        h[j] = ph; l[j] = pl;
+    }
+}
 #else
 typedef uint16_t kpn_bf16x8 __attribute__((ext_vector_type(8)));
 static inline uint16_t kpn_f2bf(float f) {  // round to nearest even, as v_cvt_pk_bf16_f32
@@ -102,6 +128,18 @@ typedef uint16_t kpn_bf16_t;
 static inline kpn_bf16_t kpn_to_bf(float f) { return kpn_f2bf(f); }
 static inline float kpn_bf_to_f(kpn_bf16_t b) { return kpn_bf2f(b); }
 #define KPN_MFMA16(a, b, c) simt_mfma_f32_32x32x16_bf16((a), (b), (c))
+typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
+static inline kpn_f32x16 kpn_mfma_f16(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
+    kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);   // eight 16-bit patterns each
+    return simt_mfma_f32_32x32x16_f16(av, bv, c);
+}
+static inline void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& h, kpn_u32x4& l) {
+    for (int j = 0; j < 4; ++j) {
+        const uint16_t h0 = kpn_f2h(x[2 * j]), h1 = kpn_f2h(x[2 * j + 1]);
+        h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        l[j] = (uint32_t)kpn_f2h(x[2 * j] - kpn_h2f(h0)) | ((uint32_t)kpn_f2h(x[2 * j + 1] - kpn_h2f(h1)) << 16);
+    }
+}
 #endif
 
 #define KPN_NKPT 24
@@ -236,9 +274,30 @@ constexpr int kpn_fseg_off(int seg) {
     return o;
 }
 constexpr int kpn_xseg_off(int seg, int np) { return np == 3 ? kpn_hseg_off(seg) : kpn_fseg_off(seg); }
-// behind the streams: [0] = number of fp16-stream weights whose magnitude is beyond fp16's range (as a float; 0 = usable)
+// ---- the per-point kernel's weights with two fp16 pieces per value (k_fuse_color_h), behind the rows kernels' streams ----
+// Segment SEG_x (x >= SEG_G2_0) again, its KS fp32 K-steps taken eight at a time: chunk c = K-steps 8c .. 8c+7 (pads beyond KS),
+// i.e. K slot (c, h, e) of v_mfma_f32_32x32x16_f16 carries what K-step 8c + e carried for the half-h lanes — the kernel's
+// B operands keep their order, eight per MFMA set instead of one.  Stream per (chunk, output block): [piece h,l][64 lanes] x 16 B
+// (consecutive lanes 16 B apart: conflict-free ds_read_b128).  Then a copy of every segment's fp32 bias block, then a copy of
+// the scalars and row vectors [kpn_scalar_off(), kpn_fwd_floats()): one contiguous region (141 KB) that the kernel stages in LDS.
+constexpr int kpn_cseg_chunks(int seg) { return (kpn_seg_shapes[seg].ks + 7) / 8; }
+constexpr int kpn_cseg_wfloats(int seg) { return kpn_cseg_chunks(seg) * kpn_seg_shapes[seg].nob * 2 * 64 * 4; }
+constexpr int kpn_cseg_woff(int seg) {
+    int o = kpn_fseg_off(HSEG_COUNT);
+    for (int i = SEG_G2_0; i < seg; ++i) o += kpn_cseg_wfloats(i);
+    return o;
+}
+constexpr int kpn_k2h_base() { return kpn_cseg_woff(SEG_G2_0); }
+constexpr int kpn_cseg_boff(int seg) {
+    int o = kpn_cseg_woff(SEG_COUNT);
+    for (int i = SEG_G2_0; i < seg; ++i) o += kpn_seg_bfloats(i);
+    return o;
+}
+constexpr int kpn_k2h_tail_off() { return kpn_cseg_boff(SEG_COUNT); }
+constexpr int kpn_k2h_floats() { return kpn_k2h_tail_off() + (kpn_fwd_floats() - kpn_scalar_off()) - kpn_k2h_base(); }
+// behind everything: [0] = number of fp16-stream weights whose magnitude is beyond fp16's range (as a float; 0 = usable)
 #define KPN_PACK_FLAG_FLOATS 4
-constexpr int kpn_pack_flags_off() { return kpn_fseg_off(HSEG_COUNT); }
+constexpr int kpn_pack_flags_off() { return kpn_k2h_base() + kpn_k2h_floats(); }
 constexpr int kpn_packed_floats() { return kpn_pack_flags_off() + KPN_PACK_FLAG_FLOATS; }
 // The split-bf16 streams carry the Softplus(beta = 100) of layers1 in log2 units (geo_rows_pair_kernels.hip, KPN_H2_LOG2ACT):
 // a layer whose OUTPUT goes through the activation is scaled by 100 log2(e) (weights here, biases when the kernel stages

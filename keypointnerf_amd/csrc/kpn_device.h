@@ -282,6 +282,47 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
     }, acc);
 }
 
+// The same Linear layer on v_mfma_f32_32x32x16_f16 with two fp16 pieces per operand and four products per term set (the
+// k_geo_rows_f2 arithmetic, geo_rows_pair_kernels.hip) for the per-point kernel: the stream is the LDS copy of a kpn_cseg_*
+// segment (kpn_common.h), KS fp32 K-steps taken eight at a time.  in_fn has kpn_mfma_layer's signature with G = 4
+// (in_fn(kpn_ic<g>, float (&x)[4]) = K-steps 4g .. 4g+3); a chunk is two such groups.  Compiler-scheduled: two waves share a
+// SIMD in this kernel.  4 MFMAs of 32 cycles per (chunk, block) against 8 of 64 on the fp32 pipe.
+template <int KS, int NOB, class InFn>
+__device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
+    constexpr int NC = (KS + 7) / 8, NG = (KS + 3) / 4;
+    const kpn_lptr4 base = KPN_LDS4(wseg) + lane;
+    kpn_static_for<0, NC>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        float x[8];
+        {
+            float lo[4], hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            in_fn(kpn_ic<2 * c>{}, lo);
+            if constexpr (2 * c + 1 < NG) in_fn(kpn_ic<2 * c + 1>{}, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = lo[i]; x[4 + i] = hi[i]; }
+        }
+        kpn_u32x4 bh, bl;
+        kpn_split_f16x8(x, bh, bl);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
+            acc[ob] = kpn_mfma_f16(ah, bh, acc[ob]);
+            acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]);
+            acc[ob] = kpn_mfma_f16(al, bh, acc[ob]);
+            acc[ob] = kpn_mfma_f16(al, bl, acc[ob]);
+        }
+    });
+}
+template <int KS, int NOB, int NSRC>
+__device__ __forceinline__ void kpn_hlayer_regs(const float* __restrict__ wseg, int lane, const float (&src)[NSRC], kpn_f32x16 (&acc)[NOB]) {
+    static_assert(NSRC >= KS, "operand array too short");
+    kpn_hlayer<KS, NOB>(wseg, lane, [&](auto gi, float (&x)[4]) {
+        constexpr int g = decltype(gi)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = (g * 4 + i < KS) ? src[g * 4 + i] : 0.0f;
+    }, acc);
+}
+
 // One Linear layer on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (kpn_common.h HSEG_*): KS16 steps of 16 k.
 // in_fn(kpn_ic<s>, float (&x)[8]) produces the 8 fp32 values this lane supplies in step s; they are split into three
 // bf16 pieces on the fly; the weights arrive pre-split.  Six products per (step, output block) keep every term above

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "kpn_set_geo_rows_mode": (ctypes.c_int, [c_i32]),
     "kpn_get_geo_rows_mode": (ctypes.c_int, []),
     "kpn_packed_f16_range_check": (ctypes.c_int, [c_p, c_p, c_p]),
+    "kpn_set_fuse_mode": (ctypes.c_int, [c_i32]),
+    "kpn_get_fuse_mode": (ctypes.c_int, []),
     "kpn_ssim_scratch_bytes": (c_sz, [c_i32, c_i32]),
     "kpn_ssim": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     "kpn_query_workspace_bytes": (c_sz, [c_i64, c_i32]),

@@ -482,6 +482,16 @@ def set_geo_rows_mode(mode):
     L.check(L.kpn_set_geo_rows_mode(int(mode)))
 
 
+def set_fuse_mode(mode):
+    """Per-point kernel (kpn_set_fuse_mode): 1 (default) = weights as two fp16 pieces on the fp16 MFMA; 0 = fp32 MFMA."""
+    L = kl.get_library()
+    L.check(L.kpn_set_fuse_mode(int(mode)))
+
+
+def get_fuse_mode():
+    return int(kl.get_library().kpn_get_fuse_mode())
+
+
 def packed_f16_range_check(packed):
     """Number of packed layers1 weights that fp16 cannot hold (rows mode 3 needs 0); synchronises the current stream."""
     import ctypes

@@ -161,10 +161,15 @@ def test_split_colour_path_is_bit_identical(ops, golden_weights, monkeypatch):
     s, ps = _prep(ops, scene)
     H, W = s["cam_tar"]["height"], s["cam_tar"]["width"]
     outs = []
-    for split in ("0", "1"):
-        monkeypatch.setenv("KPN_FUSE_SPLIT", split)
-        o = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(0, 0, 1, W, H), n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
-        outs.append({k: v.clone() for k, v in o.items()})
+    default_fuse = ops.get_fuse_mode()
+    ops.set_fuse_mode(0)                              # the split kernels are the fp32-weight experiment: compare with k_fuse_color
+    try:
+        for split in ("0", "1"):
+            monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+            o = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(0, 0, 1, W, H), n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+            outs.append({k: v.clone() for k, v in o.items()})
+    finally:
+        ops.set_fuse_mode(default_fuse)
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
 
@@ -187,11 +192,17 @@ def test_zero_density_tiles_take_the_short_path_exactly(ops, monkeypatch):
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
     monkeypatch.setenv("KPN_NO_ZERO_SKIP", "0")
-    for split in ("1", "2"):                                  # split kernels; 2 = colour head over the live points only
-        monkeypatch.setenv("KPN_FUSE_SPLIT", split)
-        o = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 48, 48), n_coarse=64, n_fine=64)
-        for k in outs[0]:
-            assert torch.equal(outs[0][k], o[k]), (split, k)
+    default_fuse = ops.get_fuse_mode()
+    ops.set_fuse_mode(0)                              # the split kernels are the fp32-weight experiment: compare with k_fuse_color
+    try:
+        ref0 = {k: v.clone() for k, v in ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 48, 48), n_coarse=64, n_fine=64).items()}
+        for split in ("1", "2"):                              # split kernels; 2 = colour head over the live points only
+            monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+            o = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 48, 48), n_coarse=64, n_fine=64)
+            for k in ref0:
+                assert torch.equal(ref0[k], o[k]), (split, k)
+    finally:
+        ops.set_fuse_mode(default_fuse)
     monkeypatch.setenv("KPN_FUSE_SPLIT", "0")
     yy, xx = np.meshgrid(np.arange(48), np.arange(48), indexing="ij")
     pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
@@ -650,6 +661,30 @@ def test_rows_kernel_modes(ops, golden_weights):
             assert int(off.sum()) == 0, mode
     finally:
         ops.set_geo_rows_mode(default_mode)
+
+
+def test_fuse_kernel_modes(ops, golden_weights):
+    """kpn_set_fuse_mode: 1 (default) = the per-point kernel with its weights as two fp16 pieces per value on the fp16 MFMA
+    (k_fuse_color_h); 0 = fp32 weights on the fp32 MFMA (k_fuse_color).  Both: the reference goldens at the parity bar,
+    bit-identical run to run, fp32-class agreement with each other on 400,000 random points."""
+    sd, w = golden_weights
+    default_fuse = ops.get_fuse_mode()
+    assert default_fuse == int(os.environ.get("KPN_FUSE_MODE", 1))
+    try:
+        results = {}
+        for fm in (1, 0):
+            ops.set_fuse_mode(fm)
+            assert ops.get_fuse_mode() == fm
+            _golden_parity_in_current_mode(ops, w)
+            pb, P, V = _soak_points(ops)
+            runs = [ops.query(pb, w, P, V, mode=1)[0].clone() for _ in range(4)]
+            assert all(torch.equal(r, runs[0]) for r in runs[1:]), fm
+            results[fm] = runs[0]
+        scale = results[0].abs().amax(dim=(0, 1))
+        off = ((results[1] - results[0]).abs() > 2e-5 * scale + 1e-6).any(-1)
+        assert int(off.sum()) == 0
+    finally:
+        ops.set_fuse_mode(default_fuse)
 
 
 def test_default_rows_kernel_soak(ops, golden_weights):

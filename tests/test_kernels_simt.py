@@ -483,6 +483,35 @@ def test_split_operand_geo_rows(env):
     assert lib.kpn_get_geo_rows_mode() == default_mode
 
 
+def test_fuse_modes(env):
+    """The per-point kernel with its weights as two fp16 pieces per value on the emulated v_mfma_f32_32x32x16_f16
+    (k_fuse_color_h, kpn_set_fuse_mode(1), the default) and with fp32 weights (k_fuse_color, mode 0): both at the golden bar on
+    the reference's recorded query, fp32-class agreement with each other (the rows kernel held at the fp32-MFMA one)."""
+    lib, packed, wflat = env
+    scene, cfg, g = load_case(CASES[0])
+    hs = sh.HostScene(lib, scene)
+    valid = g["query.0.valid"][0].reshape(-1)
+    idx = np.concatenate([np.where(valid)[0][:320], np.where(~valid)[0][:40]])
+    pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
+    default_rows, default_fuse = lib.kpn_get_geo_rows_mode(), lib.kpn_get_fuse_mode()
+    assert default_fuse == int(os.environ.get("KPN_FUSE_MODE", 1))
+    res = {}
+    try:
+        lib.check(lib.kpn_set_geo_rows_mode(0))
+        for fm in (1, 0):
+            lib.check(lib.kpn_set_fuse_mode(fm))
+            assert lib.kpn_get_fuse_mode() == fm
+            res[fm] = sh.query(lib, hs, packed, pts, view)
+    finally:
+        lib.check(lib.kpn_set_geo_rows_mode(default_rows))
+        lib.check(lib.kpn_set_fuse_mode(default_fuse))
+    (o1, v1), (o0, v0) = res[1], res[0]
+    assert np.array_equal(v0, v1) and v1.sum() == 320
+    assert np.abs(o0 - ref)[v0].max() < 1e-5 and np.abs(o1 - ref)[v1].max() < 1e-5
+    assert np.abs(o1 - o0)[v1].max() < 5e-6
+    assert lib.kpn_set_fuse_mode(2) != 0
+
+
 def test_fp16_stream_range_flag(env):
     """The packers count the layers1 weights that fp16 cannot hold (rows mode 3 would turn them into inf): 0 for ordinary
     weights, > 0 when a weight times the folded activation scale exceeds 65504 — host and device packer alike."""
@@ -599,9 +628,14 @@ def test_split_colour_path_is_bit_identical(env, monkeypatch):
     hs = sh.HostScene(lib, scene)
     pts, view = g["query.1.pts"][0][:3000], g["query.1.view"][0][:3000]
     res = []
-    for split in ("0", "1"):
-        monkeypatch.setenv("KPN_FUSE_SPLIT", split)
-        res.append([sh.query(lib, hs, packed, pts, view, mode=m) for m in (0, 1)])
+    default_fuse = lib.kpn_get_fuse_mode()
+    lib.check(lib.kpn_set_fuse_mode(0))              # the split kernels are the fp32-weight experiment: compare with k_fuse_color
+    try:
+        for split in ("0", "1"):
+            monkeypatch.setenv("KPN_FUSE_SPLIT", split)
+            res.append([sh.query(lib, hs, packed, pts, view, mode=m) for m in (0, 1)])
+    finally:
+        lib.check(lib.kpn_set_fuse_mode(default_fuse))
     for (o0, v0), (o1, v1) in zip(res[0], res[1]):
         assert np.array_equal(v0, v1) and np.array_equal(o0, o1)
 
@@ -624,12 +658,19 @@ def test_zero_density_short_path_is_exact(env, monkeypatch):
             assert np.array_equal(pair[0][k], pair[1][k]), (bias, k)
         res.append(pair[0])
     assert res[0]["alpha_fine"].max() > 0.1 and res[1]["alpha_fine"].max() == 0.0
-    # the same frames through the split kernels with the second compaction (colour head over the live points only)
-    for bias, ref in zip((-20.0,), res):
-        packed = sh.pack_weights(lib, random_hotpath_state_dict(seed=3, density_bias=bias))
+    # the same frame through the split kernels with the second compaction (colour head over the live points only); they are the
+    # fp32-weight experiment, so the comparison frame is rendered with k_fuse_color (fuse mode 0)
+    default_fuse = lib.kpn_get_fuse_mode()
+    lib.check(lib.kpn_set_fuse_mode(0))
+    try:
+        packed = sh.pack_weights(lib, random_hotpath_state_dict(seed=3, density_bias=-20.0))
         monkeypatch.setenv("KPN_NO_ZERO_SKIP", "0")
+        monkeypatch.setenv("KPN_FUSE_SPLIT", "0")
+        ref = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 12, 12), 24, 24)
         for split in ("1", "2"):
             monkeypatch.setenv("KPN_FUSE_SPLIT", split)
             o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 12, 12), 24, 24)
             for k in ref:
-                assert np.array_equal(o[k], ref[k]), (bias, split, k)
+                assert np.array_equal(o[k], ref[k]), (split, k)
+    finally:
+        lib.check(lib.kpn_set_fuse_mode(default_fuse))
