@@ -55,6 +55,7 @@ struct kpn_sc_bf16x3 {
     static constexpr int pb(int pr) { return pr == 1 || pr == 3 ? 1 : (pr == 4 ? 2 : 0); }   // B piece:                h m h m l h
     static constexpr int hseg_base() { return kpn_hseg_off(0); }
     static constexpr float out_up = 1.0f, out_down = 1.0f;
+    static constexpr bool PREFETCH = false;   // register-saturated (256 VGPRs): the next item's data would only add spills
     static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
 };
 struct kpn_sc_f16x2 {
@@ -63,6 +64,7 @@ struct kpn_sc_f16x2 {
     static constexpr int pb(int pr) { return pr & 1; }                                         // h l h l
     static constexpr int hseg_base() { return kpn_fseg_off(0); }
     static constexpr float out_up = KPN_F16_ROW_SCALE, out_down = 1.0f / KPN_F16_ROW_SCALE;    // layers1.3 is packed times 2^10
+    static constexpr bool PREFETCH = true;    // the next work item's ticket / list entries / points fetched under this one's layers
     static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
 };
 // ---- the operand production: one volatile asm BLOCK per slice ----
@@ -419,11 +421,33 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
 #ifdef KPN_H2_TIMING
     unsigned long long stamp_ = clock64();
 #endif
+    // The work items are software-pipelined (SC::PREFETCH: the fp16 scheme, which has the registers for it): the NEXT item's
+    // ticket is drawn while layers1.0 runs, its two list entries are fetched while layers1.1 runs and its points while
+    // layers1.2 runs, so that the three dependent round trips (atomic -> list -> point: 5-6 k cycles that nothing covered at one
+    // wave per SIMD) are off the critical path.  Clamped indices keep the look-ahead of a ticket beyond the last item in bounds.
+    int nx_ticket = 0;                    // lane 0: the raw result of the next ticket's atomic
+    int nx_wi = 0;
+    int64_t nx_n[2] = {0, 0};
+    kpn_point_raw nx_raw[2];
+    auto draw_ticket = [&]() { if (lane == 0) nx_ticket = atomicAdd(tickets + 0, 1); };
+    auto fetch_list = [&]() {
+        nx_wi = __shfl(nx_ticket, 0);
+        const int npair = nx_wi / sc.V;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int64_t ci = (int64_t)(t0 + 2 * npair + t) * KPN_TILE + p;
+            if (ci >= count) ci = count - 1;
+            nx_n[t] = (int64_t)list[ci];
+        }
+    };
+    auto fetch_points = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kpn_point_fetch(ps, nx_n[t], nx_raw[t]);
+    };
+    draw_ticket(); fetch_list(); fetch_points();           // the first item: nothing to hide behind
     for (;;) {
         KPN_H2_STAMP(6);
-        int wi = 0;
-        if (lane == 0) wi = atomicAdd(tickets + 0, 1);
-        wi = __shfl(wi, 0);
+        const int wi = nx_wi;
         if (wi >= nwork) return;
         const int pair = wi / sc.V, v = wi - pair * sc.V;
         const bool has1 = 2 * pair + 1 < nbt;              // an odd batch ends in half a pair: tile 1 is computed, not stored
@@ -434,25 +458,21 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tr = 2 * pair + t;
-            int ci = (t0 + tr) * KPN_TILE + p;
-            if (ci >= count) ci = count - 1;
-            kpn_get_point(ps, (int64_t)list[ci], P[t], D[t]);
+            kpn_point_finish(ps, nx_raw[t], P[t], D[t]);
             q[t] = kpn_project(tb, P[t][0], P[t][1], P[t][2], sc);
             dst[t] = reinterpret_cast<float4*>(xscr) + ((size_t)(tr * sc.V + v) * KPN_ROW_SLABS) * 64 + lane;
         }
-        if (!((sc.keep >> v) & 1u)) {                      // a dropped view: zero rows, the record is still needed
+        if (!((sc.keep >> v) & 1u)) {                      // a dropped view: zero rows (its gather records: k_row_records)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if (t == 1 && !has1) break;
-                float4 rec0, rec1;
-                kpn_row_record(sc, tb, v, h, q[t], P[t], D[t], rec0, rec1);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dst[t][k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[t][8 * 64] = rec0;
-                dst[t][9 * 64] = rec1;
             }
+            draw_ticket(); fetch_list(); fetch_points();
             continue;
         }
+        if constexpr (SC::PREFETCH) draw_ticket();
         KPN_H2_STAMP(0);
         // ---- layers1.0 as ONE 16-step chain (HSEG_G1_0A and HSEG_G1_0B are adjacent, same step size): steps 0-11 one
         //      keypoint each (7 encoding values + a zero slot), steps 12-15 eight geo0 channels each ----
@@ -593,6 +613,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                 a0, xa, xb);
         }
         KPN_H2_STAMP(1);
+        if constexpr (SC::PREFETCH) fetch_list();
         // chained step s of a 128-vector: registers 8(s%2)..+7 of block s/2
         kpn_f32x16 a2[2][4];
         float4 hraw[2][4];                                  // the four taps of the 4 hd channels of this half (layers1.2, step 8)
@@ -631,8 +652,8 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             [&](auto ti, auto ei) -> float { return a1[decltype(ti)::value][0][decltype(ei)::value]; },
             a1, xb, xa);
         KPN_H2_STAMP(2);
+        if constexpr (SC::PREFETCH) fetch_points();
         kpn_f32x16 acc[2][2];
-        float4 rec0[2], rec1[2];
         kpn_mfma16_layer2<SC, 9, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_xseg_off(HSEG_G1_2, NP), lane,
             [&](auto si, auto ti, auto ei) -> float {
                 constexpr int s = decltype(si)::value, t = decltype(ti)::value, e = decltype(ei)::value;
@@ -641,11 +662,9 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                 else return 0.0f;
             },
             [](auto, auto, auto, auto) {},
-            [&](auto mi) {                                     // last step: biases of layers1.3, the colour head's gather record
+            [&](auto mi) {                                     // last step: biases of layers1.3
                 constexpr int m = decltype(mi)::value;
                 if constexpr (m < 2) kpn_load_bias<2>(bias_s[3], h, acc[m]);
-                else if constexpr (m == 4) kpn_row_record(sc, tb, v, h, q[0], P[0], D[0], rec0[0], rec1[0]);
-                else if constexpr (m == 14) kpn_row_record(sc, tb, v, h, q[1], P[1], D[1], rec0[1], rec1[1]);
             },
             [&](auto ti, auto ei) -> float { return a2[decltype(ti)::value][0][decltype(ei)::value]; },
             a2, xa, xb);
@@ -667,9 +686,8 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                     dst[t][(b * 4 + qd) * 64] =   // (the fp16 scheme's layers1.3 is packed times 2^10: exact power-of-two unscale)
                         make_float4(acc[t][b][4 * qd + 0] * SC::out_down, acc[t][b][4 * qd + 1] * SC::out_down,
                                     acc[t][b][4 * qd + 2] * SC::out_down, acc[t][b][4 * qd + 3] * SC::out_down);
-            dst[t][8 * 64] = rec0[t];
-            dst[t][9 * 64] = rec1[t];
         }
+        if constexpr (!SC::PREFETCH) { draw_ticket(); fetch_list(); fetch_points(); }
     }
 }
 
@@ -684,4 +702,35 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_f2(kpn_scene_dev sc, kpn_points ps, con
                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
     kpn_geo_rows_pair_body<kpn_sc_f16x2>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
+}
+
+// The colour head's gather records of a batch (slabs 8, 9 of every (tile, view) block of the row scratch; kpn_row_record_a / _b,
+// model.py:806-832), for the pair-tile rows kernels: inside those the two parts ran as a divergent branch of the half-waves
+// (~800 issue slots per work item in a VALU-bound stream plus exposed tap latency).  Here a lane owns one (point, view) pair and
+// computes BOTH parts — lanes 0..31 view 2u, lanes 32..63 view 2u + 1 of one tile — without divergence and with enough waves
+// in flight to hide the taps; it writes part A to the row's h = 0 slot and part B to its h = 1 slot.
+__global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_points ps, const int* __restrict__ list,
+                                                     const int* __restrict__ count_ptr, float* __restrict__ xscr, kpn_batch batch) {
+    const int lane = threadIdx.x & 63, p = lane & 31, vsel = lane >> 5;
+    const int count = *count_ptr;
+    int t0, t1;
+    if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;
+    const int nbt = t1 - t0, vpairs = (sc.V + 1) >> 1;
+    const int nwork = nbt * vpairs;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int wi = wave; wi < nwork; wi += nwaves) {
+        const int tr = wi / vpairs, v = 2 * (wi - tr * vpairs) + vsel;
+        if (v >= sc.V) continue;
+        int64_t ci = (int64_t)(t0 + tr) * KPN_TILE + p;
+        if (ci >= count) ci = count - 1;
+        float P[3], D[3];
+        kpn_get_point(ps, (int64_t)list[ci], P, D);
+        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+        const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+        float4 a0, a1, b0, b1;
+        kpn_row_record_a(sc, tb, v, q, P, D, a0, a1);
+        kpn_row_record_b(sc, v, q, b0, b1);
+        float4* rec = reinterpret_cast<float4*>(xscr) + ((size_t)(tr * sc.V + v) * KPN_ROW_SLABS + 8) * 64;
+        rec[p] = a0; rec[32 + p] = b0; rec[64 + p] = a1; rec[64 + 32 + p] = b1;
+    }
 }

@@ -16,6 +16,12 @@ extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_geo_ro
     else
         KPN_LAUNCH(k_geo_rows_h2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, kpn_batch{batch_index, tiles_cap});
 }
+// the gather records of the same batch (the pair-tile kernels do not write them)
+extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_row_records(
+    int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const int* list, const int* count, float* xscr,
+    int batch_index, int tiles_cap) {
+    KPN_LAUNCH(k_row_records, dim3(blocks), dim3(256), stream, *sc, *ps, list, count, xscr, kpn_batch{batch_index, tiles_cap});
+}
 
 #ifdef KPN_H2_TIMING
 // debug builds only: read (and clear) the per-phase cycle sums of k_geo_rows_h2

@@ -18,6 +18,8 @@
 #ifdef KPN_SIMT_EMU
 #include "geo_rows_pair_kernels.hip"   // the device build compiles this kernel as its own translation unit (geo_rows_pair_tu.hip)
 #else
+extern "C" void kpn_internal_launch_row_records(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const int* list,
+                                                const int* count, float* xscr, int batch_index, int tiles_cap);
 extern "C" void kpn_internal_launch_geo_rows_pair(int mode, int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
                                                   const int* list, const int* count, int* tickets, float* xscr, int batch_index, int tiles_cap);
 #endif
@@ -841,6 +843,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 #endif
         else
             KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
+        const bool pair_rows = geo_rows_mode() >= 2;
 #ifndef KPN_SIMT_EMU
         if (prof) {
             (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
@@ -850,6 +853,13 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
             ++g_prof.used;
         }
 #endif
+        if (pair_rows) {   // the colour head's gather records (the pair-tile rows kernels leave them to k_row_records)
+#ifdef KPN_SIMT_EMU
+            KPN_LAUNCH(k_row_records, dim3(8), dim3(256), stream, sc, ps, (const int*)list, (const int*)count, xscr, batch);
+#else
+            kpn_internal_launch_row_records(2048, stream, &sc, &ps, list, count, xscr, batch.index, batch.tiles_cap);
+#endif
+        }
         // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going
         // to read them again (keep_rows)
         if (fuse_split_mode() >= 1 && out) {

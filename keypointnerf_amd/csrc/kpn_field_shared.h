@@ -46,6 +46,29 @@ __device__ __forceinline__ void kpn_get_point(const kpn_points& ps, int64_t n, f
     }
 }
 
+// The same in two steps, so that the loads of the NEXT work item's points can be in flight while the current one is computed:
+// kpn_point_fetch issues them, kpn_point_finish forms P and D.
+struct kpn_point_raw { float a[3], b[3], z; };
+__device__ __forceinline__ void kpn_point_fetch(const kpn_points& ps, int64_t n, kpn_point_raw& r) {
+    if (ps.pts) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.a[k] = ps.pts[n * 3 + k]; r.b[k] = ps.view[n * 3 + k]; }
+        r.z = 0.0f;
+    } else {
+        const int64_t ray = n / ps.S;
+        r.z = ps.z[n];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.b[k] = ps.dirs[ray * 3 + k]; r.a[k] = 0.0f; }
+    }
+}
+__device__ __forceinline__ void kpn_point_finish(const kpn_points& ps, const kpn_point_raw& r, float (&P)[3], float (&D)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        D[k] = r.b[k];
+        P[k] = ps.pts ? r.a[k] : RADD(ps.cam_pos[k], RMUL(r.b[k], r.z));
+    }
+}
+
 // Boundary-smooth pooling weight of one view (model.py:752-759, mask == 1), un-normalised
 __device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
     const float c3[3] = {RADD(RMUL(0.5f, q.xn), 0.5f), RADD(RMUL(0.5f, q.yn), 0.5f), RADD(RMUL(0.5f, q.zn), 0.5f)};
@@ -58,62 +81,49 @@ __device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
     return RMUL(RMUL(w3[0], w3[1]), w3[2]);
 }
 
-// the colour head's per-(point,view) gather record (query_color, model.py:806-832): h=0 lanes [r,g,b, pooling
-// weight | ray_diff direction(3), dot], h=1 lanes the 8 texture channels (model.py:818)
+// the colour head's per-(point,view) gather record (query_color, model.py:806-832) in its two parts: A = [r,g,b, pooling
+// weight | ray_diff direction(3), dot] (held by the h=0 lanes of a row), B = the 8 texture channels (model.py:818; h=1 lanes)
+__device__ __forceinline__ void kpn_row_record_a(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, const kpn_proj& q,
+                                                 const float (&P)[3], const float (&D)[3], float4& rec0, float4& rec1) {
+    const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+#ifdef KPN_DBG_REC_NOLOAD
+    const float4 c = make_float4(0.3f, 0.4f, 0.5f, 1.0f);
+    (void)ti;
+#else
+    const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
+#endif
+    rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
+    const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
+    float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
+    const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
+    cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
+    const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
+    const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
+    rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
+}
+__device__ __forceinline__ void kpn_row_record_b(const kpn_scene_dev& sc, int v, const kpn_proj& q, float4& rec0, float4& rec1) {
+    const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+    const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
+#ifdef KPN_DBG_REC_NOLOAD
+    rec0 = make_float4(0.1f, 0.2f, -0.1f, 0.3f); rec1 = make_float4(-0.2f, 0.1f, 0.0f, 0.2f);
+    (void)tt; (void)tx;
+#else
+    rec0 = kpn_tap4(tx, 8, 0, tt);
+    rec1 = kpn_tap4(tx, 8, 4, tt);
+#endif
+}
+// both parts by the lane layout of the row scratch: h = 0 lanes part A, h = 1 lanes part B
 __device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, int h,
                                                const kpn_proj& q, const float (&P)[3], const float (&D)[3], float4& rec0,
                                                float4& rec1) {
-#ifdef KPN_DBG_REC_NOBRANCH   // bisection: both halves compute both records, then select
+#ifdef KPN_DBG_REC_NOBRANCH   // bisection: both halves compute both parts, then select
     float4 ra0, ra1, rb0, rb1;
-    {
-        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
-        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);
-        ra0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
-        const float* cp = tb + KPN_TBL_CPOS;
-        float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
-        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
-        const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
-        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
-        ra1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
-        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
-        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
-        rb0 = kpn_tap4(tx, 8, 0, tt);
-        rb1 = kpn_tap4(tx, 8, 4, tt);
-    }
+    kpn_row_record_a(sc, tb, v, q, P, D, ra0, ra1);
+    kpn_row_record_b(sc, v, q, rb0, rb1);
     rec0 = h ? rb0 : ra0;
     rec1 = h ? rb1 : ra1;
     return;
 #endif
-    if (h == 0) {
-        const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
-#ifdef KPN_DBG_REC_NOLOAD
-        const float4 c = make_float4(0.3f, 0.4f, 0.5f, 1.0f);
-        (void)ti;
-#else
-        const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
-#endif
-        rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
-        const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
-        float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
-        const float nrm = fmaxf(sqrtf(kpn_dot3(cr[0], cr[1], cr[2], cr[0], cr[1], cr[2])), 1e-12f);
-        cr[0] = cr[0] / nrm; cr[1] = cr[1] / nrm; cr[2] = cr[2] / nrm;
-        const float r0 = RSUB(D[0], cr[0]), r1 = RSUB(D[1], cr[1]), r2 = RSUB(D[2], cr[2]);
-        const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
-        rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
-    } else {
-        const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
-        const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
-#ifdef KPN_DBG_REC_NOLOAD
-        rec0 = make_float4(0.1f, 0.2f, -0.1f, 0.3f); rec1 = make_float4(-0.2f, 0.1f, 0.0f, 0.2f);
-        (void)tt; (void)tx;
-#else
-        rec0 = kpn_tap4(tx, 8, 0, tt);
-        rec1 = kpn_tap4(tx, 8, 4, tt);
-#endif
-    }
+    if (h == 0) kpn_row_record_a(sc, tb, v, q, P, D, rec0, rec1);
+    else kpn_row_record_b(sc, v, q, rec0, rec1);
 }
-
-// ---------------------------------------------------------------------------------------------
-// Row kernel.  x scratch layout: [(tile*V + v)*8 + q4][lane] float4, q4 = 4 consecutive registers of
-// the lane's 32-register result (block b = q4/4, regs 4*(q4%4)..+3) — lane-contiguous 1-KB stores.

@@ -82,7 +82,8 @@ class _State:
         self.weights = None
         self.weights_key = None
         self.plans = {}
-        self.feats = None            # (key, img, feat_geo, feat_tex): encoder outputs of the last source set
+        self.feats = None            # (encoder key, (img, image key), feat_geo, feat_tex): encoder outputs of the last source set
+        self.attached = None         # (encoder key, image key) at the module's last attach_geo_feat(im) without return_val
 
     def packed_weights(self):
         params = [p for n, p in self.net.named_parameters() if n.startswith(_HOT_PREFIXES)]
@@ -117,26 +118,61 @@ class _State:
             plan = self.plans[key] = ops.RenderPlan(scene, grid, Sc, Sf, fine=fine)
         return plan
 
+    def encoder_key(self):
+        """(identity, storage, version) of every parameter AND buffer of the two encoders.  They are ordinary tensors (never
+        inference tensors), so the version counter is always there: an optimizer step, load_state_dict or a BatchNorm update
+        changes the key even when the source images are inference tensors (Lightning validate / test)."""
+        net = self.net
+        key = []
+        for name in ("geo_encoder", "tex_encoder"):
+            m = getattr(net, name, None)
+            if m is None:
+                continue
+            for t in list(m.parameters()) + list(m.buffers()):
+                if t.is_inference():
+                    return None                       # no version counter: never reuse
+                key.append((id(t), t.data_ptr(), t._version))
+        return tuple(key)
+
+    @staticmethod
+    def _same_images(cached, img_in):
+        """`cached` = (tensor, version key or None).  Versioned tensors compare by identity + version, inference tensors by
+        content against the clone that was kept."""
+        img0, k0 = cached
+        k = _version_key([img_in])
+        if k is not None and k0 is not None:
+            return k == k0
+        return img0.numel() == img_in.numel() and img0.device == img_in.device and bool(torch.equal(img0.reshape(img_in.shape), img_in))
+
+    def note_attached(self, im):
+        """Called by the wrapped attach_geo_feat (install): the module now holds feat_geo / feat_tex of `im`, computed with the
+        encoder state of this moment (the reference keeps its own clone in net.im, src/model.py:653-657)."""
+        self.attached = (self.encoder_key(), _version_key([im]))
+
     def encoder_features(self, img_in):
         """feat_geo / feat_tex of the source images.  render_novel_views runs both encoders once per source set
         (attach_im_feat, src/model.py:479) and render_pifu_nerf then runs them AGAIN for every target camera
-        (:913-914) — 28 M parameters of convolutions per orbit frame for identical inputs.  In eval mode the encoders
-        are deterministic, so their outputs are kept per (source images, encoder parameters) and reused."""
+        (:913-914) — 28 M parameters of convolutions per orbit frame for identical inputs.  In eval mode the encoders are
+        deterministic, so (1) the maps the module already holds from attach_im_feat are taken when they belong to these images
+        and to the encoders' current state (render_video_zju: every frame is a new source set, attached once), and (2) otherwise
+        the maps of the last call are kept per (source images, encoder state)."""
         net = self.net
         if net.training or (torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())):
             return net.attach_geo_feat(img_in, return_val=True), net.attach_tex_feat(img_in, return_val=True)
-        enc_params = [p for n, p in net.named_parameters() if n.startswith(("geo_encoder.", "tex_encoder."))]
-        key = _version_key([img_in] + enc_params)
-        if self.feats is not None:
-            k0, img0, g0, t0 = self.feats
-            same = (key is not None and key == k0) or (key is None and k0 is None and img0.shape == img_in.shape
-                                                       and torch.equal(img0, img_in))
-            if same:
-                return g0, t0
+        ekey = self.encoder_key()
+        if ekey is not None:
+            im0 = getattr(net, "im", None)
+            if (self.attached is not None and self.attached[0] == ekey and im0 is not None and getattr(net, "feat_geo", None) is not None
+                    and (getattr(net, "tex_encoder", None) is None or getattr(net, "feat_tex", None) is not None)
+                    and self._same_images((im0, None), img_in)):
+                return net.feat_geo, net.feat_tex
+            if self.feats is not None and self.feats[0] == ekey and self._same_images(self.feats[1], img_in):
+                return self.feats[2], self.feats[3]
         g = net.attach_geo_feat(img_in, return_val=True)
         t = net.attach_tex_feat(img_in, return_val=True)
+        ikey = _version_key([img_in])
         # versioned tensors: the strong reference pins identity; inference tensors: a clone pins the content
-        self.feats = (key, img_in if key is not None else img_in.clone(), g, t)
+        self.feats = (ekey, (img_in if ikey is not None else img_in.clone(), ikey), g, t) if ekey is not None else None
         return g, t
 
 
@@ -155,7 +191,7 @@ def _draw_keep_bits(n_views, dev):
 def install(net, rows_mode=None):
     """Rebinds the hot-path attributes of a reference ``KeypointNeRF`` instance to the HIP operators.
     Returns ``net``.  ``uninstall(net)`` restores the reference's methods.  ``rows_mode`` (optional) selects the rows
-    kernel process-wide (``ops.set_geo_rows_mode``: 2 = default split-bf16 pair tiles, 0 = fp32 MFMA)."""
+    kernel process-wide (``ops.set_geo_rows_mode``: 3 = default, two fp16 pieces per operand; 2 = three bf16 pieces; 0 = fp32 MFMA)."""
     from . import torch_ops  # noqa: F401  (registers torch.ops.kpnerf.*)
     check_supported(net)
     if rows_mode is not None:
@@ -321,7 +357,15 @@ def install(net, rows_mode=None):
             u = torch.rand(*contrib.shape[:-1], sample_per_ray).to(contrib.device)
         return ops.importance_sample(contrib, z, sample_per_ray, uniform=uniform, u=u)
 
+    def attach_geo_feat(self, im, return_val=False):
+        r = cls.attach_geo_feat(self, im, return_val)
+        if not return_val:                                         # the module keeps im / feat_geo (src/model.py:653-666)
+            st.note_attached(im)
+        return r
+
     net._kpnerf_reference_methods = {k: net.__dict__.get(k) for k in _SEAMS}
+    if hasattr(cls, "attach_geo_feat"):
+        net.attach_geo_feat = types.MethodType(attach_geo_feat, net)
     net.query = types.MethodType(query, net)
     net.batch_render_pifu_nerf = batch_render_pifu_nerf            # static in the reference: called as net.f(net=net, ...)
     net.render_pifu_nerf = render_pifu_nerf
@@ -333,7 +377,7 @@ def install(net, rows_mode=None):
 
 
 def uninstall(net):
-    for k in _SEAMS:
+    for k in _SEAMS + ("attach_geo_feat",):
         if k in net.__dict__:
             del net.__dict__[k]
     for k in ("_kpnerf_state", "_kpnerf_reference_methods"):

@@ -70,6 +70,45 @@ def test_render_pifu_nerf_of_the_live_class(emulated):
         assert torch.equal(got[k], again[k]), k
 
 
+def test_encoders_run_once_per_source_set_and_again_when_their_state_changes(emulated):
+    """render_novel_views attaches the source set once (attach_im_feat, src/model.py:479) and render_pifu_nerf re-runs both
+    encoders per camera (:913-914).  With the drop-in the attached maps are taken as long as the images AND the encoders' state
+    (parameters and buffers, by version counter) are the ones they were computed with — also under torch.inference_mode, where
+    the images carry no version counter (Lightning validate / test) — and the encoders run again the moment a weight changes."""
+    from keypointnerf_amd.dropin import install, uninstall
+    net, s = _net_and_scene()
+    calls = {"geo": 0, "tex": 0}
+    net.geo_encoder.register_forward_hook(lambda *a: calls.__setitem__("geo", calls["geo"] + 1))
+    net.tex_encoder.register_forward_hook(lambda *a: calls.__setitem__("tex", calls["tex"] + 1))
+    kw = dict(net=net, img_in=s["img"], cam_in=s["cam"], cam_tar=s["cam_tar"], tar_img=None, sp_data=dict(s["sp_data"]),
+              objcenter=torch.zeros(1, 3), fine=True, uniform=True, objrad=250., blur=3, level=1, sample_per_ray_c=8,
+              sample_per_ray_f=8, src_foreground_mask=s["src_foreground_mask"], bounds=s["bounds"], mask_at_box=torch.ones(1, 16, 16))
+    install(net)
+    try:
+        with torch.inference_mode():
+            kw_inf = dict(kw, img_in=s["img"].clone())               # an inference tensor: no version counter
+            net.attach_im_feat(kw_inf["img_in"])
+            assert calls == {"geo": 1, "tex": 1}
+            a = net.render_pifu_nerf(**kw_inf)
+            b = net.render_pifu_nerf(**kw_inf)
+            assert calls == {"geo": 1, "tex": 1}, calls              # two cameras: no further encoder run
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        with torch.no_grad():
+            next(net.geo_encoder.parameters()).mul_(1.5)             # a new checkpoint / an optimizer step: in-place, same tensor
+        with torch.inference_mode():
+            c = net.render_pifu_nerf(**kw_inf)
+            assert calls["geo"] == 2 and calls["tex"] == 2, calls    # stale maps are not served
+            assert not torch.equal(a["tex_fg_fine"], c["tex_fg_fine"])
+            net.render_pifu_nerf(**kw_inf)                           # ... and the fresh ones are kept for the next camera
+            assert calls["geo"] == 2, calls
+            other = dict(kw_inf, img_in=(kw_inf["img_in"] * 0.5).clone())
+            net.render_pifu_nerf(**other)                            # a different source set
+            assert calls["geo"] == 3, calls
+    finally:
+        uninstall(net)
+
+
 def test_validation_call_of_the_live_class_consumes_the_same_random_stream(emulated):
     """KeypointNeRF.forward in eval mode (validation_step, src/model.py:509-526 -> :866-884): uniform=False, jittered
     depths and a CPU-drawn importance u.  Same seed => the reference and the drop-in must draw the same numbers."""
