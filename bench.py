@@ -75,6 +75,12 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo + all ranks on cuda:0 only to exercise the N>1 flow on a 1-GPU box")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = size the CPU sample for ~15 s")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank renders its own frame of the orbit per step (frames sharded, the production job); "
+                         "strong = ONE frame per step, split into N bands of image rows (SURVEY 8(e))")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: gather each frame before the next one starts (default: the "
+                    "gather of frame i overlaps the rendering of frame i + 1)")
+    ap.add_argument("--no-configs4", action="store_true", help="skip secondary.configs4_full (4096^2 rays, 10 views, 128 flat samples: ~15 s + set-up)")
     return ap.parse_args()
 
 
@@ -131,6 +137,41 @@ def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1, wi
     if with_kernel:
         return dt * 1e3, rows.value / steps, ms.value / max(1, launches.value), rows.value * L.kpn_flops_per_row() / max(1e-9, ms.value * 1e-3) / 1e12
     return dt * 1e3, rows.value / steps
+
+
+def time_configs4(L, ops, torch, dev, sd, mode):
+    """BASELINE configs[4] at FULL size — 4096 x 4096 rays, 10 source views of 4096^2, 128 flat samples per ray (no fine pass),
+    dense mask, random weights: the roofline-measurement config.  One timed step (about 1.3e10 rows), the rows
+    kernel's launch times taken inside the library like the headline's."""
+    from keypointnerf_amd.synthetic import make_scene, to_device
+    res, views, samples = 4096, 10, 128
+    t_setup = time.perf_counter()
+    scene = to_device(make_scene(n_views=views, src_hw=(res, res), tar_hw=(res, res), mask="dense", seed=1, tar_focal_at_512=800.0), dev)
+    w = ops.PackedWeights(sd, device=dev)
+    ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"], scene["src_foreground_mask"])
+    plan = ops.RenderPlan(ps, (0, 0, 1, res, res), samples, samples, fine=False)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    L.check(L.kpn_profile_enable(1))
+    t0 = time.perf_counter()
+    out = ops.render_rays(ps, w, scene["cam_tar"], scene["bounds"], plan=plan)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, launches, rows, surplus = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.kpn_profile_collect2(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus)))
+    L.check(L.kpn_profile_enable(0))
+    achieved = rows.value * L.kpn_flops_per_row() / max(1e-9, ms.value * 1e-3) / 1e12
+    peak = rows_peak_tflops(mode)
+    valid = rows.value / (views * res * res * samples)
+    r = {"workload": "configs[4]: 4096x4096 rays, 10 source views 4096x4096, 128 flat samples/ray, dense mask, random weights; one step, no warm-up",
+         "ms_per_step": dt * 1e3, "rays_per_sec": res * res / dt, "sampled_points_per_sec": res * res * samples / dt,
+         "fully_evaluated_points_per_sec": res * res * samples * valid / dt, "valid_fraction_of_field_evaluations": valid,
+         "valid_rows": rows.value, "render_workspace_bytes": plan.nbytes, "mean_alpha": float(out["alpha"].mean()), "setup_s": t_setup,
+         "roofline": {"kernel": ROWS_KERNEL[mode], "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                      "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value), "kernel_time_share": ms.value * 1e-3 / dt}}
+    del plan, ps, scene, out
+    torch.cuda.empty_cache()
+    return r
 
 
 def time_training(ops, torch, dev, sd, steps=10):
@@ -219,7 +260,7 @@ def main():
 
     from keypointnerf_amd import lib as kl
     from keypointnerf_amd import ops
-    from keypointnerf_amd.parallel import gather_frames_to_root, orbit_target_camera
+    from keypointnerf_amd.parallel import FrameGatherer, band_of_rank, gather_frames_to_root, orbit_target_camera
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
 
     if args.no_coarse_reuse:
@@ -239,20 +280,26 @@ def main():
     fine = not args.no_fine
     ref_evals_per_ray = args.samples * (3 if fine else 1)          # the reference: Sc coarse + (Sc + Sf) fine
     evals_per_ray = args.samples * (2 if fine and not args.no_coarse_reuse else (3 if fine else 1))   # performed here
-    plan = ops.RenderPlan(ps, (0, 0, 1, res, res), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
-    gather_buf = None
-    if world > 1 and rank == 0:     # destination of the job's only exchange (rank 0 receives every rank's frame)
-        gather_buf = torch.empty(world, 3, res, res, device=dev if args.dist_backend == "nccl" else "cpu")
+    strong = world > 1 and args.scaling == "strong"
+    y0, nrows = band_of_rank(res, rank, world) if strong else (0, res)
+    if strong and res % world:
+        sys.exit("bench.py: --scaling strong needs the frame height to be a multiple of the rank count (equal bands gather into one frame)")
+    plan = ops.RenderPlan(ps, (0, y0, 1, res, nrows), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
+    gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+    gatherer = FrameGatherer(world, rank, (3, nrows, res), device=gdev) if world > 1 else None
 
     def step(i):
-        # frame i of the job: rank r renders target camera (i*world + r) of the orbit
-        cam_tar = orbit_target_camera(scene["cam_tar"], i * world + rank) if world > 1 else scene["cam_tar"]
+        # weak: frame i of the job, rank r renders target camera (i*world + r) of the orbit; strong: camera i, band r of its rows
+        cam_tar = orbit_target_camera(scene["cam_tar"], i if strong else i * world + rank) if world > 1 else scene["cam_tar"]
         L.check(L.kpn_scene_prepare(ctypes.byref(ps.desc), ctypes.c_void_p(ps.ws.data_ptr()),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         out = ops.render_rays(ps, w, cam_tar, scene["bounds"], plan=plan)
-        if world > 1:  # the job's only exchange: finished RGB frames (3 MB each) gathered to rank 0
-            img = out["tex_fg_fine" if fine else "tex_fg"][0]
-            gather_frames_to_root(img if args.dist_backend == "nccl" else img.cpu(), world, rank, into=gather_buf)
+        if world > 1:  # the job's only exchange: finished RGB frames (3 MB each) / bands gathered to rank 0, asynchronously
+            k = gatherer.submit(out["tex_fg_fine" if fine else "tex_fg"][0])
+            if args.sync_gather:
+                gatherer.work[k].wait()
+                if args.dist_backend == "nccl":
+                    torch.cuda.current_stream().synchronize()
         return out
 
     for i in range(args.warmup):
@@ -265,9 +312,21 @@ def main():
     for i in range(args.steps):
         out = step(args.warmup + i)
     if world > 1:
+        gatherer.finish()                     # the last frames' gathers are inside the timed region
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gather_ms = None
+    if world > 1:                             # the exchange alone (after the timed region): one synchronous round, averaged
+        img = out["tex_fg_fine" if fine else "tex_fg"][0]
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(5):
+            gatherer.work[gatherer.submit(img)].wait()
+            torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - tg) / 5 * 1e3
+        gatherer.finish()
     ms, launches, rows, surplus = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
     L.check(L.kpn_profile_collect2(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus)))
     L.check(L.kpn_profile_enable(0))
@@ -277,7 +336,13 @@ def main():
     dt = float(tmax.item())
 
     rays_per_step = res * res
-    value = world * rays_per_step * args.steps / dt
+    value = (1 if strong else world) * rays_per_step * args.steps / dt
+    rccl = None
+    if world > 1 and args.dist_backend == "nccl":
+        try:
+            rccl = "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            rccl = f"unknown ({e})"
     if rank == 0:
         flops_row = L.kpn_flops_per_row()
         achieved = (rows.value * flops_row) / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
@@ -299,7 +364,7 @@ def main():
         line = {
             "metric": f"rendered rays/sec ({args.samples} coarse" + (f" + {args.samples} fine samples/ray)" if fine else " samples/ray, flat)"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": ROWS_DTYPE[args.geo_rows_mode],
             "data": "synthetic",
@@ -318,10 +383,15 @@ def main():
                        "fully_evaluated_points_per_sec": value * evals_per_ray * valid_frac,
                        "render_workspace_bytes": plan.nbytes, "scene_workspace_bytes": ps.ws.numel() * 4,
                        "peak_device_bytes_allocated": peak_alloc,
-                       "mean_alpha_fine": alpha_mean, "parallelism": f"frames sharded over {world} rank(s), one process per GPU"
+                       "mean_alpha_fine": alpha_mean, "parallelism": (f"one frame split into {world} bands of rows" if strong else f"frames sharded over {world} rank(s)") + ", one process per GPU"
                                       + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
                        "dist_world_size": (dist.get_world_size() if world > 1 else 1),
-                       "dist_backend": (args.dist_backend if world > 1 else None)},
+                       "dist_backend": (args.dist_backend if world > 1 else None),
+                       "rccl_ranks": (dist.get_world_size() if (world > 1 and args.dist_backend == "nccl") else None),
+                       "dist_library": rccl,
+                       "gather": (None if world == 1 else ("synchronous per frame" if args.sync_gather else
+                                  "asynchronous: frame i travels while frame i+1 renders (two staging buffers)")),
+                       "gather_ms_per_round_alone": gather_ms},
             "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -372,12 +442,28 @@ def main():
                                          "unit": "TFLOP/s", "frac": ktf / rows_peak_tflops(m), "avg_launch_ms": kms}}
             if args.views == 3:
                 sec["training_step_configs3"] = time_training(ops, torch, dev, sd)
+            if not args.no_configs4 and res == 512 and fine:       # next to the headline only
+                del plan, ps, scene
+                torch.cuda.empty_cache()
+                try:
+                    sec["configs4_full"] = time_configs4(L, ops, torch, dev, sd, args.geo_rows_mode)
+                except Exception as e:  # noqa: BLE001  (e.g. a box with less host memory): say so, keep the line
+                    sec["configs4_full"] = {"error": f"{type(e).__name__}: {e}"}
             line["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(args, scene_cpu, sd, fine=fine)
+            port = cpu_baseline(args, scene_cpu, sd, fine=fine)
             rj = os.path.join(ROOT, "profiles", "reference_cpu_pytorch.json")
-            if os.path.exists(rj):   # the unmodified reference (PyTorch CPU), timed where it is mounted: scripts/time_reference_cpu.py
-                line["cpu_baseline"]["reference_pytorch"] = json.load(open(rj))
+            if os.path.exists(rj):
+                # The headline CPU baseline is the UNMODIFIED reference (PyTorch CPU, src/model.py) on a configs[1] tile, timed where
+                # /root/reference is mounted (the build container: scripts/time_reference_cpu.py; it cannot travel to the GPU
+                # box).  The C port of the same arithmetic, timed live on THIS box's host cores, sits beside it.
+                ref = json.load(open(rj))
+                line["cpu_baseline"] = {"value": ref.get("rays_per_sec", ref.get("value")), "unit": "rays/s", "cores": ref.get("cores"),
+                                        "kind": "reference", "sample": ref.get("sample", ref.get("what")),
+                                        "recorded": "profiles/reference_cpu_pytorch.json (build container; the reference is absent on the GPU box)",
+                                        "reference_pytorch": ref, "port": port}
+            else:
+                line["cpu_baseline"] = port
             ej = os.path.join(ROOT, "profiles", "r02_eager_pytorch_on_mi355x.json")
             if os.path.exists(ej):   # eager PyTorch restatement of the path on an MI355X (scripts/bench_torch_eager.py), recorded
                 e = json.load(open(ej))

@@ -105,6 +105,48 @@ def gather_frames_to_root(img, world, rank, group=None, into=None):
     return None
 
 
+class FrameGatherer:
+    """The same exchange OFF the critical path: `submit(img)` copies the finished frame into one of `depth` staging buffers and
+    starts its gather to rank 0 asynchronously (dist.gather(async_op=True): RCCL runs it on its own stream once the copy is done),
+    so that frame i travels over xGMI while frame i + 1 renders; a staging buffer is waited for only when it comes round again.
+    `finish()` waits for everything in flight.  On rank 0 `frames(k)` is the list of the `world` frames of round k mod depth
+    (valid after that round's wait).  With gloo the tensors live on the host and submit() blocks for the device-to-host copy."""
+
+    def __init__(self, world, rank, shape, dtype=torch.float32, device="cuda", group=None, depth=2):
+        import torch.distributed as dist
+        self.dist, self.world, self.rank, self.group, self.depth = dist, world, rank, group, depth
+        self.staging = [torch.empty(tuple(shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.dest = [torch.empty((world,) + tuple(shape), dtype=dtype, device=device) for _ in range(depth)] if rank == 0 else None
+        self.work = [None] * depth
+        self.rounds = 0
+
+    def submit(self, img):
+        k = self.rounds % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()                       # the buffer's previous gather (two rounds ago) has long finished
+        self.staging[k].copy_(img, non_blocking=True)
+        bucket = list(self.dest[k].unbind(0)) if self.rank == 0 else None
+        self.work[k] = self.dist.gather(self.staging[k], gather_list=bucket, dst=0, group=self.group, async_op=True)
+        self.rounds += 1
+        return k
+
+    def frames(self, k):
+        return list(self.dest[k % self.depth].unbind(0)) if self.rank == 0 else None
+
+    def finish(self):
+        for k, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[k] = None
+
+
+def band_of_rank(height, rank, world):
+    """Strong scaling of ONE frame: contiguous bands of image rows, rank r owns rows [y0, y0 + n)."""
+    base, extra = divmod(height, world)
+    y0 = rank * base + min(rank, extra)
+    return y0, base + (1 if rank < extra else 0)
+
+
 def render_job(render_frame, n_frames, rank=0, world=1, group=None, gather=True, frame_like=None):
     """Runs render_frame(i) -> (C,H,W) tensor for this rank's frames; returns the (n_frames,C,H,W) stack on
     rank 0 (None elsewhere) if gather.  One gather to rank 0 per round of `world` frames (3 MB per 512^2 RGB

@@ -33,3 +33,19 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["config"]["dist_world_size"] == 2 and d["config"]["dist_backend"] == "gloo"
     assert d["scaling"] == "weak" and d["value"] > 0 and d["config"]["rays_per_step"] == 128 * 128
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_splits_one_frame_into_bands():
+    """--scaling strong: both ranks render one band of rows of the SAME frame per step; value counts the frame's rays once."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--scaling", "strong", "--steps", "2",
+                        "--warmup", "1", "--res", "128", "--samples", "16", "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gather_ms_per_round_alone"] > 0
+    assert abs(d["value"] - 128 * 128 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+

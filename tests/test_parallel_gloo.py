@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from keypointnerf_amd.parallel import (frames_of_rank, orbit_cam_tar, orbit_target_camera, render_job,
+from keypointnerf_amd.parallel import (FrameGatherer, band_of_rank, frames_of_rank, orbit_cam_tar, orbit_target_camera, render_job,
                                        zju_orbit_cameras)
 
 
@@ -36,6 +36,43 @@ def _worker(rank, world, port, n_frames, q):
     q.put((rank, rendered, None if out is None else out.clone()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _gatherer_worker(rank, world, port, rounds, q):
+    """FrameGatherer: every rank submits one frame per round (asynchronously, two staging buffers); rank 0 reads each round's
+    frames after the buffer's next wait / finish()."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = FrameGatherer(world, rank, (3, 4, 5), device="cpu")
+    got = []
+    for r in range(rounds):
+        k = g.submit(_fake_frame(r * world + rank))
+        if r >= 1 and rank == 0:                     # round r - 1 used the other buffer: wait for it, then read it
+            g.work[(k + 1) % 2].wait()
+            got.append(torch.stack(g.frames(k + 1)).clone())
+    g.finish()
+    if rank == 0:
+        got.append(torch.stack(g.frames(rounds - 1)).clone())
+    q.put((rank, None, torch.cat(got) if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_frame_gatherer_delivers_every_round():
+    world, rounds = 2, 5
+    res = _run_world(_gatherer_worker, world, rounds)
+    expect = torch.stack([_fake_frame(i) for i in range(world * rounds)])
+    assert torch.equal(res[0][1], expect) and res[1][1] is None
+
+
+def test_bands_partition_the_rows():
+    for h, w in ((512, 8), (512, 3), (7, 4), (4096, 8)):
+        rows = []
+        for r in range(w):
+            y0, n = band_of_rank(h, r, w)
+            rows += list(range(y0, y0 + n))
+        assert rows == list(range(h))
 
 
 def test_assignment_is_a_partition():
