@@ -707,20 +707,21 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_f2(kpn_scene_dev sc, kpn_points ps, con
 // The colour head's gather records of a batch (slabs 8, 9 of every (tile, view) block of the row scratch; kpn_row_record_a / _b,
 // model.py:806-832), for the pair-tile rows kernels: inside those the two parts ran as a divergent branch of the half-waves
 // (~800 issue slots per work item in a VALU-bound stream plus exposed tap latency).  Here a lane owns one (point, view) pair and
-// computes BOTH parts — lanes 0..31 view 2u, lanes 32..63 view 2u + 1 of one tile — without divergence and with enough waves
-// in flight to hide the taps; it writes part A to the row's h = 0 slot and part B to its h = 1 slot.
+// computes BOTH parts without divergence, with enough waves in flight to hide the taps: a wavefront takes the 64 points of a
+// tile pair for ONE view (the view's table entries are wave-uniform: scalar loads) and writes part A to the row's h = 0 slot
+// and part B to its h = 1 slot.
 __global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_points ps, const int* __restrict__ list,
                                                      const int* __restrict__ count_ptr, float* __restrict__ xscr, kpn_batch batch) {
-    const int lane = threadIdx.x & 63, p = lane & 31, vsel = lane >> 5;
+    const int lane = threadIdx.x & 63, p = lane & 31, tsel = lane >> 5;
     const int count = *count_ptr;
     int t0, t1;
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;
-    const int nbt = t1 - t0, vpairs = (sc.V + 1) >> 1;
-    const int nwork = nbt * vpairs;
+    const int nbt = t1 - t0;
+    const int nwork = ((nbt + 1) >> 1) * sc.V;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int wi = wave; wi < nwork; wi += nwaves) {
-        const int tr = wi / vpairs, v = 2 * (wi - tr * vpairs) + vsel;
-        if (v >= sc.V) continue;
+        const int pair = wi / sc.V, v = wi - pair * sc.V;       // wave-uniform
+        const int tr = 2 * pair + tsel;
         int64_t ci = (int64_t)(t0 + tr) * KPN_TILE + p;
         if (ci >= count) ci = count - 1;
         float P[3], D[3];
@@ -730,7 +731,9 @@ __global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_point
         float4 a0, a1, b0, b1;
         kpn_row_record_a(sc, tb, v, q, P, D, a0, a1);
         kpn_row_record_b(sc, v, q, b0, b1);
-        float4* rec = reinterpret_cast<float4*>(xscr) + ((size_t)(tr * sc.V + v) * KPN_ROW_SLABS + 8) * 64;
-        rec[p] = a0; rec[32 + p] = b0; rec[64 + p] = a1; rec[64 + 32 + p] = b1;
+        if (tr < nbt) {                                          // an odd batch ends in half a pair
+            float4* rec = reinterpret_cast<float4*>(xscr) + ((size_t)(tr * sc.V + v) * KPN_ROW_SLABS + 8) * 64;
+            rec[p] = a0; rec[32 + p] = b0; rec[64 + p] = a1; rec[64 + 32 + p] = b1;
+        }
     }
 }

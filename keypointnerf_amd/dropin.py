@@ -318,9 +318,10 @@ def install(net, rows_mode=None):
         if not uniform:                                              # validation: src/model.py:1018-1022 + :1049-1053
             yg, xg = torch.meshgrid(torch.arange(0, height, step, device=dev), torch.arange(0, width, step, device=dev), indexing="ij")
             grids = torch.stack([xg, yg], -1).view(-1, 2) + torch.tensor([x0, y0], device=dev)
-            with torch.no_grad():
-                return stochastic_render(net, img_in, cam_in, n_views, cam_tar, grids, ny, nx, tar_img, feat_geo, feat_tex,
-                                         sp_data, False, **config)
+            # like the reference's eval-mode forward, differentiable when the caller has gradients enabled (fine-tuning with
+            # net.eval() to freeze the norm layers); Lightning's validation loop runs it under no_grad / inference_mode
+            return stochastic_render(net, img_in, cam_in, n_views, cam_tar, grids, ny, nx, tar_img, feat_geo, feat_tex,
+                                     sp_data, False, **config)
         scene = st.prepared_scene(img_in, cam_in, feat_geo, feat_tex, sp_data, config["src_foreground_mask"])
         Sc, Sf = config.get("sample_per_ray_c", 64), config.get("sample_per_ray_f", 64)
         plan = st.plan(scene, (x0, y0, step, nx, ny), Sc, Sf, fine)

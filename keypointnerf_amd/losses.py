@@ -7,8 +7,9 @@ with the reference's keys (``e_pix_c``, ``e_pix_l1``, ``e_vgg``, ``e_all``) and 
 are ``torch.ops.kpnerf.pix_l1_loss`` (one kernel each, value and seed gradient together), so ``loss.backward()`` hands
 ``kpn_render_rays_train_backward`` its ``d_tex_fg`` / ``d_tex_fg_fine`` without eager elementwise passes.  The perceptual
 term stays the caller's ``vggloss`` module (a pretrained torchvision VGG19 — model weights that are not part of this
-path; its gradient joins ``d_tex_fg_fine`` through autograd).  Terms the shipped configuration switches off (l2, lp, ssim,
-top-k, mask loss, aux outputs) are refused rather than silently dropped.
+path; its gradient joins ``d_tex_fg_fine`` through autograd).  The terms the shipped configuration switches off behave as in
+the reference: l2 / lp / the mask losses keep its eager formulas, an ssim weight and `*top*` lambdas have no effect there
+either; only the auxiliary texture heads (never produced by this renderer) are refused.
 
 ``install_loss(module)`` rebinds the module-global ``compute_error`` that ``KeypointNeRF.forward`` looks up
 (reference src/model.py:894) — the same kind of seam as dropin.install uses for the renderer.
@@ -19,33 +20,46 @@ from . import torch_ops  # noqa: F401  (registers torch.ops.kpnerf.*)
 
 
 def pix_loss(src, tar, w_losses={"l1": 1.0}):
-    """reference src/utils.py:159-185, L1 term only."""
+    """reference src/utils.py:173-196: the L1 term (the one configs/zju.json switches on) is one device kernel; l2 / lp keep the
+    reference's eager formulas; an "ssim" weight is ignored exactly as the reference ignores it (its pix_loss has no such
+    branch).  The top-k terms cannot occur: compute_error_nerf collects the `*top*` lambdas but never passes them on (:124-127)."""
     losses = {}
     for k, v in w_losses.items():
         if v <= 0.0:
             continue
-        if k != "l1":
-            raise NotImplementedError(f"pix_loss term {k!r} is switched off in configs/zju.json and not built here")
-        losses[k] = torch.ops.kpnerf.pix_l1_loss(src.contiguous(), tar.contiguous(), float(v))[0]
+        if k == "l1":
+            losses[k] = torch.ops.kpnerf.pix_l1_loss(src.contiguous(), tar.contiguous(), float(v))[0]
+        elif k == "l2":
+            losses[k] = v * (src - tar).pow(2.0).mean()
+        elif k == "lp":
+            losses[k] = v * ((src - tar).abs() + 1e-4).pow(0.4).mean()
     return losses
 
 
 def compute_error_nerf(out_nerf, lambdas, vggloss):
-    """reference src/utils.py:108-171 for the outputs batch_render_pifu_nerf produces (no aux heads)."""
+    """reference src/utils.py:108-171 for the outputs batch_render_pifu_nerf produces (no aux heads): same keys under the same
+    conditions — e_pix_c only when it is > 0 (:141, one host sync as there), the mask losses when tar_alpha is present and
+    lambda_mloss > 0 (:155-163), `*top*` lambdas without effect (:124-127)."""
     lambda_l1_c = lambdas.get("lambda_l1_c", 10.0)
     pix_weights = {"l1": lambdas.get("lambda_l1", 10.0), "l2": lambdas.get("lambda_l2", 0.0), "lp": lambdas.get("lambda_lp", 0.0),
                    "ssim": lambdas.get("lambda_ssim", 0.0)}
     lambda_vgg = lambdas.get("lambda_vgg", 1.0)
-    if lambdas.get("lambda_mloss", 0.0) > 0.0 or any("top" in k for k in lambdas):
-        raise NotImplementedError("mask loss / top-k pixel losses are not used by configs/zju.json and not built here")
+    lambda_mloss = lambdas.get("lambda_mloss", 0.0)
     if "tex_aux_cal" in out_nerf or "tex_aux_cal_fine" in out_nerf:
         raise NotImplementedError("auxiliary texture heads are not produced by batch_render_pifu_nerf")
     err_dict = {}
     if "tex_cal" in out_nerf and lambda_l1_c > 0.0:
-        err_dict["e_pix_c"] = pix_loss(out_nerf["tex_cal"], out_nerf["tar_img"], {"l1": lambda_l1_c})["l1"]
+        loss_pix_c = pix_loss(out_nerf["tex_cal"], out_nerf["tar_img"], {"l1": lambda_l1_c})["l1"]
+        if loss_pix_c > 0.0:
+            err_dict["e_pix_c"] = loss_pix_c
     if "tex_cal_fine" in out_nerf:
         for k, v in pix_loss(out_nerf["tex_cal_fine"], out_nerf["tar_img"], pix_weights).items():
             err_dict[f"e_pix_{k}"] = v
+    if "tar_alpha" in out_nerf and lambda_mloss > 0.0:
+        for key, name in (("alpha", "mask_loss_c"), ("alpha_fine", "mask_loss_f")):
+            if key in out_nerf:
+                err_dict[name] = lambda_mloss * torch.nn.functional.mse_loss(out_nerf[key].clip(1e-3, 1.0).squeeze(),
+                                                                            out_nerf["tar_alpha"].squeeze())
     if vggloss is not None and "tex_cal_fine" in out_nerf:
         loss_vgg = lambda_vgg * vggloss(out_nerf["tex_cal_fine"], out_nerf["tar_img"])
         if loss_vgg > 0.0:                       # the reference's own test, src/utils.py:168 (one host sync, as there)

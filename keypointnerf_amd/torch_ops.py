@@ -163,6 +163,29 @@ def _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
                              disable_fg_mask=fg_mask is None, sigma=scal[3])
 
 
+# One training iteration calls the forward op and then the backward op with the SAME parameters and maps: the packed weights
+# (weight-norm fold + operand order + fp16 / bf16 streams) and the prepared scene (NCHW -> NHWC of every map) of the forward call
+# are kept for the backward call instead of being built twice.  Keyed on storage + version counter of every tensor (autograd
+# hands the backward op new tensor objects over the same storage), so an in-place change in between is a miss, never a stale hit.
+_iter_cache = {"key": None, "scene": None, "w": None}
+
+
+def _tensor_key(t):
+    if t is None:
+        return None
+    return (t.data_ptr(), t._version if not t.is_inference() else -1, tuple(t.shape), str(t.device))
+
+
+def _scene_and_weights(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
+    tensors = (plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask)
+    key = tuple(_tensor_key(t) for t in tensors) + (tuple(scal),)
+    if any(t is not None and t.is_inference() for t in tensors) or key != _iter_cache["key"]:
+        _iter_cache["scene"] = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal)
+        _iter_cache["w"] = ops.PackedWeights.from_plain(plain, device=geo0.device)
+        _iter_cache["key"] = key
+    return _iter_cache["scene"], _iter_cache["w"]
+
+
 @_lib.custom_op("kpnerf::render_rays_train", mutates_args=(), device_types="cuda")
 def render_rays_train(plain: torch.Tensor, geo0: torch.Tensor, geo1: torch.Tensor, tex: torch.Tensor, img: torch.Tensor,
                       KRT: torch.Tensor, extrin: torch.Tensor, kpt3d: torch.Tensor, fg_mask: Optional[torch.Tensor],
@@ -176,8 +199,7 @@ def render_rays_train(plain: torch.Tensor, geo0: torch.Tensor, geo1: torch.Tenso
     Outputs: (1,3,R) / (1,R) tensors in the order of `pix`, then the pass state (uint8; empty unless keep_state): with it
     the backward op starts from the forward's rays, depths, field values, valid lists and rows instead of repeating the
     forward (kpn_render_rays_train_keep / kpn_render_rays_train_backward_kept)."""
-    scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
-    w = ops.PackedWeights.from_plain(plain, device=geo0.device)
+    scene, w = _scene_and_weights(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
     res = ops.render_rays_train(scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f,
                                 noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse,
                                 n_fine=n_fine, keep_state=keep_state)
@@ -207,8 +229,7 @@ def render_rays_train_backward(plain: torch.Tensor, geo0: torch.Tensor, geo1: to
                                ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """loss.backward() through render_rays_train (kpn_render_rays_train_backward) -> (d_plain, d_geo0, d_geo1, d_tex),
     the map gradients NCHW like the maps."""
-    scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
-    w = ops.PackedWeights.from_plain(plain, device=geo0.device)
+    scene, w = _scene_and_weights(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, list(scene_scalars))
     grads = dict(zip(_OUT_KEYS, (d_tex_fg, d_depth, d_alpha, d_tex_fg_fine, d_depth_fine, d_alpha_fine, d_sdf)))
     d_plain, d_g0, d_g1, d_tx = ops.render_rays_train_backward(
         scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f, grads,
@@ -222,17 +243,25 @@ def _(plain, geo0, geo1, tex, *rest):
 
 
 def _train_setup(ctx, inputs, output):
-    ctx.args = inputs[:25]                 # tensors and scalars of the forward call
+    # tensors go through save_for_backward, so that autograd's version-counter check raises if one of them (feature maps, the
+    # flat parameters, the draws) or the kept pass state is modified in place between forward and backward — the state is only
+    # valid for the values it was computed from; scalars stay on ctx
+    args = list(inputs[:25])
+    ctx.tensor_slots = [i for i, a in enumerate(args) if isinstance(a, torch.Tensor)]
+    ctx.scalars = [None if isinstance(a, torch.Tensor) else a for a in args]
+    ctx.save_for_backward(*[args[i] for i in ctx.tensor_slots], output[7])   # ... and the pass state (empty unless keep_state)
     ctx.n_inputs = len(inputs)
-    ctx.state = output[7]                  # the pass state (empty unless keep_state): rays, depths, rgba, lists, rows
     ctx.set_materialize_grads(False)
 
 
 def _train_bwd(ctx, *grads):
-    state = ctx.state if ctx.state.numel() > 0 else None
+    saved = ctx.saved_tensors
+    args = list(ctx.scalars)
+    for i, t in zip(ctx.tensor_slots, saved[:-1]):
+        args[i] = t
+    state = saved[-1] if saved[-1].numel() > 0 else None
     d_plain, d_g0, d_g1, d_tx = torch.ops.kpnerf.render_rays_train_backward(
-        *ctx.args, *[None if g is None else g.contiguous() for g in grads[:7]], state)
-    ctx.state = None                       # release the rows as soon as they have been used
+        *args, *[None if g is None else g.contiguous() for g in grads[:7]], state)
     return (d_plain, d_g0, d_g1, d_tx) + (None,) * (ctx.n_inputs - 4)
 
 

@@ -109,6 +109,28 @@ def test_encoders_run_once_per_source_set_and_again_when_their_state_changes(emu
         uninstall(net)
 
 
+def test_compute_error_matches_the_reference_for_its_other_lambdas(emulated):
+    """losses.compute_error against the reference's compute_error (src/utils.py:97-171) beyond the shipped lambdas: l2 / lp /
+    mask loss switched on, an ssim weight and `*top*` keys present (both without effect in the reference), weights of 0 —
+    same keys, same values, nothing refused."""
+    from keypointnerf_amd import losses
+    ref_shim.load_reference()
+    import src.utils as rutils
+    g = torch.Generator().manual_seed(3)
+    out = {"tex_cal": torch.rand(1, 3, 8, 8, generator=g), "tex_cal_fine": torch.rand(1, 3, 8, 8, generator=g),
+           "alpha": torch.rand(1, 1, 8, 8, generator=g), "alpha_fine": torch.rand(1, 1, 8, 8, generator=g),
+           "tar_img": torch.rand(1, 3, 8, 8, generator=g), "tar_alpha": (torch.rand(1, 1, 8, 8, generator=g) > 0.5).float()}
+    for lambdas in ({"lambda_l1": 10.0, "lambda_l1_c": 1.0, "lambda_vgg": 0.5},
+                    {"lambda_l1": 2.0, "lambda_l1_c": 0.0, "lambda_l2": 3.0, "lambda_lp": 0.5, "lambda_ssim": 1.0, "lambda_mloss": 4.0,
+                     "lambda_l1top30": 1.0, "lambda_l2top10": 0.0}):
+        want_loss, want = rutils.compute_error(out, None, lambdas)
+        got_loss, got = losses.compute_error(out, None, lambdas)
+        assert set(got) == set(want), (set(got), set(want))
+        for k in want:
+            assert abs(float(got[k]) - float(want[k])) <= 1e-6 * max(1.0, abs(float(want[k]))), k
+        assert abs(float(got_loss) - float(want_loss)) <= 1e-6 * max(1.0, abs(float(want_loss)))
+
+
 def test_validation_call_of_the_live_class_consumes_the_same_random_stream(emulated):
     """KeypointNeRF.forward in eval mode (validation_step, src/model.py:509-526 -> :866-884): uniform=False, jittered
     depths and a CPU-drawn importance u.  Same seed => the reference and the drop-in must draw the same numbers."""
