@@ -395,7 +395,7 @@ def main():
             "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "algorithmic_bytes_per_launch": 320.0 * rows.value / max(1, launches.value),
+                         "algorithmic_bytes_per_launch": (320.0 if args.geo_rows_mode == 0 else 256.0) * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "surplus_launches": surplus.value,
                          "traffic_source": "profiles/geo_rows_traffic.json: PMC (FETCH_SIZE, WRITE_SIZE) bytes per row from separate rocprofv3 --pmc passes of this kernel, times this run's rows per launch" if traffic is not None else None,

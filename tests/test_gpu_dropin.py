@@ -185,9 +185,21 @@ def test_validation_path_uniform_false_is_served():
                                    scene["bounds"], pix, Sc, Sf, u_c.cpu().numpy().reshape(R, Sc), n_c.cpu().numpy().reshape(-1),
                                    n_f.cpu().numpy().reshape(-1), u_f.numpy().reshape(R, Sf), (1 << V) - 1, (1 << V) - 1, 0.01)
     for k in ("tex_fg", "tex_fg_fine"):
-        assert np.abs(out[k][0].reshape(3, -1).T.cpu().numpy() - ref[k]).max() <= 1e-4, k
+        assert np.abs(out[k][0].detach().reshape(3, -1).T.cpu().numpy() - ref[k]).max() <= 1e-4, k
     for k in ("alpha", "alpha_fine"):
-        assert np.abs(out[k].reshape(-1).cpu().numpy() - ref[k]).max() <= 1e-4, k
+        assert np.abs(out[k].detach().reshape(-1).cpu().numpy() - ref[k]).max() <= 1e-4, k
+    # like the reference's eval-mode forward, the call is differentiable when gradients are enabled (fine-tuning with net.eval())
+    # and carries no graph under no_grad (Lightning's validation loop)
+    assert out["tex_fg_fine"].requires_grad == any(p.requires_grad for p in net.parameters())
+    with torch.no_grad():
+        torch.manual_seed(21)
+        out2 = net.batch_render_pifu_nerf(net=net, img_in=s["img"], cam_in=s["cam"], n_views=V, cam_tar=s["cam_tar"], level=level,
+                                          stride=stride, tar_img=tar, bg_img=None, feat_geo=s["feat_geo"], feat_tex=s["feat_tex"],
+                                          sp_data=dict(s["sp_data"]), camcenter=None, objcenter=None,
+                                          msk=torch.ones(1, 1, H, W, device="cuda"), src_foreground_mask=s["src_foreground_mask"],
+                                          bounds=s["bounds"], fine=True, uniform=False, blur=3, rand_noise_std=0.01,
+                                          sample_per_ray_c=Sc, sample_per_ray_f=Sf)
+    assert not out2["tex_fg_fine"].requires_grad and torch.equal(out2["tex_fg_fine"], out["tex_fg_fine"].detach())
 
 
 @pytest.mark.parametrize("case,seed", [("case_k_v3_train_grad", 6), ("case_l_v3_train_grad", 10)])
