@@ -171,7 +171,7 @@ def set_perturbation(eps_z=0.0, eps_f=0.0, seed=0):
     lib().kpo_set_perturbation(ctypes.c_float(eps_z), ctypes.c_float(eps_f), ctypes.c_uint32(seed))
 
 
-def render_envelope(oscene, wflat, cam_tar, bounds, pix, Sc=64, Sf=64, fine=True, trials=6, eps_z=2.4e-7, eps_f=1e-6, ref=None):
+def render_envelope(oscene, wflat, cam_tar, bounds, pix, Sc=64, Sf=64, fine=True, trials=8, eps_z=2.4e-7, eps_f=1e-6, ref=None):
     """Per ray and output key, the largest movement of the oracle's OWN result over `trials` re-runs with its intermediate values
     disturbed at fp32-rounding level (see kpo_set_perturbation): {key: (R,) array}.  Rays where this exceeds the parity bar are
     ill-conditioned in the reference's formulation itself."""

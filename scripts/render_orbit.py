@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--save", default="")
+    ap.add_argument("--with-encoders", action="store_true",
+                    help="every frame is a new source set, as in render_video_zju: run both image encoders (cost-equivalent stand-ins of "
+                         "the reference's 28 M parameters, scripts/encoder_standin.py) on the 3 x 512^2 sources and prepare the scene from "
+                         "their maps before rendering — once per frame, which is what the drop-in does (the reference runs them twice)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,9 +53,20 @@ def main():
     cams = zju_orbit_cameras(headpose, sc_factor=1.0, n_frames=90, im_w=args.res, im_h=args.res)
     cam_tars = [orbit_cam_tar(c) for c in cams]
 
+    enc = None
+    if args.with_encoders:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import encoder_standin
+        enc = (encoder_standin.GeoEncoder().cuda().eval(), encoder_standin.TexEncoder().cuda().eval())
+
     def render_frame(i):
         cam = cam_tars[i % 90]                                                      # camera = orbit[frame_index % 90], :214
-        out = ops.render_rays(ps, w, cam, scene["bounds"], plan=plan)
+        scene_i = ps
+        if enc is not None:
+            with torch.no_grad():
+                feat_geo, feat_tex = encoder_standin.encode(enc[0], enc[1], scene["img"])
+            scene_i = ops.PreparedScene(scene["img"], scene["cam"], feat_geo, feat_tex, scene["sp_data"], scene["src_foreground_mask"])
+        out = ops.render_rays(scene_i, w, cam, scene["bounds"], plan=plan)
         return ops.frame_to_rgb8(out["tex_fg_fine"]).permute(2, 0, 1).contiguous()  # (3,H,W) uint8, what the gather moves
 
     render_frame(0)
@@ -61,7 +76,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
-        print(f"orbit: {args.frames} frames {args.res}x{args.res} on {world} GPU(s): {dt:.2f} s = {args.frames / dt:.2f} frames/s; "
+        print(f"orbit{' with both encoders per frame' if enc is not None else ''}: {args.frames} frames {args.res}x{args.res} on {world} GPU(s): {dt:.2f} s = {args.frames / dt:.2f} frames/s; "
               f"gathered {tuple(frames.shape)} {frames.dtype}")
         if args.save:
             import numpy as np

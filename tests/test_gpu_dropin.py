@@ -303,8 +303,13 @@ def test_training_loss_on_the_device():
     loss2.backward()
     extra = (0.5 * 2.0 * (tex_f - out["tar_img"]) / tex_f.numel()).detach().cpu().numpy()
     assert np.abs(tex_f.grad.cpu().numpy() - (g["d_tex_fg_fine"] + extra)).max() < 1e-9
+    # the lambdas the shipped configuration switches off behave as in the reference (src/utils.py:173-196): l2 keeps its formula,
+    # an ssim weight and `*top*` keys have no effect; only the (never produced) auxiliary heads are refused
+    loss3, err3 = compute_error(out_nerf=out, vggloss=None, lambdas=dict(lambdas, lambda_l2=1.0, lambda_ssim=1.0, lambda_l1top30=1.0))
+    assert set(err3) == set(err) | {"e_pix_l2"}
+    assert abs(float(err3["e_pix_l2"]) - float(((tex_f - out["tar_img"]) ** 2).mean())) < 1e-6
     with pytest.raises(NotImplementedError):
-        compute_error(out_nerf=out, vggloss=None, lambdas=dict(lambdas, lambda_l2=1.0))
+        compute_error(out_nerf=dict(out, tex_aux_cal=out["tex_cal"]), vggloss=None, lambdas=lambdas)
 
 
 def test_real_keypointnerf_on_rocm_when_the_reference_is_mounted():
