@@ -20,7 +20,7 @@
 #include "kpn_device.h"
 
 struct kpn_bwd_bufs {
-    float* X0;  // [rows][232]: cols (12h+j)*7+t = PE block t of keypoint 12h+j; cols 168..231 geometry channels
+    float* X0;  // [rows][232]: cols 14j+7h+t = PE block t of keypoint 12h+j; cols 168..231 geometry channels
     float* X1;  // [rows][128]
     float* X2;  // [rows][136]
     float* X3;  // [rows][128]  (cols >= 120 unused)
@@ -38,7 +38,8 @@ struct kpn_bwd_bufs {
 #define KPN_ST4(p, v) (*reinterpret_cast<float4*>(p) = (v))
 #define KPN_ST1(p, v) (*(p) = (v))
 #endif
-#define KPN_SCAT_LD 76  // 72 floats + pad: rows start on different banks, float4-aligned
+#define KPN_STAGE_LD 132  // 128 floats + pad: rows start on different banks, float4-aligned
+#define KPN_SCAT_LD KPN_STAGE_LD
 #ifndef KPN_BWD_OCC
 #define KPN_BWD_OCC 2
 #endif
@@ -62,7 +63,12 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
     const int nwork = ntiles * sc.V;
     const float pe_pi = 3.14159274101257324f;
     __shared__ __attribute__((aligned(16))) float bias_s[3][128];
-    __shared__ __attribute__((aligned(16))) float scat_s[4][KPN_TILE][KPN_SCAT_LD];  // per wave: 32 rows x (64 + 8 channels)
+    // Per wave: 32 rows x up to 128 features (+ pad).  Every dump below is staged here and written out with the LANES ALONG THE
+    // FEATURES (one instruction = two whole 512-B rows): from the registers a lane holds ONE row, and a store instruction issued
+    // from that layout touches 64 different cache lines with 4 or 16 bytes each — measured (PMC, profiles/r03_j_train_pmc_counters.txt)
+    // 7.1 KB written per row for 4.3 KB of dumps and a kernel at 27 % matrix-pipe busy.  The same buffer is the transposition
+    // buffer of the feature-map scatter at the end of a tile.
+    __shared__ __attribute__((aligned(16))) float stage_s[4][KPN_TILE][KPN_STAGE_LD];
     __shared__ __attribute__((aligned(16))) int4 tap_o[4][2][KPN_TILE];
     __shared__ __attribute__((aligned(16))) float4 tap_w[4][2][KPN_TILE];
     {
@@ -90,10 +96,22 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
         const kpn_taps tp0 = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);
         const kpn_taps tp1 = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
-        float* const x0row = bufs.X0 + row * KPN_LDX0;
         float* const x1row = bufs.X1 + row * 128;
         float* const x2row = bufs.X2 + row * KPN_LDX2;
         float* const x3row = bufs.X3 + row * 128;
+        float* const stg = stage_s[threadIdx.x >> 6][0];         // this wave's staging tile
+        float* const srow = stg + p * KPN_STAGE_LD;              // this lane's row of it
+        const size_t row0 = (size_t)wi * KPN_TILE;               // first row of the tile in the dumps
+        // write columns [0, ncols) of the staged tile to dump[(row0 + r) * ld + col0 + c]; ncols a multiple of 4
+        auto flush = [&](float* __restrict__ dump, int ld, int col0, int ncols) {
+            KPN_WAVE_SYNC();
+            const int q = ncols >> 2;                             // float4 per row
+            for (int i = lane; i < KPN_TILE * q; i += 64) {
+                const int r = i / q, c = (i - r * q) << 2;
+                KPN_ST4(dump + (row0 + r) * ld + col0 + c, *reinterpret_cast<const float4*>(stg + r * KPN_STAGE_LD + c));
+            }
+            KPN_WAVE_SYNC();
+        };
 
         // ================= F phase (same arithmetic as k_geo_rows) =================
         kpn_f32x16 a0[4];
@@ -117,17 +135,21 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 x[1] = s1 * w; x[2] = c1 * w;
                 x[3] = s2 * w; x[4] = c2 * w;
                 x[5] = s4 * w; x[6] = c4 * w;
-                float* d = x0row + (12 * h + j) * 7;
+                // X0's encoding columns are keypoint-major: column 14 j + 7 h + t (kpn_grad_col, cmap 1): the values of six
+                // keypoint steps (both halves) are 84 adjacent columns = one staged flush
+                float* d = srow + (j % 6) * 14 + 7 * h;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) KPN_ST1(d + i, x[i]);
+                for (int i = 0; i < 7; ++i) d[i] = x[i];
+                if constexpr (j == 5 || j == 11) flush(bufs.X0, KPN_LDX0, 84 * (j / 6), 84);
             }, a0);
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
             kpn_mfma_layer<32, 4, 4>(wp + kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp0);
                 x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
-                KPN_ST4(x0row + 168 + 32 * h + 4 * g, f);
+                *reinterpret_cast<float4*>(srow + 32 * h + 4 * g) = f;
             }, a0);
+            flush(bufs.X0, KPN_LDX0, 168, 64);
         }
         // chained group g of a 128-vector = features 32(g/4) + 8(g%4) + 4h .. +3 of this lane's row
         kpn_f32x16 a1[4];
@@ -136,23 +158,25 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             constexpr int g = decltype(gi)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a0[g / 4][(g % 4) * 4 + i]);
-            KPN_ST4(x1row + 32 * (g / 4) + 8 * (g % 4) + 4 * h, make_float4(x[0], x[1], x[2], x[3]));
+            *reinterpret_cast<float4*>(srow + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
         }, a1);
+        flush(bufs.X1, 128, 0, 128);
         kpn_f32x16 a2[4];
         {
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1);
-            KPN_ST4(x2row + 128 + 4 * h, f);
+            KPN_ST4(x2row + 128 + 4 * h, f);   // (8 of 136 columns: left as a per-row store)
             kpn_load_bias<4>(bias_s[2], h, a2);
             kpn_mfma_layer<68, 4, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 if constexpr (g < 16) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a1[g / 4][(g % 4) * 4 + i]);
-                    KPN_ST4(x2row + 32 * (g / 4) + 8 * (g % 4) + 4 * h, make_float4(x[0], x[1], x[2], x[3]));
+                    *reinterpret_cast<float4*>(srow + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
                 } else {
                     x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
                 }
             }, a2);
+            flush(bufs.X2, KPN_LDX2, 0, 128);
         }
         // X3 = softplus(a2), the input of layers1.3 (its forward product itself is not needed here)
 #pragma unroll
@@ -160,8 +184,9 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             float4 o;
             o.x = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 0]); o.y = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 1]);
             o.z = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 2]); o.w = kpn_softplus100(a2[g / 4][(g % 4) * 4 + 3]);
-            KPN_ST4(x3row + 32 * (g / 4) + 8 * (g % 4) + 4 * h, o);
+            *reinterpret_cast<float4*>(srow + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = o;
         }
+        flush(bufs.X3, 128, 0, 128);
 
         // ================= B phase =================
         // dX3 = W3^T dY3
@@ -172,14 +197,14 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             for (int r = 0; r < 16; ++r) d3[ob][r] = 0.0f;
         {
             const float* grow = dx_compact ? dx + row * 64 : dx + ((size_t)n * sc.V + v) * 64;
-            float* d3row = bufs.D3 + row * 64;
             kpn_mfma_layer<32, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
                 const float4 f = *reinterpret_cast<const float4*>(grow + col);
                 x[0] = f.x * live; x[1] = f.y * live; x[2] = f.z * live; x[3] = f.w * live;
-                KPN_ST4(d3row + col, make_float4(x[0], x[1], x[2], x[3]));
+                *reinterpret_cast<float4*>(srow + col) = make_float4(x[0], x[1], x[2], x[3]);
             }, d3);
+            flush(bufs.D3, 64, 0, 64);
         }
         // dA2 = dX3 * softplus'(a2);  [dX2 | d hd] = W2^T dA2
         kpn_f32x16 d2[5];
@@ -188,7 +213,6 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[ob][r] = 0.0f;
         {
-            float* drow = bufs.D2 + row * 128;
             kpn_mfma_layer<64, 5, 4>(wp + kpn_bseg_woff(BSEG_G1_2T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -197,8 +221,9 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 x[1] = d3[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d3[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
                 x[3] = d3[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
-                KPN_ST4(drow + col, make_float4(x[0], x[1], x[2], x[3]));
+                *reinterpret_cast<float4*>(srow + col) = make_float4(x[0], x[1], x[2], x[3]);
             }, d2);
+            flush(bufs.D2, 128, 0, 128);
         }
         // the 8 hd channels (rows 128..135 of dX2 = block 4 regs 0..3: channels 4h..4h+3) go back to feat_geo[1]
         const float4 dhd = make_float4(d2[4][0], d2[4][1], d2[4][2], d2[4][3]);
@@ -209,7 +234,6 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[ob][r] = 0.0f;
         {
-            float* drow = bufs.D1 + row * 128;
             kpn_mfma_layer<64, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_1T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -218,8 +242,9 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 x[1] = d2[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d2[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
                 x[3] = d2[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
-                KPN_ST4(drow + col, make_float4(x[0], x[1], x[2], x[3]));
+                *reinterpret_cast<float4*>(srow + col) = make_float4(x[0], x[1], x[2], x[3]);
             }, d1);
+            flush(bufs.D1, 128, 0, 128);
         }
         // dA0 = dX1 * softplus'(a0);  d geo0 = W0[:,168:232]^T dA0
         kpn_f32x16 dg[2];
@@ -228,7 +253,6 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) dg[ob][r] = 0.0f;
         {
-            float* drow = bufs.D0 + row * 128;
             kpn_mfma_layer<64, 2, 4>(wp + kpn_bseg_woff(BSEG_G1_0T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -237,15 +261,16 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 x[1] = d1[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d1[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
                 x[3] = d1[g / 4][(g % 4) * 4 + 3] * kpn_softplus100_grad_from_value(s.w);
-                KPN_ST4(drow + col, make_float4(x[0], x[1], x[2], x[3]));
+                *reinterpret_cast<float4*>(srow + col) = make_float4(x[0], x[1], x[2], x[3]);
             }, dg);
+            flush(bufs.D0, 128, 0, 128);
         }
         // Scatter through the bilinear taps.  A lane holds 32 channels of ONE row; issued from this layout an atomic
         // instruction would touch 32 different texels (cache lines).  The tile is transposed through LDS instead:
         // lane = channel, so that one instruction adds 64 consecutive floats (two lines) of one texel.
         {
             const int w4 = threadIdx.x >> 6;
-            float* sg = scat_s[w4][0];
+            float* sg = stg;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -261,28 +286,10 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 tap_w[w4][1][p] = make_float4(tp1.w00 * live, tp1.w01 * live, tp1.w10 * live, tp1.w11 * live);
             }
             KPN_WAVE_SYNC();
-            float* g0 = bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64 + lane;
             const int npt = min(KPN_TILE, count - t * KPN_TILE);
-            for (int pt = 0; pt < npt; ++pt) {
-                const float val = sg[pt * KPN_SCAT_LD + lane];
-                const int4 o = tap_o[w4][0][pt];
-                const float4 ww = tap_w[w4][0][pt];
-                kpn_atomic_add(g0 + (size_t)o.x * 64, val * ww.x); kpn_atomic_add(g0 + (size_t)o.y * 64, val * ww.y);
-                kpn_atomic_add(g0 + (size_t)o.z * 64, val * ww.z); kpn_atomic_add(g0 + (size_t)o.w * 64, val * ww.w);
-            }
-            // 8 hd channels: lane = (point pt8, channel c), 8 points per instruction
-            float* g1 = bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8 + (lane & 7);
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                const int pt = grp * 8 + (lane >> 3);
-                if (pt < npt) {
-                    const float val = sg[pt * KPN_SCAT_LD + 64 + (lane & 7)];
-                    const int4 o = tap_o[w4][1][pt];
-                    const float4 ww = tap_w[w4][1][pt];
-                    kpn_atomic_add(g1 + (size_t)o.x * 8, val * ww.x); kpn_atomic_add(g1 + (size_t)o.y * 8, val * ww.y);
-                    kpn_atomic_add(g1 + (size_t)o.z * 8, val * ww.z); kpn_atomic_add(g1 + (size_t)o.w * 8, val * ww.w);
-                }
-            }
+            // one atomic per run of equal texel offsets and tap (kpn_scatter_rle*, kpn_device.h), not one per point
+            kpn_scatter_rle64(bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64, sg, KPN_SCAT_LD, tap_o[w4][0], tap_w[w4][0], npt, lane);
+            kpn_scatter_rle8(bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8, sg + 64, KPN_SCAT_LD, tap_o[w4][1], tap_w[w4][1], npt, lane);
             KPN_WAVE_SYNC();  // the next tile overwrites the exchange buffers
         }
     }
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const 
 // cmap: 0 = X columns are plain input features; 1 = X0 dump (first 168 columns in (keypoint, PE block) order);
 //       2 = base_layer.0's [mean' | var' | x'] dump (3 x 36 columns, x' order).  omap: 1 = dY rows are in x' order.
 __device__ __forceinline__ int kpn_grad_col(int cmap, int c) {
-    if (cmap == 1) return c < 168 ? (c % 7) * 24 + c / 7 : c;
+    if (cmap == 1) return c < 168 ? (c % 7) * 24 + 12 * ((c % 14) / 7) + c / 14 : c;   // X0 column 14 j + 7 h + t = PE block t of keypoint 12 h + j
     if (cmap == 2) { const int q = c % 36; return q < 35 ? (c / 36) * 35 + kpn_xprime_to_orig(q) : -1; }
     return c;
 }

@@ -623,19 +623,8 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
                     sg[1] = dq[12]; sg[2] = dq[13]; sg[3] = dq[14]; sg[4] = dq[15];
                 }
                 KPN_WAVE_SYNC();
-                float* gtex = B.dtex + (size_t)v * sc.th * sc.tw * 8 + (lane & 7);
                 const int npt = min(KPN_TILE, count - t * KPN_TILE);
-#pragma unroll
-                for (int grp = 0; grp < 4; ++grp) {
-                    const int pt = grp * 8 + (lane >> 3);
-                    if (pt < npt) {
-                        const float val = scat_s[w4][pt][lane & 7];
-                        const int4 o = tap_o[w4][pt];
-                        const float4 ww = tap_w[w4][pt];
-                        kpn_atomic_add(gtex + (size_t)o.x * 8, val * ww.x); kpn_atomic_add(gtex + (size_t)o.y * 8, val * ww.y);
-                        kpn_atomic_add(gtex + (size_t)o.z * 8, val * ww.z); kpn_atomic_add(gtex + (size_t)o.w * 8, val * ww.w);
-                    }
-                }
+                kpn_scatter_rle8(B.dtex + (size_t)v * sc.th * sc.tw * 8, scat_s[w4][0], 8, tap_o[w4], tap_w[w4], npt, lane);
                 KPN_WAVE_SYNC();
             }
             // ray_encoder reverse: dA(ray_encoder.2) = d x' * elu'(dir), in x' order

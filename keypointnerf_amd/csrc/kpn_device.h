@@ -474,6 +474,52 @@ __device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg,
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Scatter of a tile's feature-map gradients through the four bilinear taps (reverse of feat_sample, reference src/utils.py:74-89)
+// with RUN-LENGTH COMBINING.  The points of a tile are consecutive samples of a few rays, so neighbouring points project into the
+// same texels — and in training all 1024 rays of the 32 x 32 patch cover a handful of texels of a 1/8-resolution map: issued
+// one atomic per (point, tap), the float atomics serialised on those cache lines and were 43 % of k_geo_rows_bwd and 45 % of
+// k_color_bwd (ablation on the MI355X: 1.53 -> 0.88 ms and 0.95 -> 0.52 ms per call without them).  Here a lane walks the
+// points in order and adds up the contributions of a run of equal texel offsets in a register; one atomic per run and tap.
+//   sg: staged values [point][ld], tap_o / tap_w: per point the four texel offsets / weights (LDS), npt points.
+// C = 64 channels: lane = channel, the four taps in four accumulators.
+__device__ __forceinline__ void kpn_scatter_rle64(float* __restrict__ gmap, const float* __restrict__ sg, int ld, const int4* __restrict__ tap_o,
+                                                  const float4* __restrict__ tap_w, int npt, int lane) {
+    if (npt <= 0) return;
+    float* g = gmap + lane;
+    int4 cur = tap_o[0];
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (int pt = 0; pt < npt; ++pt) {
+        const float val = sg[pt * ld + lane];
+        const int4 o = tap_o[pt];
+        const float4 w = tap_w[pt];
+        if (o.x != cur.x) { kpn_atomic_add(g + (size_t)cur.x * 64, a0); a0 = 0.0f; cur.x = o.x; }
+        if (o.y != cur.y) { kpn_atomic_add(g + (size_t)cur.y * 64, a1); a1 = 0.0f; cur.y = o.y; }
+        if (o.z != cur.z) { kpn_atomic_add(g + (size_t)cur.z * 64, a2); a2 = 0.0f; cur.z = o.z; }
+        if (o.w != cur.w) { kpn_atomic_add(g + (size_t)cur.w * 64, a3); a3 = 0.0f; cur.w = o.w; }
+        a0 = fmaf(val, w.x, a0); a1 = fmaf(val, w.y, a1); a2 = fmaf(val, w.z, a2); a3 = fmaf(val, w.w, a3);
+    }
+    kpn_atomic_add(g + (size_t)cur.x * 64, a0); kpn_atomic_add(g + (size_t)cur.y * 64, a1);
+    kpn_atomic_add(g + (size_t)cur.z * 64, a2); kpn_atomic_add(g + (size_t)cur.w * 64, a3);
+}
+// C = 8 channels: lane = (half of the points, tap, channel): lanes 0..31 walk points [0, 16), lanes 32..63 points [16, 32)
+__device__ __forceinline__ void kpn_scatter_rle8(float* __restrict__ gmap, const float* __restrict__ sg, int ld, const int4* __restrict__ tap_o,
+                                                 const float4* __restrict__ tap_w, int npt, int lane) {
+    const int c = lane & 7, tau = (lane >> 3) & 3, p0 = 16 * (lane >> 5);
+    const int p1 = npt < p0 + 16 ? npt : p0 + 16;
+    if (p0 >= p1) return;
+    auto off = [&](int pt) { const int4 o = tap_o[pt]; return tau == 0 ? o.x : (tau == 1 ? o.y : (tau == 2 ? o.z : o.w)); };
+    auto wgt = [&](int pt) { const float4 w = tap_w[pt]; return tau == 0 ? w.x : (tau == 1 ? w.y : (tau == 2 ? w.z : w.w)); };
+    int cur = off(p0);
+    float a = 0.0f;
+    for (int pt = p0; pt < p1; ++pt) {
+        const int o = off(pt);
+        if (o != cur) { kpn_atomic_add(gmap + (size_t)cur * 8 + c, a); a = 0.0f; cur = o; }
+        a = fmaf(sg[pt * ld + c], wgt(pt), a);
+    }
+    kpn_atomic_add(gmap + (size_t)cur * 8 + c, a);
+}
+
 // A single-output Linear over a lane's 16 chained features: both halves of a point add their partial
 // dot products (lanes p and p+32) and every lane gets  W[row,:].x + b.
 __device__ __forceinline__ float kpn_row_dot(const float* __restrict__ rowvec, int h, const float (&x)[16]) {
