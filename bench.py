@@ -296,7 +296,7 @@ def main():
         out = ops.render_rays(ps, w, cam_tar, scene["bounds"], plan=plan)
         if world > 1:  # the job's only exchange: finished RGB frames (3 MB each) / bands gathered to rank 0, asynchronously
             k = gatherer.submit(out["tex_fg_fine" if fine else "tex_fg"][0])
-            if args.sync_gather:
+            if args.sync_gather and gatherer.work[k] is not None:
                 gatherer.work[k].wait()
                 if args.dist_backend == "nccl":
                     torch.cuda.current_stream().synchronize()
@@ -322,7 +322,9 @@ def main():
         torch.cuda.synchronize(); dist.barrier()
         tg = time.perf_counter()
         for _ in range(5):
-            gatherer.work[gatherer.submit(img)].wait()
+            wk = gatherer.work[gatherer.submit(img)]
+            if wk is not None:
+                wk.wait()
             torch.cuda.synchronize()
         dist.barrier()
         gather_ms = (time.perf_counter() - tg) / 5 * 1e3
@@ -389,7 +391,7 @@ def main():
                        "dist_backend": (args.dist_backend if world > 1 else None),
                        "rccl_ranks": (dist.get_world_size() if (world > 1 and args.dist_backend == "nccl") else None),
                        "dist_library": rccl,
-                       "gather": (None if world == 1 else ("synchronous per frame" if args.sync_gather else
+                       "gather": (None if world == 1 else ("synchronous per frame" if (args.sync_gather or not gatherer.asynchronous) else
                                   "asynchronous: frame i travels while frame i+1 renders (two staging buffers)")),
                        "gather_ms_per_round_alone": gather_ms},
             "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,

@@ -46,6 +46,19 @@ struct kpn_bwd_bufs {
 #define KPN_LDX0 232
 #define KPN_LDX2 136
 
+// The nine Linear layers of the kernel below run on v_mfma_f32_32x32x16_bf16 with three bf16 pieces per operand (kpn_blayer, the
+// BH_* streams: 2.7x less matrix time than the fp32 pipe, fp32-class results in fp32's exponent range — gradients included);
+// -DKPN_BWD_F32 builds the fp32-MFMA form (kpn_mfma_layer on the fp32 streams) for A/B measurements.
+template <int BH, int KS, int NOB, int G, class InFn>
+__device__ __forceinline__ void kpn_bwd_layer(const float* __restrict__ wp, int segoff, int lane, InFn&& fn, kpn_f32x16 (&acc)[NOB]) {
+    static_assert(KS == kpn_bh_shape(BH).ks && NOB == kpn_bh_shape(BH).nob && G == kpn_bh_shape(BH).g, "segment shape");
+#ifdef KPN_BWD_F32
+    kpn_mfma_layer<KS, NOB, G>(wp + segoff, lane, fn, acc);
+#else
+    (void)segoff;
+    kpn_blayer<BH>(wp, lane, fn, acc);
+#endif
+}
 // d softplus100(a) / da from the softplus value itself: sigmoid(100 a) = 1 - exp(-100 softplus(a)); above the
 // threshold (softplus == a, 100 a > 20) this is 1 to within 2e-9, the reference's exact 1
 __device__ __forceinline__ float kpn_softplus100_grad_from_value(float sp) { return 1.0f - kpn_exp2(sp * -144.269504088896341f); }
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             const float cz = RADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             kpn_load_bias<4>(bias_s[0], h, a0);
-            kpn_mfma_layer<84, 4, 7>(wp + kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
+            kpn_bwd_layer<BH_G1_0A, 84, 4, 7>(wp, kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
                 constexpr int j = decltype(gi)::value;
                 const float dx_ = RSUB(cx, kc[j * 3 + 0]), dy = RSUB(cy, kc[j * 3 + 1]), dz = RSUB(cz, kc[j * 3 + 2]);
                 const float d2 = RADD(RADD(RMUL(dx_, dx_), RMUL(dy, dy)), RMUL(dz, dz));
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 if constexpr (j == 5 || j == 11) flush(bufs.X0, KPN_LDX0, 84 * (j / 6), 84);
             }, a0);
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
-            kpn_mfma_layer<32, 4, 4>(wp + kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
+            kpn_bwd_layer<BH_G1_0B, 32, 4, 4>(wp, kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp0);
                 x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w;
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         // chained group g of a 128-vector = features 32(g/4) + 8(g%4) + 4h .. +3 of this lane's row
         kpn_f32x16 a1[4];
         kpn_load_bias<4>(bias_s[1], h, a1);
-        kpn_mfma_layer<64, 4, 4>(wp + kpn_seg_woff(SEG_G1_1), lane, [&](auto gi, float (&x)[4]) {
+        kpn_bwd_layer<BH_G1_1, 64, 4, 4>(wp, kpn_seg_woff(SEG_G1_1), lane, [&](auto gi, float (&x)[4]) {
             constexpr int g = decltype(gi)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a0[g / 4][(g % 4) * 4 + i]);
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1);
             KPN_ST4(x2row + 128 + 4 * h, f);   // (8 of 136 columns: left as a per-row store)
             kpn_load_bias<4>(bias_s[2], h, a2);
-            kpn_mfma_layer<68, 4, 4>(wp + kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
+            kpn_bwd_layer<BH_G1_2, 68, 4, 4>(wp, kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 if constexpr (g < 16) {
 #pragma unroll
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             for (int r = 0; r < 16; ++r) d3[ob][r] = 0.0f;
         {
             const float* grow = dx_compact ? dx + row * 64 : dx + ((size_t)n * sc.V + v) * 64;
-            kpn_mfma_layer<32, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
+            kpn_bwd_layer<BH_G1_3T, 32, 4, 4>(wp, kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
                 const float4 f = *reinterpret_cast<const float4*>(grow + col);
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[ob][r] = 0.0f;
         {
-            kpn_mfma_layer<64, 5, 4>(wp + kpn_bseg_woff(BSEG_G1_2T), lane, [&](auto gi, float (&x)[4]) {
+            kpn_bwd_layer<BH_G1_2T, 64, 5, 4>(wp, kpn_bseg_woff(BSEG_G1_2T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
                 const float4 s = *reinterpret_cast<const float4*>(x3row + col);
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[ob][r] = 0.0f;
         {
-            kpn_mfma_layer<64, 4, 4>(wp + kpn_bseg_woff(BSEG_G1_1T), lane, [&](auto gi, float (&x)[4]) {
+            kpn_bwd_layer<BH_G1_1T, 64, 4, 4>(wp, kpn_bseg_woff(BSEG_G1_1T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
                 const float4 s = *reinterpret_cast<const float4*>(x2row + col);
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) dg[ob][r] = 0.0f;
         {
-            kpn_mfma_layer<64, 2, 4>(wp + kpn_bseg_woff(BSEG_G1_0T), lane, [&](auto gi, float (&x)[4]) {
+            kpn_bwd_layer<BH_G1_0T, 64, 2, 4>(wp, kpn_bseg_woff(BSEG_G1_0T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
                 const float4 s = *reinterpret_cast<const float4*>(x1row + col);
@@ -314,11 +327,13 @@ struct kpn_wgrad_job {
     int ldy, M, ldx, Kc;               // Kc: columns of X read (even)
     int Kt, in_dim, cmap, omap;        // reduce: real columns, row stride of dW, column / row maps
     int mv, which;                     // MV of the job (reduce), rows[which] = row count
+    int V; uint32_t keep;              // which == 0: row r belongs to view (r / 32) % V; rows of views whose keep bit is 0 (train-time
+                                       // view dropout) count as zeros — their dumps are never written
 };
 struct kpn_wgrad_jobs { kpn_wgrad_job j[KPN_WGRAD_MAX_JOBS]; int n; };
 
 template <int MV>
-__global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const int64_t* __restrict__ rows_ptr) {
+__global__ __launch_bounds__(256) void k_weight_grad_f32(kpn_wgrad_jobs jobs, const int64_t* __restrict__ rows_ptr) {
     const kpn_wgrad_job& J = jobs.j[blockIdx.y];
     const int z = threadIdx.x >> 6;
     if (64 * z >= J.Kc) return;  // this job has fewer column groups than the launch's widest
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = 2 * (pr + u) + kk;
-            const bool in = pr + u < pend;
+            const bool in = pr + u < pend && ((J.keep >> ((uint32_t)(r >> 5) % (uint32_t)J.V)) & 1u);
             const bool yin = in && MV * i < M;  // M is a multiple of MV
             if constexpr (MV == 4) {
                 float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -385,6 +400,111 @@ __global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const 
             fetch(pr + U, ya[1], xb[1]);   // (reads nothing past pend)
             consume(ya[0], xb[0]);
             fetch(pr + 2 * U, ya[0], xb[0]);
+            consume(ya[1], xb[1]);
+        }
+    }
+    float* dst = J.partial + ((size_t)z * nworkers + worker) * (MV * 2 * 16 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < MV; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
+    if (z == 0) {
+#pragma unroll
+        for (int a = 0; a < MV; ++a) J.dbp[((size_t)worker * MV + a) * 64 + lane] = bs[a];
+    }
+}
+
+// The default form (round 3): the same sum on v_mfma_f32_32x32x16_bf16 with every operand as three bf16 pieces and six products
+// (fp32-class, fp32's exponent range — gradients span too many decades for fp16 pieces): K = 16 rows per step, lane l supplies
+// rows 8 (l >> 5) + e of a step.  2.7x less matrix time than the fp32 form (48 MFMAs of 32 cycles per 16 rows against 64 of 64);
+// the partial tiles, the reduce kernel and the operand labelling are unchanged.
+template <int MV>
+__global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const int64_t* __restrict__ rows_ptr) {
+    const kpn_wgrad_job& J = jobs.j[blockIdx.y];
+    const int z = threadIdx.x >> 6;
+    if (64 * z >= J.Kc) return;  // this job has fewer column groups than the launch's widest
+    const float* __restrict__ dY = J.dY;
+    const float* __restrict__ X = J.X;
+    const int ldy = J.ldy, M = J.M, ldx = J.ldx, Kc = J.Kc;
+    const int64_t rows = rows_ptr[J.which];
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+    const int worker = blockIdx.x, nworkers = gridDim.x;
+    const int c0 = z * 64;
+    const int64_t nchunks = (rows + 15) / 16;
+    const int64_t per = (nchunks + nworkers - 1) / nworkers;
+    const int64_t cbeg = (int64_t)worker * per;
+    const int64_t cend = cbeg + per < nchunks ? cbeg + per : nchunks;
+    kpn_f32x16 acc[MV][2];
+#pragma unroll
+    for (int a = 0; a < MV; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bs[MV];
+#pragma unroll
+    for (int a = 0; a < MV; ++a) bs[a] = 0.0f;
+    const bool cok = c0 + 2 * i < Kc;  // Kc is even: both columns of the pair are in or out
+    const bool yok = MV * i < M;       // M is a multiple of MV
+    float ya[2][8][MV];
+    float2 xb[2][8];
+    auto fetch = [&](int64_t c, float (&y)[8][MV], float2 (&x)[8]) {
+        // the 16 rows of a step lie in one 32-row (tile, view) block: one view test per step (rows of dropped views read as zeros)
+        const bool vkeep = c < cend && ((J.keep >> ((uint32_t)(c >> 1) % (uint32_t)J.V)) & 1u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t r = 16 * c + 8 * kk + e;
+            const bool in = vkeep && r < rows;
+            if constexpr (MV == 4) {
+                float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in && yok) y4 = *reinterpret_cast<const float4*>(dY + r * ldy + 4 * i);
+                y[e][0] = y4.x; y[e][1] = y4.y; y[e][2] = y4.z; y[e][3] = y4.w;
+            } else if constexpr (MV == 2) {
+                float2 y2 = make_float2(0.f, 0.f);
+                if (in && yok) y2 = *reinterpret_cast<const float2*>(dY + r * ldy + 2 * i);
+                y[e][0] = y2.x; y[e][1] = y2.y;
+            } else {
+                y[e][0] = (in && yok) ? dY[r * ldy + i] : 0.0f;
+            }
+            x[e] = make_float2(0.f, 0.f);
+            if (in && cok) x[e] = *reinterpret_cast<const float2*>(X + r * ldx + c0 + 2 * i);
+        }
+    };
+    auto consume = [&](const float (&y)[8][MV], const float2 (&x)[8]) {
+        kpn_bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = b == 0 ? x[e].x : x[e].y;
+            kpn_split_bf16x8(v, bh[b], bm[b], bl[b]);
+        }
+#pragma unroll
+        for (int a = 0; a < MV; ++a) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] = y[e][a]; bs[a] += v[e]; }
+            kpn_bf16x8 ah, am, al;
+            kpn_split_bf16x8(v, ah, am, al);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[a][b] = KPN_MFMA16(ah, bh[b], acc[a][b]);
+                acc[a][b] = KPN_MFMA16(ah, bm[b], acc[a][b]);
+                acc[a][b] = KPN_MFMA16(am, bh[b], acc[a][b]);
+                acc[a][b] = KPN_MFMA16(am, bm[b], acc[a][b]);
+                acc[a][b] = KPN_MFMA16(ah, bl[b], acc[a][b]);
+                acc[a][b] = KPN_MFMA16(al, bh[b], acc[a][b]);
+            }
+        }
+    };
+    if (cbeg < cend) {
+        fetch(cbeg, ya[0], xb[0]);
+        for (int64_t c = cbeg; c < cend; c += 2) {
+            fetch(c + 1, ya[1], xb[1]);   // (reads nothing past cend)
+            consume(ya[0], xb[0]);
+            fetch(c + 2, ya[0], xb[0]);
             consume(ya[1], xb[1]);
         }
     }

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
     __shared__ __attribute__((aligned(16))) int4 tap_o[4][KPN_TILE];
     __shared__ __attribute__((aligned(16))) float4 tap_w[4][KPN_TILE];
     const int w4 = threadIdx.x >> 6;
+    float dani_acc = 0.0f;                     // this wave's share of d ani_al (every lane holds the tile sums)
     for (;;) {
         int t = 0;
         if (lane == 0) t = atomicAdd(tickets, 1);
@@ -682,7 +683,8 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             dabs = (h == 0) ? dabs * live * wp[kpn_scalar_off() + 3] : 0.0f;  // d|a|/da = sign(ani_al)
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) dabs += __shfl_xor(dabs, m);
-            if (lane == 0) kpn_atomic_add(B.dani, dabs);
+            dani_acc += dabs;                  // one atomic per wave at the end of the kernel, not one per tile on one address
         }
     }
+    if (lane == 0 && dani_acc != 0.0f) kpn_atomic_add(B.dani, dani_acc);
 }

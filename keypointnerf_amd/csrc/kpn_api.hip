@@ -189,6 +189,25 @@ __host__ __device__ inline void k2h_locate(int seg, int el, int& src, int& slot)
     src = s < KS ? kpn_seg_woff(seg) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob : -1;
     slot = kpn_cseg_woff(seg) * 2 + (((c * NOB + ob) * 2) * 64 + lane) * 8 + e;
 }
+// ---- the backward chains' bf16 region (kpn_common.h BH_*): same idea, three bf16 pieces, chunk width 7 or 8 ----
+inline int bh_elements(int i) { return kpn_bh_chunks(i) * kpn_bh_shape(i).nob * 64 * 8; }
+inline int bh_total_elements() { int n = 0; for (int i = 0; i < BH_COUNT; ++i) n += bh_elements(i); return n; }
+void pack_bh_host(float* P) {
+    uint16_t* P16 = reinterpret_cast<uint16_t*>(P);
+    for (int i = 0; i < BH_COUNT; ++i) {
+        const int NOB = kpn_bh_shape(i).nob, G = kpn_bh_shape(i).g, KS = kpn_bh_shape(i).ks, CW = kpn_bh_cw(i);
+        for (int el = 0; el < bh_elements(i); ++el) {
+            const int e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, c = el / (512 * NOB);
+            const int s = c * CW + e;
+            const float w = (e < CW && s < KS) ? P[kpn_bh_src_woff(i) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob] : 0.0f;
+            const size_t slot = (size_t)kpn_bh_off(i) * 2 + (((size_t)(c * NOB + ob) * 3) * 64 + lane) * 8 + e;
+            const uint16_t ph = host_f2bf(w);
+            const float r1 = w - host_bf2f(ph);
+            const uint16_t pm = host_f2bf(r1);
+            P16[slot] = ph; P16[slot + 512] = pm; P16[slot + 1024] = host_f2bf(r1 - host_bf2f(pm));
+        }
+    }
+}
 int pack_k2h_host(float* P) {   // returns the number of weights beyond fp16's range
     uint16_t* P16 = reinterpret_cast<uint16_t*>(P);
     int beyond = 0;
@@ -362,6 +381,7 @@ extern "C" int kpn_pack_weights(const float* plain_host, float* packed_host) {
         });
         // the per-point kernel's region with two fp16 pieces per value (k_fuse_color_h): derived from the fp32 streams packed above
         beyond += pack_k2h_host(P);
+        pack_bh_host(P);
         float* fl = P + kpn_pack_flags_off();
         fl[0] = (float)beyond; fl[1] = fl[2] = fl[3] = 0.0f;
     }
@@ -456,6 +476,28 @@ __global__ void k_pack_scalars(const float* __restrict__ plain, size_t w0, size_
 
 // The gather maps of the device packer live in device memory, so they are kept PER DEVICE (a process that renders on two
 // GPUs packs on both); built on first use for the device that is current at the call.
+__global__ void k_pack_bh(float* __restrict__ packed, int n_elem) {
+    int el = blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= n_elem) return;
+    int i = 0;
+    for (;;) {
+        const int n = kpn_bh_chunks(i) * kpn_bh_shape(i).nob * 64 * 8;
+        if (el < n) break;
+        el -= n; ++i;
+    }
+    const int NOB = kpn_bh_shape(i).nob, G = kpn_bh_shape(i).g, KS = kpn_bh_shape(i).ks, CW = kpn_bh_cw(i);
+    const int e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, c = el / (512 * NOB);
+    const int s = c * CW + e;
+    const float w = (e < CW && s < KS) ? packed[kpn_bh_src_woff(i) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob] : 0.0f;
+    float one[8] = {w, 0, 0, 0, 0, 0, 0, 0};
+    kpn_bf16x8 h, m, l;
+    kpn_split3(one, h, m, l);
+    uint16_t ph, pm, plo;
+    { const auto hv = h[0]; const auto mv = m[0]; const auto lv = l[0]; memcpy(&ph, &hv, 2); memcpy(&pm, &mv, 2); memcpy(&plo, &lv, 2); }
+    uint16_t* p16 = reinterpret_cast<uint16_t*>(packed);
+    const size_t slot = (size_t)kpn_bh_off(i) * 2 + (((size_t)(c * NOB + ob) * 3) * 64 + lane) * 8 + e;
+    p16[slot] = ph; p16[slot + 512] = pm; p16[slot + 1024] = plo;
+}
 namespace {
 struct DevicePackMaps {
     int32_t* map = nullptr;
@@ -536,6 +578,8 @@ extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev
     // the per-point kernel's fp16 region from the fp32 streams, biases, scalars and row vectors written above (same stream: ordered)
     const int n_k2h = k2h_total_elements();
     KPN_LAUNCH(k_pack_k2h, grid1d((int64_t)n_k2h, 256), dim3(256), stream, packed_dev, n_k2h, packed_dev + kpn_pack_flags_off());
+    const int n_bh = bh_total_elements();
+    KPN_LAUNCH(k_pack_bh, grid1d((int64_t)n_bh, 256), dim3(256), stream, packed_dev, n_bh);
     return check_launch("kpn_pack_weights_device");
 }
 
@@ -1056,7 +1100,9 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
     float* partial = fp(L.partial);
     float* dbp = fp(L.dbp);
     const int blocks = field_grid_blocks();
-    const bool views_dropped = (keep_mask & ((1u << V) - 1u)) != ((1u << V) - 1u);
+    // rows of views switched off by the train-time dropout are skipped by k_color_bwd (their dumps are never written) and carry a
+    // zero upstream gradient in k_geo_rows_bwd: k_weight_grad reads them as zeros by the same mask (no memset of the dumps)
+    const uint32_t wgrad_keep = keep_mask | ~((V >= 32) ? 0xFFFFFFFFu : ((1u << V) - 1u));
     // dW[layer] += dY^T X over the rows (which = 0) or points (which = 1) of this pass
     // weight-gradient jobs of a pass: queued while the producers are launched, then run in one launch per MV class
     // and one reduce launch
@@ -1072,6 +1118,7 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         const int gz = (Kc + 63) / 64;
         kpn_wgrad_job j;
         j.dY = dY; j.X = X; j.ldy = ldy; j.M = M; j.ldx = ldx; j.Kc = Kc; j.Kt = Kt; j.cmap = cmap; j.omap = omap; j.mv = mv; j.which = which;
+        j.V = which == 0 ? V : 1; j.keep = which == 0 ? wgrad_keep : 0xFFFFFFFFu;
         j.partial = partial + partial_used;
         partial_used += (size_t)gz * kGradWorkers * mv * 2048;
         if (partial_used > (size_t)kPartialUnits * kGradWorkers * 2048 || all.n >= KPN_WGRAD_MAX_JOBS) { overflow = true; return; }
@@ -1084,9 +1131,16 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         if (gz > gzmax[cls]) gzmax[cls] = gz;
     };
     auto run_jobs = [&]() {
-        if (jobs[0].n) KPN_LAUNCH(k_weight_grad<1>, dim3(kGradWorkers, jobs[0].n), dim3(64 * gzmax[0]), stream, jobs[0], (const int64_t*)rows_dev);
-        if (jobs[1].n) KPN_LAUNCH(k_weight_grad<2>, dim3(kGradWorkers, jobs[1].n), dim3(64 * gzmax[1]), stream, jobs[1], (const int64_t*)rows_dev);
-        if (jobs[2].n) KPN_LAUNCH(k_weight_grad<4>, dim3(kGradWorkers, jobs[2].n), dim3(64 * gzmax[2]), stream, jobs[2], (const int64_t*)rows_dev);
+        static const int wgrad_f32 = [] { const char* e = getenv("KPN_WGRAD_F32"); return e ? atoi(e) : 0; }();   // A/B knob: the fp32-MFMA form
+        if (wgrad_f32) {
+            if (jobs[0].n) KPN_LAUNCH(k_weight_grad_f32<1>, dim3(kGradWorkers, jobs[0].n), dim3(64 * gzmax[0]), stream, jobs[0], (const int64_t*)rows_dev);
+            if (jobs[1].n) KPN_LAUNCH(k_weight_grad_f32<2>, dim3(kGradWorkers, jobs[1].n), dim3(64 * gzmax[1]), stream, jobs[1], (const int64_t*)rows_dev);
+            if (jobs[2].n) KPN_LAUNCH(k_weight_grad_f32<4>, dim3(kGradWorkers, jobs[2].n), dim3(64 * gzmax[2]), stream, jobs[2], (const int64_t*)rows_dev);
+        } else {
+            if (jobs[0].n) KPN_LAUNCH(k_weight_grad<1>, dim3(kGradWorkers, jobs[0].n), dim3(64 * gzmax[0]), stream, jobs[0], (const int64_t*)rows_dev);
+            if (jobs[1].n) KPN_LAUNCH(k_weight_grad<2>, dim3(kGradWorkers, jobs[1].n), dim3(64 * gzmax[1]), stream, jobs[1], (const int64_t*)rows_dev);
+            if (jobs[2].n) KPN_LAUNCH(k_weight_grad<4>, dim3(kGradWorkers, jobs[2].n), dim3(64 * gzmax[2]), stream, jobs[2], (const int64_t*)rows_dev);
+        }
         int gz_all = gzmax[0] > gzmax[1] ? gzmax[0] : gzmax[1];
         if (gzmax[2] > gz_all) gz_all = gzmax[2];
         const int mv_all = jobs[2].n ? 4 : (jobs[1].n ? 2 : 1);
@@ -1119,8 +1173,6 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
                 KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 1, xscr,
                            kpn_batch{0, 1 << 30});
             if (full == 2) {
-                // rows of dropped views are skipped by k_color_bwd: their dumps must read as zeros in k_weight_grad
-                if (views_dropped) hipMemsetAsync(fp(L.color), 0, L.color_bytes, (hipStream_t)stream);
                 if (V <= 3)
                     KPN_LAUNCH(k_color_bwd<3>, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
                                (const float*)xscr, d_out + c0 * 5, C);

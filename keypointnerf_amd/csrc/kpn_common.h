@@ -104,6 +104,29 @@ __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& 
         h[j] = ph; l[j] = pl;
     }
 }
+// eight fp32 values -> three bf16 pieces each (x = h + m + l to 2^-24 relative, fp32's exponent range): the packed form of
+// kpn_split3 — v_cvt_pk_bf16_f32 converts two values at once, 5.5 instead of 7.5 instructions per value — for kernels whose
+// operands have a gradient's dynamic range (k_weight_grad).  The conversions' results are MFMA operands: idle states behind them
+// (see kpn_split_f16x8).
+__device__ __forceinline__ void kpn_split_bf16x8(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) {
+    kpn_u32x4 ph, pm, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t a, b, c;
+        float r0, r1, t0, t1;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(a) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(a));
+        asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(a));
+        r0 = x[2 * j] - t0; r1 = x[2 * j + 1] - t1;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(b) : "v"(r0), "v"(r1));
+        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(b));
+        asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(b));
+        r0 = r0 - t0; r1 = r1 - t1;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(c) : "v"(r0), "v"(r1));
+        ph[j] = a; pm[j] = b; pl[j] = c;
+    }
+    h = __builtin_bit_cast(kpn_bf16x8, ph); m = __builtin_bit_cast(kpn_bf16x8, pm); l = __builtin_bit_cast(kpn_bf16x8, pl);
+}
 #else
 typedef uint16_t kpn_bf16x8 __attribute__((ext_vector_type(8)));
 static inline uint16_t kpn_f2bf(float f) {  // round to nearest even, as v_cvt_pk_bf16_f32
@@ -129,6 +152,7 @@ static inline kpn_bf16_t kpn_to_bf(float f) { return kpn_f2bf(f); }
 static inline float kpn_bf_to_f(kpn_bf16_t b) { return kpn_bf2f(b); }
 #define KPN_MFMA16(a, b, c) simt_mfma_f32_32x32x16_bf16((a), (b), (c))
 typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
+static inline void kpn_split_bf16x8(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) { kpn_split3(x, h, m, l); }
 static inline kpn_f32x16 kpn_mfma_f16(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
     kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);   // eight 16-bit patterns each
     return simt_mfma_f32_32x32x16_f16(av, bv, c);
@@ -295,9 +319,28 @@ constexpr int kpn_cseg_boff(int seg) {
 }
 constexpr int kpn_k2h_tail_off() { return kpn_cseg_boff(SEG_COUNT); }
 constexpr int kpn_k2h_floats() { return kpn_k2h_tail_off() + (kpn_fwd_floats() - kpn_scalar_off()) - kpn_k2h_base(); }
+// ---- the backward chains of layers1 with three bf16 pieces per weight (k_geo_rows_bwd), behind the per-point kernel's region ----
+// The forward segments SEG_G1_0A .. SEG_G1_2 (recomputed in the backward pass) and the transposed segments BSEG_G1_3T .. BSEG_G1_0T
+// (dX = W^T dY), their fp32 K-steps taken CW at a time (CW = 7 for the keypoint segment, whose groups are one keypoint's seven
+// values: one zero slot per chunk; 8 otherwise) = one K = 16 chunk of v_mfma_f32_32x32x16_bf16.  bf16, not fp16: gradients span
+// too many decades for fp16 pieces.  Stream per (chunk, output block): [piece h,m,l][64 lanes] x 16 B.
+enum { BH_G1_0A, BH_G1_0B, BH_G1_1, BH_G1_2, BH_G1_3T, BH_G1_2T, BH_G1_1T, BH_G1_0T, BH_COUNT };
+struct kpn_bh_desc { int bwd, seg; };   // bwd: 0 = kpn_seg_* (forward), 1 = kpn_bseg_* (transposed)
+static constexpr kpn_bh_desc kpn_bh_descs[BH_COUNT] = {{0, SEG_G1_0A}, {0, SEG_G1_0B}, {0, SEG_G1_1}, {0, SEG_G1_2},
+                                                       {1, BSEG_G1_3T}, {1, BSEG_G1_2T}, {1, BSEG_G1_1T}, {1, BSEG_G1_0T}};
+constexpr kpn_seg_shape kpn_bh_shape(int i) { return kpn_bh_descs[i].bwd ? kpn_bseg_shapes[kpn_bh_descs[i].seg] : kpn_seg_shapes[kpn_bh_descs[i].seg]; }
+constexpr int kpn_bh_src_woff(int i) { return kpn_bh_descs[i].bwd ? kpn_bseg_woff(kpn_bh_descs[i].seg) : kpn_seg_woff(kpn_bh_descs[i].seg); }
+constexpr int kpn_bh_cw(int i) { return kpn_bh_shape(i).g == 7 ? 7 : 8; }
+constexpr int kpn_bh_chunks(int i) { return (kpn_bh_shape(i).ks + kpn_bh_cw(i) - 1) / kpn_bh_cw(i); }
+constexpr int kpn_bh_wfloats(int i) { return kpn_bh_chunks(i) * kpn_bh_shape(i).nob * 3 * 64 * 4; }
+constexpr int kpn_bh_off(int i) {
+    int o = kpn_k2h_base() + kpn_k2h_floats();
+    for (int k = 0; k < i; ++k) o += kpn_bh_wfloats(k);
+    return o;
+}
 // behind everything: [0] = number of fp16-stream weights whose magnitude is beyond fp16's range (as a float; 0 = usable)
 #define KPN_PACK_FLAG_FLOATS 4
-constexpr int kpn_pack_flags_off() { return kpn_k2h_base() + kpn_k2h_floats(); }
+constexpr int kpn_pack_flags_off() { return kpn_bh_off(BH_COUNT); }
 constexpr int kpn_packed_floats() { return kpn_pack_flags_off() + KPN_PACK_FLAG_FLOATS; }
 // The split-bf16 streams carry the Softplus(beta = 100) of layers1 in log2 units (geo_rows_pair_kernels.hip, KPN_H2_LOG2ACT):
 // a layer whose OUTPUT goes through the activation is scaled by 100 log2(e) (weights here, biases when the kernel stages

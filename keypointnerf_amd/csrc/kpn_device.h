@@ -323,6 +323,84 @@ __device__ __forceinline__ void kpn_hlayer_regs(const float* __restrict__ wseg, 
     }, acc);
 }
 
+// A Linear layer of the backward chains on v_mfma_f32_32x32x16_bf16 with three bf16 pieces per operand and six products per term
+// set (kpn_common.h BH_*): the stream lives in global memory (L2), KS fp32 K-steps taken CW = 7 or 8 at a time.  in_fn has
+// kpn_mfma_layer's signature for the segment's G (7: one group per chunk, 4: two).  The B pieces of chunk c + 1 are produced
+// while the MFMAs of chunk c issue; the A pieces are fetched in two halves of the output blocks, each half re-loaded right after
+// its last MFMA has been issued (an MFMA captures its operands at issue), so that its loads fly under the other half's MFMAs.
+template <int BH, class InFn>
+__device__ __forceinline__ void kpn_blayer(const float* __restrict__ wp, int lane, InFn&& in_fn,
+                                           kpn_f32x16 (&acc)[kpn_bh_shape(BH).nob]) {
+    constexpr int KS = kpn_bh_shape(BH).ks, NOB = kpn_bh_shape(BH).nob, G = kpn_bh_shape(BH).g;
+    constexpr int CW = kpn_bh_cw(BH), NC = kpn_bh_chunks(BH), NG = KS / G;
+    constexpr int H0 = (NOB + 1) / 2, H1 = NOB - H0;
+    const float* wseg = wp + kpn_bh_off(BH);
+    kpn_bf16x8 wa[3][H0], wb[3][H1 > 0 ? H1 : 1];
+    kpn_bf16x8 bp[2][3];                                 // [buffer][piece] of the B operand
+    // a RUNNING base pointer (advanced from half to half, re-defined through an empty asm): computed as `segment + constant`
+    // the bases are loop-invariant, and hipcc hoists them all out of the tile loop into SGPRs it then spills (242 of them here)
+    int prev_pos = 0;
+    const float* gp = wseg;
+    auto load_half = [&](int c, int ob0, int n, auto& w) {
+        const int pos = (c * NOB + ob0) * (3 * 64 * 4);
+        gp += pos - prev_pos;
+        prev_pos = pos;
+        KPN_PIN_POINTER(gp);
+        const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
+#pragma unroll
+        for (int k = 0; k < n; ++k)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) w[pc][k] = kpn_as_bf16x8(src[(k * 3 + pc) * 64]);
+    };
+    auto produce = [&](auto ci, int buf) {
+        constexpr int c = decltype(ci)::value;
+        float x[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (G == 7) {
+            float x7[7];
+            in_fn(kpn_ic<c>{}, x7);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i] = x7[i];
+        } else {
+            float lo[4], hi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            in_fn(kpn_ic<2 * c>{}, lo);
+            if constexpr (2 * c + 1 < NG) in_fn(kpn_ic<2 * c + 1>{}, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i] = lo[i]; x[4 + i] = hi[i]; }
+        }
+        kpn_split_bf16x8(x, bp[buf][0], bp[buf][1], bp[buf][2]);
+    };
+    auto mfma_half = [&](int ob0, int n, auto& w, const kpn_bf16x8 (&b)[3]) {
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            acc[ob0 + k] = KPN_MFMA16(w[0][k], b[0], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[0][k], b[1], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[1][k], b[0], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[1][k], b[1], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[0][k], b[2], acc[ob0 + k]);
+            acc[ob0 + k] = KPN_MFMA16(w[2][k], b[0], acc[ob0 + k]);
+        }
+    };
+    load_half(0, 0, H0, wa);
+    if constexpr (H1 > 0) load_half(0, H0, H1, wb);
+    produce(kpn_ic<0>{}, 0);
+    kpn_static_for<0, NC>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        constexpr int cur = c & 1, nxt = cur ^ 1;
+        if constexpr (c + 1 < NC) produce(kpn_ic<c + 1>{}, nxt);
+        mfma_half(0, H0, wa, bp[cur]);
+#pragma unroll
+        for (int k = 0; k < H0; ++k) KPN_FENCE_RW(acc[k]);
+        if constexpr (c + 1 < NC) load_half(c + 1, 0, H0, wa);
+        if constexpr (H1 > 0) {
+            mfma_half(H0, H1, wb, bp[cur]);
+#pragma unroll
+            for (int k = 0; k < H1; ++k) KPN_FENCE_RW(acc[H0 + k]);
+            if constexpr (c + 1 < NC) load_half(c + 1, H0, H1, wb);
+        }
+        KPN_SCHED_BARRIER();
+    });
+}
+
 // One Linear layer on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (kpn_common.h HSEG_*): KS16 steps of 16 k.
 // in_fn(kpn_ic<s>, float (&x)[8]) produces the 8 fp32 values this lane supplies in step s; they are split into three
 // bf16 pieces on the fly; the weights arrive pre-split.  Six products per (step, output block) keep every term above

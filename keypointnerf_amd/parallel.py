@@ -119,6 +119,7 @@ class FrameGatherer:
         self.dest = [torch.empty((world,) + tuple(shape), dtype=dtype, device=device) for _ in range(depth)] if rank == 0 else None
         self.work = [None] * depth
         self.rounds = 0
+        self.asynchronous = True
 
     def submit(self, img):
         k = self.rounds % self.depth
@@ -126,7 +127,14 @@ class FrameGatherer:
             self.work[k].wait()                       # the buffer's previous gather (two rounds ago) has long finished
         self.staging[k].copy_(img, non_blocking=True)
         bucket = list(self.dest[k].unbind(0)) if self.rank == 0 else None
-        self.work[k] = self.dist.gather(self.staging[k], gather_list=bucket, dst=0, group=self.group, async_op=True)
+        if self.asynchronous:
+            try:
+                self.work[k] = self.dist.gather(self.staging[k], gather_list=bucket, dst=0, group=self.group, async_op=True)
+            except (RuntimeError, NotImplementedError):   # a backend without asynchronous gather: the same exchange, blocking
+                self.asynchronous = False
+        if not self.asynchronous:
+            self.dist.gather(self.staging[k], gather_list=bucket, dst=0, group=self.group)
+            self.work[k] = None
         self.rounds += 1
         return k
 
