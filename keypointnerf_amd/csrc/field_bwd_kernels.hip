@@ -63,6 +63,12 @@ __device__ __forceinline__ void kpn_bwd_layer(const float* __restrict__ wp, int 
 // threshold (softplus == a, 100 a > 20) this is 1 to within 2e-9, the reference's exact 1
 __device__ __forceinline__ float kpn_softplus100_grad_from_value(float sp) { return 1.0f - kpn_exp2(sp * -144.269504088896341f); }
 
+#ifdef KPN_BWD_TIMING   // debug builds: cycles (s_memtime) per phase of the tiles of one wave, summed (scripts/bwd_timing.py)
+__device__ unsigned long long kpn_bwd_cycles[16];
+#define KPN_BWD_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 3 && threadIdx.x == 64) atomicAdd(&kpn_bwd_cycles[i], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define KPN_BWD_STAMP(i) ((void)0)
+#endif
 // dx: upstream gradient d loss / d x_view: [N][V][64] indexed by the ORIGINAL point index, or (dx_compact) by
 // row = (tile*V + v)*32 + p as k_fuse_bwd writes it
 __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
@@ -90,7 +96,11 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
     }
     __syncthreads();
 
+#ifdef KPN_BWD_TIMING
+    unsigned long long stamp_ = clock64();
+#endif
     for (;;) {
+        KPN_BWD_STAMP(11);
         int wi = 0;
         if (lane == 0) wi = atomicAdd(tickets, 1);
         wi = __shfl(wi, 0);
@@ -126,6 +136,11 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             KPN_WAVE_SYNC();
         };
 
+        KPN_BWD_STAMP(0);
+        // The B phase re-reads its rows (upstream gradient, X3, X2, X1) one chained group per call; fetched where it is used, every
+        // group exposed a whole L2 round trip (two per chunk of the layer): a two-deep ring fetches group g + 2 when g is consumed.
+        float4 pf[2];
+        auto row4 = [&](const float* rowp, int g) { return *reinterpret_cast<const float4*>(rowp + 32 * (g / 4) + 8 * (g % 4) + 4 * h); };
         // ================= F phase (same arithmetic as k_geo_rows) =================
         kpn_f32x16 a0[4];
         {
@@ -155,6 +170,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 for (int i = 0; i < 7; ++i) d[i] = x[i];
                 if constexpr (j == 5 || j == 11) flush(bufs.X0, KPN_LDX0, 84 * (j / 6), 84);
             }, a0);
+            KPN_BWD_STAMP(1);
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
             kpn_bwd_layer<BH_G1_0B, 32, 4, 4>(wp, kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
@@ -164,6 +180,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             }, a0);
             flush(bufs.X0, KPN_LDX0, 168, 64);
         }
+        KPN_BWD_STAMP(2);
         // chained group g of a 128-vector = features 32(g/4) + 8(g%4) + 4h .. +3 of this lane's row
         kpn_f32x16 a1[4];
         kpn_load_bias<4>(bias_s[1], h, a1);
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             *reinterpret_cast<float4*>(srow + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = make_float4(x[0], x[1], x[2], x[3]);
         }, a1);
         flush(bufs.X1, 128, 0, 128);
+        KPN_BWD_STAMP(3);
         kpn_f32x16 a2[4];
         {
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1);
@@ -191,6 +209,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             }, a2);
             flush(bufs.X2, KPN_LDX2, 0, 128);
         }
+        KPN_BWD_STAMP(4);
         // X3 = softplus(a2), the input of layers1.3 (its forward product itself is not needed here)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -200,6 +219,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             *reinterpret_cast<float4*>(srow + 32 * (g / 4) + 8 * (g % 4) + 4 * h) = o;
         }
         flush(bufs.X3, 128, 0, 128);
+        KPN_BWD_STAMP(5);
 
         // ================= B phase =================
         // dX3 = W3^T dY3
@@ -210,15 +230,18 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             for (int r = 0; r < 16; ++r) d3[ob][r] = 0.0f;
         {
             const float* grow = dx_compact ? dx + row * 64 : dx + ((size_t)n * sc.V + v) * 64;
+            pf[0] = row4(grow, 0); pf[1] = row4(grow, 1);
             kpn_bwd_layer<BH_G1_3T, 32, 4, 4>(wp, kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
-                const float4 f = *reinterpret_cast<const float4*>(grow + col);
+                const float4 f = pf[g & 1];
+                if constexpr (g + 2 < 8) pf[g & 1] = row4(grow, g + 2);
                 x[0] = f.x * live; x[1] = f.y * live; x[2] = f.z * live; x[3] = f.w * live;
                 *reinterpret_cast<float4*>(srow + col) = make_float4(x[0], x[1], x[2], x[3]);
             }, d3);
             flush(bufs.D3, 64, 0, 64);
         }
+        KPN_BWD_STAMP(6);
         // dA2 = dX3 * softplus'(a2);  [dX2 | d hd] = W2^T dA2
         kpn_f32x16 d2[5];
 #pragma unroll
@@ -226,10 +249,12 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[ob][r] = 0.0f;
         {
+            pf[0] = row4(x3row, 0); pf[1] = row4(x3row, 1);
             kpn_bwd_layer<BH_G1_2T, 64, 5, 4>(wp, kpn_bseg_woff(BSEG_G1_2T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
-                const float4 s = *reinterpret_cast<const float4*>(x3row + col);
+                const float4 s = pf[g & 1];
+                if constexpr (g + 2 < 16) pf[g & 1] = row4(x3row, g + 2);
                 x[0] = d3[g / 4][(g % 4) * 4 + 0] * kpn_softplus100_grad_from_value(s.x);
                 x[1] = d3[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d3[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
@@ -238,6 +263,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             }, d2);
             flush(bufs.D2, 128, 0, 128);
         }
+        KPN_BWD_STAMP(7);
         // the 8 hd channels (rows 128..135 of dX2 = block 4 regs 0..3: channels 4h..4h+3) go back to feat_geo[1]
         const float4 dhd = make_float4(d2[4][0], d2[4][1], d2[4][2], d2[4][3]);
         // dA1 = dX2 * softplus'(a1);  dX1 = W1^T dA1
@@ -247,10 +273,12 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[ob][r] = 0.0f;
         {
+            pf[0] = row4(x2row, 0); pf[1] = row4(x2row, 1);
             kpn_bwd_layer<BH_G1_1T, 64, 4, 4>(wp, kpn_bseg_woff(BSEG_G1_1T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
-                const float4 s = *reinterpret_cast<const float4*>(x2row + col);
+                const float4 s = pf[g & 1];
+                if constexpr (g + 2 < 16) pf[g & 1] = row4(x2row, g + 2);
                 x[0] = d2[g / 4][(g % 4) * 4 + 0] * kpn_softplus100_grad_from_value(s.x);
                 x[1] = d2[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d2[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
@@ -259,6 +287,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             }, d1);
             flush(bufs.D1, 128, 0, 128);
         }
+        KPN_BWD_STAMP(8);
         // dA0 = dX1 * softplus'(a0);  d geo0 = W0[:,168:232]^T dA0
         kpn_f32x16 dg[2];
 #pragma unroll
@@ -266,10 +295,12 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #pragma unroll
             for (int r = 0; r < 16; ++r) dg[ob][r] = 0.0f;
         {
+            pf[0] = row4(x1row, 0); pf[1] = row4(x1row, 1);
             kpn_bwd_layer<BH_G1_0T, 64, 2, 4>(wp, kpn_bseg_woff(BSEG_G1_0T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
-                const float4 s = *reinterpret_cast<const float4*>(x1row + col);
+                const float4 s = pf[g & 1];
+                if constexpr (g + 2 < 16) pf[g & 1] = row4(x1row, g + 2);
                 x[0] = d1[g / 4][(g % 4) * 4 + 0] * kpn_softplus100_grad_from_value(s.x);
                 x[1] = d1[g / 4][(g % 4) * 4 + 1] * kpn_softplus100_grad_from_value(s.y);
                 x[2] = d1[g / 4][(g % 4) * 4 + 2] * kpn_softplus100_grad_from_value(s.z);
@@ -278,6 +309,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             }, dg);
             flush(bufs.D0, 128, 0, 128);
         }
+        KPN_BWD_STAMP(9);
         // Scatter through the bilinear taps.  A lane holds 32 channels of ONE row; issued from this layout an atomic
         // instruction would touch 32 different texels (cache lines).  The tile is transposed through LDS instead:
         // lane = channel, so that one instruction adds 64 consecutive floats (two lines) of one texel.
@@ -305,6 +337,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             kpn_scatter_rle8(bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8, sg + 64, KPN_SCAT_LD, tap_o[w4][1], tap_w[w4][1], npt, lane);
             KPN_WAVE_SYNC();  // the next tile overwrites the exchange buffers
         }
+        KPN_BWD_STAMP(10);
     }
 }
 
@@ -327,6 +360,7 @@ struct kpn_wgrad_job {
     int ldy, M, ldx, Kc;               // Kc: columns of X read (even)
     int Kt, in_dim, cmap, omap;        // reduce: real columns, row stride of dW, column / row maps
     int mv, which;                     // MV of the job (reduce), rows[which] = row count
+    int olab;                          // labelling of the partial tiles' output features: 0 = MV i + a (k_weight_grad_f32), 1 = 32 a + i
     int V; uint32_t keep;              // which == 0: row r belongs to view (r / 32) % V; rows of views whose keep bit is 0 (train-time
                                        // view dropout) count as zeros — their dumps are never written
 };
@@ -418,24 +452,49 @@ __global__ __launch_bounds__(256) void k_weight_grad_f32(kpn_wgrad_jobs jobs, co
 
 // The default form (round 3): the same sum on v_mfma_f32_32x32x16_bf16 with every operand as three bf16 pieces and six products
 // (fp32-class, fp32's exponent range — gradients span too many decades for fp16 pieces): K = 16 rows per step, lane l supplies
-// rows 8 (l >> 5) + e of a step.  2.7x less matrix time than the fp32 form (48 MFMAs of 32 cycles per 16 rows against 64 of 64);
-// the partial tiles, the reduce kernel and the operand labelling are unchanged.
+// rows 8 (l >> 5) + e of a step.  2.7x less matrix time than the fp32 form (48 MFMAs of 32 cycles per 16 rows against 64 of 64).
+//
+// With the matrix time that small the kernel is bound by what feeds it, so the feeding is shared: a value of dY is split ONCE per
+// workgroup (the fp32 form and the first bf16 form split it in every wave, i.e. up to four times) — the wave that owns output
+// block a loads dY[16 rows][32 a + i], splits it and parks the three pieces in LDS in operand order; after one barrier every
+// wave reads the MV blocks back (ds_read_b128) for its own 64 columns, whose X pieces never leave its registers.  Two LDS
+// stages: a stage is rewritten two steps later, behind the next step's barrier.  Waves beyond the job's column groups own
+// output blocks before the others do (they have nothing else to do).  Loads are unconditional: the dumps are whole tiles
+// (rows % 32 == 0), a lane beyond M or Kc re-reads the last valid feature / column pair (its tile rows / columns are never
+// read by the reduce), and the steps of a dropped view (never written) are skipped as a whole.  The barrier is s_barrier behind
+// s_waitcnt lgkmcnt(0) only: __syncthreads() would also drain the global loads of the next step, which are the point.
+//   labelling: tile (a, b) holds output feature 32 a + i (A lane i) x column c0 + 2 j + b (B lane j)   [olab = 1]
+#ifndef KPN_SIMT_EMU
+#define KPN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define KPN_LDS_BARRIER() __syncthreads()
+#endif
 template <int MV>
-__global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const int64_t* __restrict__ rows_ptr) {
+__global__ __launch_bounds__(256, 2) void k_weight_grad(kpn_wgrad_jobs jobs, const int64_t* __restrict__ rows_ptr) {
     const kpn_wgrad_job& J = jobs.j[blockIdx.y];
-    const int z = threadIdx.x >> 6;
-    if (64 * z >= J.Kc) return;  // this job has fewer column groups than the launch's widest
-    const float* __restrict__ dY = J.dY;
-    const float* __restrict__ X = J.X;
+    const int z = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int G = (J.Kc + 63) >> 6;            // column groups of this job: waves z < G multiply, every wave may split
+    const bool mul = z < G;
     const int ldy = J.ldy, M = J.M, ldx = J.ldx, Kc = J.Kc;
     const int64_t rows = rows_ptr[J.which];
     const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
     const int worker = blockIdx.x, nworkers = gridDim.x;
-    const int c0 = z * 64;
-    const int64_t nchunks = (rows + 15) / 16;
+    const int64_t nchunks = rows / 16;
     const int64_t per = (nchunks + nworkers - 1) / nworkers;
     const int64_t cbeg = (int64_t)worker * per;
     const int64_t cend = cbeg + per < nchunks ? cbeg + per : nchunks;
+    __shared__ __attribute__((aligned(16))) kpn_u32x4 a_s[2][MV][3][64];
+    bool own[MV];                              // wave-uniform: this wave splits output block a
+    uint32_t fo4[MV];                          // byte offset of (row 8 kk, feature 32 a + i, clamped) in a step of dY
+#pragma unroll
+    for (int a = 0; a < MV; ++a) {
+        own[a] = (nw > G ? G + a % (nw - G) : a % nw) == z;
+        const int f = 32 * a + i;
+        fo4[a] = 4u * (uint32_t)(8 * kk * ldy + (f < M ? f : M - 1));
+    }
+    // (row 8 kk, column pair 64 z + 2 i, clamped; Kc is even) in a step of X; row e of the eight adds e * ld * 4 on the scalar side
+    const uint32_t xo4 = 4u * (uint32_t)(8 * kk * ldx + (mul ? min(64 * z + 2 * i, Kc - 2) : 0));
+    const uint32_t ldy4 = 4u * (uint32_t)ldy, ldx4 = 4u * (uint32_t)ldx;
     kpn_f32x16 acc[MV][2];
 #pragma unroll
     for (int a = 0; a < MV; ++a)
@@ -446,79 +505,85 @@ __global__ __launch_bounds__(256) void k_weight_grad(kpn_wgrad_jobs jobs, const 
     float bs[MV];
 #pragma unroll
     for (int a = 0; a < MV; ++a) bs[a] = 0.0f;
-    const bool cok = c0 + 2 * i < Kc;  // Kc is even: both columns of the pair are in or out
-    const bool yok = MV * i < M;       // M is a multiple of MV
-    float ya[2][8][MV];
-    float2 xb[2][8];
-    auto fetch = [&](int64_t c, float (&y)[8][MV], float2 (&x)[8]) {
-        // the 16 rows of a step lie in one 32-row (tile, view) block: one view test per step (rows of dropped views read as zeros)
-        const bool vkeep = c < cend && ((J.keep >> ((uint32_t)(c >> 1) % (uint32_t)J.V)) & 1u);
+    float ya[MV][8];
+    float2 xb[8];
+    // the 16 rows of a step lie in one 32-row (tile, view) block
+    auto kept = [&](int64_t c) { return ((J.keep >> ((uint32_t)(c >> 1) % (uint32_t)J.V)) & 1u) != 0; };
+    auto next_kept = [&](int64_t c) { while (c < cend && !kept(c)) ++c; return c; };
+    auto fetch = [&](int64_t c) {
+        const char* yb = reinterpret_cast<const char*>(J.dY + c * 16 * ldy);   // uniform
+        const char* xp = reinterpret_cast<const char*>(J.X + c * 16 * ldx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t r = 16 * c + 8 * kk + e;
-            const bool in = vkeep && r < rows;
-            if constexpr (MV == 4) {
-                float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in && yok) y4 = *reinterpret_cast<const float4*>(dY + r * ldy + 4 * i);
-                y[e][0] = y4.x; y[e][1] = y4.y; y[e][2] = y4.z; y[e][3] = y4.w;
-            } else if constexpr (MV == 2) {
-                float2 y2 = make_float2(0.f, 0.f);
-                if (in && yok) y2 = *reinterpret_cast<const float2*>(dY + r * ldy + 2 * i);
-                y[e][0] = y2.x; y[e][1] = y2.y;
-            } else {
-                y[e][0] = (in && yok) ? dY[r * ldy + i] : 0.0f;
+        for (int a = 0; a < MV; ++a)
+            if (own[a]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ya[a][e] = *reinterpret_cast<const float*>(yb + e * ldy4 + fo4[a]);
             }
-            x[e] = make_float2(0.f, 0.f);
-            if (in && cok) x[e] = *reinterpret_cast<const float2*>(X + r * ldx + c0 + 2 * i);
+        if (mul) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xb[e] = *reinterpret_cast<const float2*>(xp + e * ldx4 + xo4);
         }
     };
-    auto consume = [&](const float (&y)[8][MV], const float2 (&x)[8]) {
+    int64_t c = next_kept(cbeg);
+    if (c < cend) fetch(c);
+    int st = 0;
+    while (c < cend) {
+#pragma unroll
+        for (int a = 0; a < MV; ++a)
+            if (own[a]) {
+                kpn_bf16x8 h, m, l;
+                kpn_split_bf16x8<false>(ya[a], h, m, l);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs[a] += ya[a][e];
+                a_s[st][a][0][lane] = __builtin_bit_cast(kpn_u32x4, h);
+                a_s[st][a][1][lane] = __builtin_bit_cast(kpn_u32x4, m);
+                a_s[st][a][2][lane] = __builtin_bit_cast(kpn_u32x4, l);
+            }
         kpn_bf16x8 bh[2], bm[2], bl[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = b == 0 ? x[e].x : x[e].y;
-            kpn_split_bf16x8(v, bh[b], bm[b], bl[b]);
-        }
-#pragma unroll
-        for (int a = 0; a < MV; ++a) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] = y[e][a]; bs[a] += v[e]; }
-            kpn_bf16x8 ah, am, al;
-            kpn_split_bf16x8(v, ah, am, al);
+        if (mul) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                acc[a][b] = KPN_MFMA16(ah, bh[b], acc[a][b]);
-                acc[a][b] = KPN_MFMA16(ah, bm[b], acc[a][b]);
-                acc[a][b] = KPN_MFMA16(am, bh[b], acc[a][b]);
-                acc[a][b] = KPN_MFMA16(am, bm[b], acc[a][b]);
-                acc[a][b] = KPN_MFMA16(ah, bl[b], acc[a][b]);
-                acc[a][b] = KPN_MFMA16(al, bh[b], acc[a][b]);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = b == 0 ? xb[e].x : xb[e].y;
+                kpn_split_bf16x8<false>(v, bh[b], bm[b], bl[b]);
             }
         }
-    };
-    if (cbeg < cend) {
-        fetch(cbeg, ya[0], xb[0]);
-        for (int64_t c = cbeg; c < cend; c += 2) {
-            fetch(c + 1, ya[1], xb[1]);   // (reads nothing past cend)
-            consume(ya[0], xb[0]);
-            fetch(c + 2, ya[0], xb[0]);
-            consume(ya[1], xb[1]);
+        const int64_t cn = next_kept(c + 1);
+        if (cn < cend) fetch(cn);
+        KPN_LDS_BARRIER();
+        if (mul) {
+#pragma unroll
+            for (int a = 0; a < MV; ++a) {
+                const kpn_bf16x8 ah = __builtin_bit_cast(kpn_bf16x8, a_s[st][a][0][lane]);
+                const kpn_bf16x8 am = __builtin_bit_cast(kpn_bf16x8, a_s[st][a][1][lane]);
+                const kpn_bf16x8 al = __builtin_bit_cast(kpn_bf16x8, a_s[st][a][2][lane]);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = KPN_MFMA16(ah, bh[b], acc[a][b]);
+                    acc[a][b] = KPN_MFMA16(ah, bm[b], acc[a][b]);
+                    acc[a][b] = KPN_MFMA16(am, bh[b], acc[a][b]);
+                    acc[a][b] = KPN_MFMA16(am, bm[b], acc[a][b]);
+                    acc[a][b] = KPN_MFMA16(ah, bl[b], acc[a][b]);
+                    acc[a][b] = KPN_MFMA16(al, bh[b], acc[a][b]);
+                }
+            }
         }
+        st ^= 1;
+        c = cn;
     }
-    float* dst = J.partial + ((size_t)z * nworkers + worker) * (MV * 2 * 16 * 64) + lane;
+    if (mul) {
+        float* dst = J.partial + ((size_t)z * nworkers + worker) * (MV * 2 * 16 * 64) + lane;
+#pragma unroll
+        for (int a = 0; a < MV; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
+    }
 #pragma unroll
     for (int a = 0; a < MV; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64] = acc[a][b][r];
-    if (z == 0) {
-#pragma unroll
-        for (int a = 0; a < MV; ++a) J.dbp[((size_t)worker * MV + a) * 64 + lane] = bs[a];
-    }
+        if (own[a]) J.dbp[((size_t)worker * MV + a) * 64 + lane] = bs[a];
 }
 
 // cmap: 0 = X columns are plain input features; 1 = X0 dump (first 168 columns in (keypoint, PE block) order);
@@ -555,7 +620,7 @@ __global__ __launch_bounds__(256) void k_weight_grad_reduce(kpn_wgrad_jobs jobs,
     for (int k = 1; k < 8; ++k) s += red[k][el];
     if (e < TILE_E) {
         const int lane = e & 63, r = (e >> 6) & 15, ab = e >> 10, a = ab >> 1, b = ab & 1;
-        int o = MV * KPN_ROWMAP(r, lane >> 5) + a;
+        int o = J.olab ? 32 * a + KPN_ROWMAP(r, lane >> 5) : MV * KPN_ROWMAP(r, lane >> 5) + a;
         const int c = z * 64 + 2 * (lane & 31) + b;
         if (o < M && c < Kc) {
             const int f = kpn_grad_col(J.cmap, c);
@@ -564,7 +629,7 @@ __global__ __launch_bounds__(256) void k_weight_grad_reduce(kpn_wgrad_jobs jobs,
         }
     } else if (z == 0 && e < TILE_E + MV * 32) {
         const int q = e - TILE_E, a = q / 32, i = q % 32;
-        const int o = MV * i + a;
+        const int o = J.olab ? 32 * a + i : MV * i + a;
         if (o < M) J.dB[J.omap ? kpn_xprime_to_orig(o) : o] += s;
     }
 }

@@ -709,7 +709,14 @@ extern "C" int kpn_rgba2out_backward(const float* rgba, const float* z, int64_t 
     KPN_REQUIRE(rgba && z && d_rgba, "null pointer");
     KPN_REQUIRE(S >= 1, "bad sample count");
     if (R <= 0) return R == 0 ? KPN_OK : fail(KPN_EINVAL, "negative ray count");
-    KPN_LAUNCH(k_rgba2out_bwd, grid1d(R, 64), dim3(64), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
+    static const int serial = [] { const char* e = getenv("KPN_RGBA2OUT_BWD_SERIAL"); return e ? atoi(e) : 0; }();   // A/B knob
+    const int per = serial ? 9 : (int)((S + 63) / 64);
+    const dim3 wgrid = grid1d(R * 64, 256);   // one wavefront per ray
+    if (per <= 1) KPN_LAUNCH(k_rgba2out_bwd_w<1>, wgrid, dim3(256), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
+    else if (per <= 2) KPN_LAUNCH(k_rgba2out_bwd_w<2>, wgrid, dim3(256), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
+    else if (per <= 4) KPN_LAUNCH(k_rgba2out_bwd_w<4>, wgrid, dim3(256), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
+    else if (per <= 8) KPN_LAUNCH(k_rgba2out_bwd_w<8>, wgrid, dim3(256), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
+    else KPN_LAUNCH(k_rgba2out_bwd, grid1d(R, 64), dim3(64), stream, R, (int)S, rgba, z, d_color, d_depth, d_alpha, d_sdf, d_rgba);
     return check_launch("kpn_rgba2out_backward");
 }
 
@@ -997,7 +1004,10 @@ static_assert(kBwdChunk <= 262144, "kUncappedPoints (query_layout) must cover a 
 #ifdef KPN_SIMT_EMU
 const int kGradWorkers = 3;     // row workers (one workgroup each; its waves are the column groups)
 #else
-const int kGradWorkers = 512;   // 2 workgroups per CU
+#ifndef KPN_GRAD_WORKERS
+#define KPN_GRAD_WORKERS 512    // 2 workgroups per CU
+#endif
+const int kGradWorkers = KPN_GRAD_WORKERS;
 #endif
 const int kPartialUnits = 72;   // capacity of the partial-tile scratch in units of (workers x 2048 floats)
 // full = 1: the whole-query reverse (adds the forward row scratch, the per-point dumps and the d x_view rows)
@@ -1106,6 +1116,7 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
     // dW[layer] += dY^T X over the rows (which = 0) or points (which = 1) of this pass
     // weight-gradient jobs of a pass: queued while the producers are launched, then run in one launch per MV class
     // and one reduce launch
+    static const int wgrad_f32 = [] { const char* e = getenv("KPN_WGRAD_F32"); return e ? atoi(e) : 0; }();   // A/B knob: the fp32-MFMA form
     kpn_wgrad_jobs jobs[3], all;  // MV = 1, 2, 4
     int gzmax[3];
     size_t partial_used = 0;
@@ -1119,6 +1130,7 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         kpn_wgrad_job j;
         j.dY = dY; j.X = X; j.ldy = ldy; j.M = M; j.ldx = ldx; j.Kc = Kc; j.Kt = Kt; j.cmap = cmap; j.omap = omap; j.mv = mv; j.which = which;
         j.V = which == 0 ? V : 1; j.keep = which == 0 ? wgrad_keep : 0xFFFFFFFFu;
+        j.olab = wgrad_f32 ? 0 : 1;
         j.partial = partial + partial_used;
         partial_used += (size_t)gz * kGradWorkers * mv * 2048;
         if (partial_used > (size_t)kPartialUnits * kGradWorkers * 2048 || all.n >= KPN_WGRAD_MAX_JOBS) { overflow = true; return; }
@@ -1131,7 +1143,6 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
         if (gz > gzmax[cls]) gzmax[cls] = gz;
     };
     auto run_jobs = [&]() {
-        static const int wgrad_f32 = [] { const char* e = getenv("KPN_WGRAD_F32"); return e ? atoi(e) : 0; }();   // A/B knob: the fp32-MFMA form
         if (wgrad_f32) {
             if (jobs[0].n) KPN_LAUNCH(k_weight_grad_f32<1>, dim3(kGradWorkers, jobs[0].n), dim3(64 * gzmax[0]), stream, jobs[0], (const int64_t*)rows_dev);
             if (jobs[1].n) KPN_LAUNCH(k_weight_grad_f32<2>, dim3(kGradWorkers, jobs[1].n), dim3(64 * gzmax[1]), stream, jobs[1], (const int64_t*)rows_dev);
@@ -1211,6 +1222,13 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
 }
 }  // namespace
 
+#ifdef KPN_BWD_TIMING
+extern "C" int kpn_bwd_timing(unsigned long long* out16) {   // read and clear (debug builds only; not part of the ABI)
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(kpn_bwd_cycles), 128) != hipSuccess) return 1;
+    const unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(kpn_bwd_cycles), z, 128) != hipSuccess;
+}
+#endif
 extern "C" size_t kpn_geo_rows_backward_workspace_bytes(int64_t N, int32_t V) {
     if (N <= 0 || V <= 0) return 0;
     return bwd_layout(N, V, 0).total;

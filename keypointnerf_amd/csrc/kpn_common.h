@@ -108,21 +108,28 @@ __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& 
 // kpn_split3 — v_cvt_pk_bf16_f32 converts two values at once, 5.5 instead of 7.5 instructions per value — for kernels whose
 // operands have a gradient's dynamic range (k_weight_grad).  The conversions' results are MFMA operands: idle states behind them
 // (see kpn_split_f16x8).
+// One asm statement per pair of values (11 instructions): hipcc's hazard recogniser puts an s_nop behind every asm result it sees
+// consumed (it assumes a partial write), i.e. one per instruction when each is its own statement.  TO_MFMA: the last conversion's
+// result may be an MFMA operand in the very next slot -> two idle states behind it (the h and m pieces are older by 5+ slots);
+// false where the pieces go to LDS or sit behind a barrier first (k_weight_grad).
+template <bool TO_MFMA = true>
 __device__ __forceinline__ void kpn_split_bf16x8(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) {
     kpn_u32x4 ph, pm, pl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint32_t a, b, c;
         float r0, r1, t0, t1;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(a) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(a));
-        asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(a));
-        r0 = x[2 * j] - t0; r1 = x[2 * j + 1] - t1;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(b) : "v"(r0), "v"(r1));
-        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(t0) : "v"(b));
-        asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(t1) : "v"(b));
-        r0 = r0 - t0; r1 = r1 - t1;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(c) : "v"(r0), "v"(r1));
+#define KPN_SPLIT3_BODY                                                                                               \
+        "v_cvt_pk_bf16_f32 %0, %7, %8\n\tv_lshlrev_b32 %5, 16, %0\n\tv_and_b32 %6, 0xffff0000, %0\n\t"               \
+        "v_sub_f32 %3, %7, %5\n\tv_sub_f32 %4, %8, %6\n\t"                                                          \
+        "v_cvt_pk_bf16_f32 %1, %3, %4\n\tv_lshlrev_b32 %5, 16, %1\n\tv_and_b32 %6, 0xffff0000, %1\n\t"               \
+        "v_sub_f32 %3, %3, %5\n\tv_sub_f32 %4, %4, %6\n\t"                                                          \
+        "v_cvt_pk_bf16_f32 %2, %3, %4"
+        if constexpr (TO_MFMA)
+            asm(KPN_SPLIT3_BODY "\n\ts_nop 1" : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+        else
+            asm(KPN_SPLIT3_BODY : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+#undef KPN_SPLIT3_BODY
         ph[j] = a; pm[j] = b; pl[j] = c;
     }
     h = __builtin_bit_cast(kpn_bf16x8, ph); m = __builtin_bit_cast(kpn_bf16x8, pm); l = __builtin_bit_cast(kpn_bf16x8, pl);
@@ -152,6 +159,7 @@ static inline kpn_bf16_t kpn_to_bf(float f) { return kpn_f2bf(f); }
 static inline float kpn_bf_to_f(kpn_bf16_t b) { return kpn_bf2f(b); }
 #define KPN_MFMA16(a, b, c) simt_mfma_f32_32x32x16_bf16((a), (b), (c))
 typedef uint32_t kpn_u32x4 __attribute__((ext_vector_type(4)));
+template <bool TO_MFMA = true>
 static inline void kpn_split_bf16x8(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) { kpn_split3(x, h, m, l); }
 static inline kpn_f32x16 kpn_mfma_f16(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
     kpn_bf16x8 av, bv; memcpy(&av, &a, 16); memcpy(&bv, &b, 16);   // eight 16-bit patterns each

@@ -321,6 +321,89 @@ __global__ void k_rgba2out_bwd(int64_t R, int S, const float* __restrict__ rgba,
     }
 }
 
+// The same backward with one wavefront per ray (S <= 512; a training patch is ~1,000 rays, far too few threads for the form above:
+// 16 workgroups on 256 CUs, 86 us per call).  Lane l owns the contiguous samples [l*per, (l+1)*per) as in k_rgba2out: the
+// transmittance is the same 64-lane product scan, and the reverse recurrence, being affine in Q (Q_{i-1} = e_i Q_i + g_i a_i),
+// is a 64-lane suffix scan of the per-lane maps (E, B): Q before the lane's first sample = E * (Q behind its last) + B.
+template <int PER>
+__global__ __launch_bounds__(256) void k_rgba2out_bwd_w(int64_t R, int S, const float* __restrict__ rgba, const float* __restrict__ z,
+                                                        const float* __restrict__ d_color, const float* __restrict__ d_depth,
+                                                        const float* __restrict__ d_alpha, const float* __restrict__ d_sdf,
+                                                        float* __restrict__ d_rgba) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= R) return;   // a whole wavefront
+    const int per = (S + 63) / 64;   // <= PER
+    const float* zz = z + r * S;
+    float sd[PER], cr[PER], cg[PER], cb[PER], zv[PER], dist[PER], e[PER], a[PER], Tk[PER];
+    float tl = 1.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane * per + k;
+        sd[k] = cr[k] = cg[k] = cb[k] = zv[k] = dist[k] = 0.0f;
+        e[k] = 1.0f; a[k] = 0.0f;
+        if (k < per && i < S) {
+            const float* q = rgba + (r * S + i) * 5;
+            sd[k] = q[1]; cr[k] = q[2]; cg[k] = q[3]; cb[k] = q[4];
+            zv[k] = zz[i];
+            dist[k] = (i + 1 < S) ? (zz[i + 1] - zz[i]) : 1e10f;
+            e[k] = expf(-q[0] * dist[k]);   // 1 - a_i
+            a[k] = 1.0f - e[k];
+            tl *= (1.0f - a[k]);
+        }
+    }
+    float incl = tl;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(incl, d);
+        if (lane >= d) incl *= o;
+    }
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.0f;
+    float A = 0.0f, Ssum = 0.0f, Dsum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        Tk[k] = T;
+        const float c = a[k] * T;
+        T *= (1.0f - a[k]);
+        A += c; Ssum += sd[k] * c; Dsum += zv[k] * c;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { A += __shfl_xor(A, m); Ssum += __shfl_xor(Ssum, m); Dsum += __shfl_xor(Dsum, m); }
+    const float dc0 = d_color ? d_color[r * 3 + 0] : 0.f, dc1 = d_color ? d_color[r * 3 + 1] : 0.f, dc2 = d_color ? d_color[r * 3 + 2] : 0.f;
+    const float dA = d_alpha ? d_alpha[r] : 0.f, dS = d_sdf ? d_sdf[r] : 0.f, dD = d_depth ? d_depth[r] : 0.f;
+    const float inv = 1.0f / (A + 1e-8f);
+    const float gA = dA - (dS * Ssum + dD * Dsum) * inv * inv;
+    float g[PER];
+    float E = 1.0f, B = 0.0f;   // this lane's map, last sample first
+#pragma unroll
+    for (int k = PER - 1; k >= 0; --k) {
+        g[k] = dc0 * cr[k] + dc1 * cg[k] + dc2 * cb[k] + gA + dS * sd[k] * inv + dD * zv[k] * inv;
+        B = g[k] * a[k] + e[k] * B;
+        E *= e[k];
+    }
+    // inclusive suffix scan: (E, B) of lane l becomes the map of lanes l..63
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float Eo = __shfl_down(E, d), Bo = __shfl_down(B, d);
+        if (lane + d < 64) { B = E * Bo + B; E *= Eo; }
+    }
+    float Q = __shfl_down(B, 1);   // the lanes behind this one, applied to Q = 0 behind the last sample
+    if (lane == 63) Q = 0.0f;
+    float* dq = d_rgba + r * S * 5;
+#pragma unroll
+    for (int k = PER - 1; k >= 0; --k) {
+        const int i = lane * per + k;
+        if (k < per && i < S) {
+            const float c = a[k] * Tk[k];
+            dq[i * 5 + 0] = Tk[k] * (g[k] - Q) * dist[k] * e[k];
+            dq[i * 5 + 1] = c * dS * inv;
+            dq[i * 5 + 2] = c * dc0; dq[i * 5 + 3] = c * dc1; dq[i * 5 + 4] = c * dc2;
+        }
+        Q = g[k] * a[k] + e[k] * Q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // importance_sample (model.py:1110-1148): one thread per ray, sequential cdf (torch.cumsum order),
 // searchsorted(right=True) by bisection in LDS.  contrib (R,Dm2), zin (R,Dm2+1), u (R,n)|NULL -> out (R,n)

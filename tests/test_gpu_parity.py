@@ -411,7 +411,14 @@ def test_rgba2out_autograd(ops):
     ok = torch.isfinite(g2).all(-1).all(-1) & ((1 - a[..., :-1]).detach().amin(-1) > 1e-3)
     assert ok.float().mean() > 0.5
     scale = g2[ok].abs().amax((-1, -2), keepdim=True)
-    assert ((g1[ok] - g2[ok]).abs() <= 2e-4 * scale + 1e-6).all()
+    # d sigma_i = T_i (g_i - Q_i) dist_i e_i, where g_i = <w, colour_i> is a three-term dot product that can cancel: its rounding is
+    # 2^-24 of sum |w_c| (colours <= 1), not of the result, and the last sample multiplies it by dist = 1e10 — two of these 65,536
+    # rays have a last-sample entry (the ray's largest, i.e. its own `scale`) where the dot product cancels to 1e-4 of its terms, and
+    # torch's own fp32 result is 1.2e-3 from the float64 one there.  The bound carries that conditioning term.
+    T = torch.cumprod(torch.cat([torch.ones_like(a[..., :1]), 1 - a[..., :-1]], -1), -1).detach()
+    cond = torch.zeros_like(g2)
+    cond[..., 0] = T * dist * (1 - a).detach() * w.abs().sum(-1, keepdim=True)
+    assert ((g1[ok] - g2[ok]).abs() <= 2e-4 * scale + 1e-6 + 3e-6 * cond[ok]).all()
     assert torch.isfinite(g1).all()  # the hand-written backward has no 1/(1-a) and stays finite everywhere
 
 
