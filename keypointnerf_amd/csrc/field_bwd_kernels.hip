@@ -35,13 +35,32 @@ struct kpn_bwd_bufs {
 #define KPN_ST4(p, v) ((void)0)
 #define KPN_ST1(p, v) ((void)0)
 #else
+// The dumps are written once and read once by a later kernel (k_weight_grad; 2.5 GB per training iteration from this kernel alone):
+// streaming stores (global_store ... nt) keep them from displacing the weight streams and the feature maps in L2.  Measured:
+// backward 4.98 -> 4.80 ms; without any dump stores (-DKPN_ABLATE_DUMP) 4.48 ms.  -DKPN_DUMP_NT=0 restores plain stores.
+#ifndef KPN_DUMP_NT
+#define KPN_DUMP_NT 1
+#endif
+#if KPN_DUMP_NT && !defined(KPN_SIMT_EMU)
+typedef float kpn_nt4 __attribute__((ext_vector_type(4)));
+#define KPN_ST4(p, v) do { const float4 v_ = (v); kpn_nt4 n_; n_[0] = v_.x; n_[1] = v_.y; n_[2] = v_.z; n_[3] = v_.w; __builtin_nontemporal_store(n_, reinterpret_cast<kpn_nt4*>(p)); } while (0)
+#else
 #define KPN_ST4(p, v) (*reinterpret_cast<float4*>(p) = (v))
+#endif
 #define KPN_ST1(p, v) (*(p) = (v))
 #endif
 #define KPN_STAGE_LD 132  // 128 floats + pad: rows start on different banks, float4-aligned
 #define KPN_SCAT_LD KPN_STAGE_LD
 #ifndef KPN_BWD_OCC
 #define KPN_BWD_OCC 2
+#endif
+#ifndef KPN_BWD_LOCKSTEP
+#define KPN_BWD_LOCKSTEP 1
+#endif
+#ifndef KPN_SIMT_EMU
+#define KPN_BLOCK_MEET() __builtin_amdgcn_s_barrier()   // execution only: no memory is exchanged at these points
+#else
+#define KPN_BLOCK_MEET() __syncthreads()
 #endif
 #define KPN_LDX0 232
 #define KPN_LDX2 136
@@ -99,17 +118,37 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 #ifdef KPN_BWD_TIMING
     unsigned long long stamp_ = clock64();
 #endif
+#if KPN_BWD_LOCKSTEP
+    __shared__ int ticket_s;
+#endif
     for (;;) {
         KPN_BWD_STAMP(11);
+#if KPN_BWD_LOCKSTEP
+        // The four waves of a workgroup take four consecutive work items and meet at a barrier before every layer: they then ask for
+        // the same weight lines within a few hundred cycles of each other and three of the four requests are served by the CU's L1
+        // (or merged with the miss in flight) instead of by L2 — every wave streams 708 KB of weights per work item.  A wave whose
+        // item lies beyond the end redoes the last one with nothing live and nothing stored (at most three per workgroup).
+        __syncthreads();
+        if (threadIdx.x == 0) ticket_s = atomicAdd(tickets, 4);
+        __syncthreads();
+        const int wbase = ticket_s;
+        if (wbase >= nwork) break;
+        const bool item_ok = wbase + (int)(threadIdx.x >> 6) < nwork;
+        const int wi = item_ok ? wbase + (int)(threadIdx.x >> 6) : nwork - 1;
+#define KPN_BWD_MEET() KPN_BLOCK_MEET()
+#else
         int wi = 0;
         if (lane == 0) wi = atomicAdd(tickets, 1);
         wi = __shfl(wi, 0);
         if (wi >= nwork) break;
+        const bool item_ok = true;
+#define KPN_BWD_MEET() ((void)0)
+#endif
         const int t = wi / sc.V, v = wi - t * sc.V;
         int ci = t * KPN_TILE + p;
         // pad lanes recompute the last point with a zero upstream gradient; so do views switched off by the
         // train-time dropout (their pooling weight is 0, model.py:748)
-        const float live = (ci < count && ((sc.keep >> v) & 1u)) ? 1.0f : 0.0f;
+        const float live = (item_ok && ci < count && ((sc.keep >> v) & 1u)) ? 1.0f : 0.0f;
         if (ci >= count) ci = count - 1;
         const int64_t n = list[ci];
         const size_t row = (size_t)wi * KPN_TILE + p;
@@ -129,7 +168,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         auto flush = [&](float* __restrict__ dump, int ld, int col0, int ncols) {
             KPN_WAVE_SYNC();
             const int q = ncols >> 2;                             // float4 per row
-            for (int i = lane; i < KPN_TILE * q; i += 64) {
+            for (int i = lane; item_ok && i < KPN_TILE * q; i += 64) {
                 const int r = i / q, c = (i - r * q) << 2;
                 KPN_ST4(dump + (row0 + r) * ld + col0 + c, *reinterpret_cast<const float4*>(stg + r * KPN_STAGE_LD + c));
             }
@@ -150,6 +189,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             const float cz = RADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             kpn_load_bias<4>(bias_s[0], h, a0);
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_0A, 84, 4, 7>(wp, kpn_seg_woff(SEG_G1_0A), lane, [&](auto gi, float (&x)[7]) {
                 constexpr int j = decltype(gi)::value;
                 const float dx_ = RSUB(cx, kc[j * 3 + 0]), dy = RSUB(cy, kc[j * 3 + 1]), dz = RSUB(cz, kc[j * 3 + 2]);
@@ -172,6 +212,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             }, a0);
             KPN_BWD_STAMP(1);
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_0B, 32, 4, 4>(wp, kpn_seg_woff(SEG_G1_0B), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const float4 f = kpn_tap4(g0, 64, 32 * h + 4 * g, tp0);
@@ -184,6 +225,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         // chained group g of a 128-vector = features 32(g/4) + 8(g%4) + 4h .. +3 of this lane's row
         kpn_f32x16 a1[4];
         kpn_load_bias<4>(bias_s[1], h, a1);
+        KPN_BWD_MEET();
         kpn_bwd_layer<BH_G1_1, 64, 4, 4>(wp, kpn_seg_woff(SEG_G1_1), lane, [&](auto gi, float (&x)[4]) {
             constexpr int g = decltype(gi)::value;
 #pragma unroll
@@ -195,8 +237,9 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         kpn_f32x16 a2[4];
         {
             const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp1);
-            KPN_ST4(x2row + 128 + 4 * h, f);   // (8 of 136 columns: left as a per-row store)
+            if (item_ok) KPN_ST4(x2row + 128 + 4 * h, f);   // (8 of 136 columns: left as a per-row store)
             kpn_load_bias<4>(bias_s[2], h, a2);
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_2, 68, 4, 4>(wp, kpn_seg_woff(SEG_G1_2), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 if constexpr (g < 16) {
@@ -231,6 +274,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
         {
             const float* grow = dx_compact ? dx + row * 64 : dx + ((size_t)n * sc.V + v) * 64;
             pf[0] = row4(grow, 0); pf[1] = row4(grow, 1);
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_3T, 32, 4, 4>(wp, kpn_bseg_woff(BSEG_G1_3T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -250,6 +294,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             for (int r = 0; r < 16; ++r) d2[ob][r] = 0.0f;
         {
             pf[0] = row4(x3row, 0); pf[1] = row4(x3row, 1);
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_2T, 64, 5, 4>(wp, kpn_bseg_woff(BSEG_G1_2T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -274,6 +319,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             for (int r = 0; r < 16; ++r) d1[ob][r] = 0.0f;
         {
             pf[0] = row4(x2row, 0); pf[1] = row4(x2row, 1);
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_1T, 64, 4, 4>(wp, kpn_bseg_woff(BSEG_G1_1T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -296,6 +342,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
             for (int r = 0; r < 16; ++r) dg[ob][r] = 0.0f;
         {
             pf[0] = row4(x1row, 0); pf[1] = row4(x1row, 1);
+            KPN_BWD_MEET();
             kpn_bwd_layer<BH_G1_0T, 64, 2, 4>(wp, kpn_bseg_woff(BSEG_G1_0T), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
                 const int col = 32 * (g / 4) + 8 * (g % 4) + 4 * h;
@@ -323,17 +370,18 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                     *reinterpret_cast<float4*>(sg + p * KPN_SCAT_LD + 32 * b + 8 * qd + 4 * h) =
                         make_float4(dg[b][4 * qd + 0], dg[b][4 * qd + 1], dg[b][4 * qd + 2], dg[b][4 * qd + 3]);
             *reinterpret_cast<float4*>(sg + p * KPN_SCAT_LD + 64 + 4 * h) = dhd;
-            if (h == 0) {
-                tap_o[w4][0][p] = make_int4(tp0.o00, tp0.o01, tp0.o10, tp0.o11);
-                tap_w[w4][0][p] = make_float4(tp0.w00 * live, tp0.w01 * live, tp0.w10 * live, tp0.w11 * live);
-            } else {
+            if (h == 1) {   // (the 64-channel map's taps stay in registers: kpn_scatter_rle64_regs)
                 tap_o[w4][1][p] = make_int4(tp1.o00, tp1.o01, tp1.o10, tp1.o11);
                 tap_w[w4][1][p] = make_float4(tp1.w00 * live, tp1.w01 * live, tp1.w10 * live, tp1.w11 * live);
             }
             KPN_WAVE_SYNC();
             const int npt = min(KPN_TILE, count - t * KPN_TILE);
             // one atomic per run of equal texel offsets and tap (kpn_scatter_rle*, kpn_device.h), not one per point
-            kpn_scatter_rle64(bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64, sg, KPN_SCAT_LD, tap_o[w4][0], tap_w[w4][0], npt, lane);
+            {
+                const int o0[4] = {tp0.o00, tp0.o01, tp0.o10, tp0.o11};
+                const float w0[4] = {tp0.w00 * live, tp0.w01 * live, tp0.w10 * live, tp0.w11 * live};
+                kpn_scatter_rle64_regs(bufs.dgeo0 + (size_t)v * sc.g0h * sc.g0w * 64, sg, KPN_SCAT_LD, o0, w0, lane);
+            }
             kpn_scatter_rle8(bufs.dgeo1 + (size_t)v * sc.g1h * sc.g1w * 8, sg + 64, KPN_SCAT_LD, tap_o[w4][1], tap_w[w4][1], npt, lane);
             KPN_WAVE_SYNC();  // the next tile overwrites the exchange buffers
         }

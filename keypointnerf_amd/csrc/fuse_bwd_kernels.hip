@@ -12,6 +12,16 @@
 // The colour head's reverse is k_color_bwd (below); it runs first and hands d lat to k_fuse_bwd.
 #include "kpn_device.h"
 
+// streaming stores for the row-major dumps of these two kernels, as in k_geo_rows_bwd (field_bwd_kernels.hip: KPN_DUMP_NT)
+#ifndef KPN_DUMP_NT
+#define KPN_DUMP_NT 1
+#endif
+#if KPN_DUMP_NT && !defined(KPN_SIMT_EMU)
+typedef float kpn_row_nt4 __attribute__((ext_vector_type(4)));
+#define KPN_ST_ROW4(p, v) do { const float4 v_ = (v); kpn_row_nt4 n_; n_[0] = v_.x; n_[1] = v_.y; n_[2] = v_.z; n_[3] = v_.w; __builtin_nontemporal_store(n_, reinterpret_cast<kpn_row_nt4*>(p)); } while (0)
+#else
+#define KPN_ST_ROW4(p, v) (*reinterpret_cast<float4*>(p) = (v))
+#endif
 // 4*NQ registers of one 32-feature block in the chained layout <-> row-major: regs 4q..4q+3 = features 8q+4h..+3
 template <int NQ>
 __device__ __forceinline__ void kpn_ld_chain(const float* __restrict__ base, int h, float (&x)[4 * NQ]) {
@@ -23,9 +33,11 @@ __device__ __forceinline__ void kpn_ld_chain(const float* __restrict__ base, int
 }
 template <int NQ>
 __device__ __forceinline__ void kpn_st_chain(float* __restrict__ base, int h, const float (&x)[4 * NQ]) {
+#ifndef KPN_ABLATE_DUMP2   // (timing experiment only: no dumps from k_fuse_bwd / k_color_bwd, wrong results)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-        *reinterpret_cast<float4*>(base + 8 * q + 4 * h) = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        KPN_ST_ROW4(base + 8 * q + 4 * h, make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
+#endif
 }
 
 struct kpn_fuse_bwd_bufs {

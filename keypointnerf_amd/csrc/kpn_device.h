@@ -580,6 +580,38 @@ __device__ __forceinline__ void kpn_scatter_rle64(float* __restrict__ gmap, cons
     kpn_atomic_add(g + (size_t)cur.x * 64, a0); kpn_atomic_add(g + (size_t)cur.y * 64, a1);
     kpn_atomic_add(g + (size_t)cur.z * 64, a2); kpn_atomic_add(g + (size_t)cur.w * 64, a3);
 }
+// The same walk over all KPN_TILE points with the taps in REGISTERS (lane p holds point p's four offsets and weights; a pad
+// lane repeats the last point with zero weights): v_readlane_b32 puts a point's offsets and weights into SGPRs, the run tests
+// become scalar compares and branches, and the only LDS access of a step is the staged value.  The LDS-table form above cost
+// 43 k cycles per (tile, view) of k_geo_rows_bwd with the atomics compiled out (three dependent LDS reads and four exec-mask
+// branches per point).
+#ifndef KPN_SIMT_EMU
+__device__ __forceinline__ int kpn_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float kpn_readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+#else
+static inline int kpn_readlane(int v, int l) { return __shfl(v, l); }
+static inline float kpn_readlane(float v, int l) { return __shfl(v, l); }
+#endif
+__device__ __forceinline__ void kpn_scatter_rle64_regs(float* __restrict__ gmap, const float* __restrict__ sg, int ld, const int (&o)[4],
+                                                       const float (&w)[4], int lane) {
+    float* g = gmap + lane;
+    int cur[4];
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = kpn_readlane(o[k], 0);
+    kpn_static_for<0, KPN_TILE>([&](auto pi) {
+        constexpr int pt = decltype(pi)::value;
+        const float val = sg[pt * ld + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ok = kpn_readlane(o[k], pt);
+            if (ok != cur[k]) { kpn_atomic_add(g + (size_t)cur[k] * 64, a[k]); a[k] = 0.0f; cur[k] = ok; }
+            a[k] = fmaf(val, kpn_readlane(w[k], pt), a[k]);
+        }
+    });
+#pragma unroll
+    for (int k = 0; k < 4; ++k) kpn_atomic_add(g + (size_t)cur[k] * 64, a[k]);
+}
 // C = 8 channels: lane = (half of the points, tap, channel): lanes 0..31 walk points [0, 16), lanes 32..63 points [16, 32)
 __device__ __forceinline__ void kpn_scatter_rle8(float* __restrict__ gmap, const float* __restrict__ sg, int ld, const int4* __restrict__ tap_o,
                                                  const float4* __restrict__ tap_w, int npt, int lane) {
