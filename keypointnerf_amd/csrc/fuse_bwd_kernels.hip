@@ -12,11 +12,9 @@
 // The colour head's reverse is k_color_bwd (below); it runs first and hands d lat to k_fuse_bwd.
 #include "kpn_device.h"
 
-// streaming stores for the row-major dumps of these two kernels, as in k_geo_rows_bwd (field_bwd_kernels.hip: KPN_DUMP_NT)
-#ifndef KPN_DUMP_NT
-#define KPN_DUMP_NT 1
-#endif
-#if KPN_DUMP_NT && !defined(KPN_SIMT_EMU)
+// Plain stores here: k_color_bwd reads most of its own dumps back in its reverse half, and with streaming stores
+// (-DKPN_DUMP_NT2, as in k_geo_rows_bwd) those reads miss: measured k_color_bwd 555 -> 592 us per call.
+#if defined(KPN_DUMP_NT2) && !defined(KPN_SIMT_EMU)
 typedef float kpn_row_nt4 __attribute__((ext_vector_type(4)));
 #define KPN_ST_ROW4(p, v) do { const float4 v_ = (v); kpn_row_nt4 n_; n_[0] = v_.x; n_[1] = v_.y; n_[2] = v_.z; n_[3] = v_.w; __builtin_nontemporal_store(n_, reinterpret_cast<kpn_row_nt4*>(p)); } while (0)
 #else
@@ -246,6 +244,40 @@ __device__ __forceinline__ float kpn_pair_sum(float x) { return x + __shfl_xor(x
 
 // VMAX = 3: the per-view scalars (dot, source colour, logit, ...) stay in registers; VMAX = KPN_MAXV: any view count, the
 // small per-view arrays are indexed dynamically (private memory).
+// [base, base + nfloats) of the packed buffer = the whole backward segments bseg0 .. bseg1-1, copied into LDS in the layout
+// kpn_load_group<NQ, 1> reads (kpn_stage_lds_range, field_kernels.hip, for the transposed segments)
+__device__ __forceinline__ void kpn_stage_lds_brange(const float* __restrict__ wp, float* __restrict__ wlds, int base, int nfloats,
+                                                     int bseg0, int bseg1) {
+    const float4* src = reinterpret_cast<const float4*>(wp + base);
+    float4* dst = reinterpret_cast<float4*>(wlds);
+    for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) {
+        int j = i;
+#pragma unroll
+        for (int seg = BSEG_CMPT; seg < BSEG_COUNT; ++seg) {
+            if (seg < bseg0 || seg >= bseg1) continue;
+            const int nq = kpn_bseg_shapes[seg].g * kpn_bseg_shapes[seg].nob / 4;
+            if (nq == 1) continue;
+            const int w0 = (kpn_bseg_woff(seg) - base) / 4, w1 = w0 + kpn_bseg_wfloats(seg) / 4;
+            if (i >= w0 && i < w1) {
+                const int r = i - w0, g = r / (64 * nq), e = r - g * 64 * nq;   // e = lane * nq + q
+                j = w0 + g * 64 * nq + (e % nq) * 64 + e / nq;
+            }
+        }
+        dst[j] = src[i];
+    }
+}
+// The colour head is fourteen small layers per view in each direction, every one waiting for its weights: fetched from L2 a layer
+// at a time (one wave per SIMD: 482 registers) the kernel ran at a fifth of its arithmetic.  Everything the per-view part reads —
+// the forward segments from ray_encoder.0 on with the scalars and row vectors (64 KB) and the transposed segments from
+// ray_encoder.2^T on (78 KB) — is therefore staged in LDS once per persistent workgroup (KPN_COLOR_WLDS, the default);
+// ibr_compress_gfeat and its transpose (once per tile) stay in L2.
+#ifndef KPN_COLOR_WLDS
+#define KPN_COLOR_WLDS 1
+#endif
+constexpr int kpn_color_fbase() { return kpn_seg_woff(SEG_RE_0); }
+constexpr int kpn_color_ffloats() { return kpn_fwd_floats() - kpn_color_fbase(); }
+constexpr int kpn_color_bbase() { return kpn_bseg_woff(BSEG_RE_1T); }
+constexpr int kpn_color_bfloats() { return kpn_bseg_woff(BSEG_COUNT) - kpn_color_bbase(); }
 template <int VMAX>
 __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
@@ -257,7 +289,19 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
     const int V = sc.V;  // <= VMAX (the launcher picks the instantiation)
     const uint32_t keep = sc.keep;
-    const float ani = wp[kpn_scalar_off() + 0];  // |ani_al|
+#if KPN_COLOR_WLDS
+    __shared__ __attribute__((aligned(16))) float wl_f[kpn_color_ffloats()];
+    __shared__ __attribute__((aligned(16))) float wl_b[kpn_color_bfloats()];
+    kpn_stage_lds_range(wp, wl_f, kpn_color_fbase(), kpn_color_ffloats(), SEG_RE_0, SEG_COUNT);
+    kpn_stage_lds_brange(wp, wl_b, kpn_color_bbase(), kpn_color_bfloats(), BSEG_RE_1T, BSEG_COUNT);
+    __syncthreads();
+    const float* wf = wl_f - kpn_color_fbase();   // biased: the packed-buffer offsets index the LDS copies directly
+    const float* wb = wl_b - kpn_color_bbase();
+#else
+    const float* wf = wp;
+    const float* wb = wp;
+#endif
+    const float ani = wf[kpn_scalar_off() + 0];  // |ani_al|
     __shared__ __attribute__((aligned(16))) float scat_s[4][KPN_TILE][8];
     __shared__ __attribute__((aligned(16))) int4 tap_o[4][KPN_TILE];
     __shared__ __attribute__((aligned(16))) float4 tap_w[4][KPN_TILE];
@@ -300,15 +344,15 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             if (!((keep >> v) & 1u)) continue;
             const float in4[4] = {h ? g.rd[1] : g.rd[0], h ? g.rd[3] : g.rd[2], 0.0f, 0.0f};
             kpn_f32x16 a1[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_RE_0), h, a1);
-            kpn_mfma_layer_regs<4, 1, 4, 0>(wp + kpn_seg_woff(SEG_RE_0), lane, in4, a1);
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_RE_0), h, a1);
+            kpn_mfma_layer_regs<4, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_RE_0), lane, in4, a1);
             float in8[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) in8[r] = kpn_elu(a1[0][r]);
             kpn_st_chain<2>(B.Xe1 + hrow(v) * 16, h, in8);
             kpn_f32x16 a2[2];
-            kpn_load_bias<2>(wp + kpn_seg_boff(SEG_RE_1), h, a2);
-            kpn_mfma_layer_regs<8, 2, 4, 0>(wp + kpn_seg_woff(SEG_RE_1), lane, in8, a2);
+            kpn_load_bias<2>(wf + kpn_seg_boff(SEG_RE_1), h, a2);
+            kpn_mfma_layer_regs<8, 2, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_RE_1), lane, in8, a2);
             float dir[19], xq[19];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dir[r] = kpn_elu(a2[0][r]); xq[r] = dir[r] + lat0[r]; }
@@ -338,8 +382,8 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
                 }
             }
         kpn_f32x16 base[2];
-        kpn_load_bias<2>(wp + kpn_seg_boff(SEG_BL_0A), h, base);
-        kpn_mfma_layer_regs<40, 2, 4, 0>(wp + kpn_seg_woff(SEG_BL_0A), lane, mv, base);
+        kpn_load_bias<2>(wf + kpn_seg_boff(SEG_BL_0A), h, base);
+        kpn_mfma_layer_regs<40, 2, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_BL_0A), lane, mv, base);
         float meanq[19], varq[19];
 #pragma unroll
         for (int i = 0; i < 19; ++i) { meanq[i] = mv[i]; varq[i] = mv[20 + i]; }
@@ -357,11 +401,11 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             for (int i = 0; i < 19; ++i) xin[i] = xq[i];
             xin[19] = 0.0f;
             kpn_f32x16 a[2] = {base[0], base[1]};
-            kpn_mfma_layer_regs<20, 2, 4, 0>(wp + kpn_seg_woff(SEG_BL_0B), lane, xin, a);
+            kpn_mfma_layer_regs<20, 2, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_BL_0B), lane, xin, a);
             kpn_f32x16 xa[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_BL_1), h, xa);
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_BL_1), h, xa);
             float* xb1 = B.Xb1 + hr * 64;
-            kpn_mfma_layer<32, 1, 4, 0>(wp + kpn_seg_woff(SEG_BL_1), lane, [&](auto gi, float (&x)[4]) {
+            kpn_mfma_layer<32, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_BL_1), lane, [&](auto gi, float (&x)[4]) {
                 constexpr int gq = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_elu(a[gq / 4][(gq % 4) * 4 + i]);
@@ -373,25 +417,25 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_st_chain<4>(B.Xa + hr * 32, h, x);
             kpn_st_chain<4>(B.Xv10 + hr * 32, h, tin);
             kpn_f32x16 va[1], vb[1];
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V1_0), h, va);
-            kpn_mfma_layer_regs<16, 1, 4, 0>(wp + kpn_seg_woff(SEG_V1_0), lane, tin, va);
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_V1_0), h, va);
+            kpn_mfma_layer_regs<16, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_V1_0), lane, tin, va);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
             kpn_st_chain<4>(B.Xv11 + hr * 32, h, tin);
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V1_1), h, vb);
-            kpn_mfma_layer_regs<16, 1, 4, 0>(wp + kpn_seg_woff(SEG_V1_1), lane, tin, vb);
-            const float visr = kpn_elu(kpn_row_dot(wp + kpn_row_off(ROW_V1_VIS), h, tin));
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_V1_1), h, vb);
+            kpn_mfma_layer_regs<16, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_V1_1), lane, tin, vb);
+            const float visr = kpn_elu(kpn_row_dot(wf + kpn_row_off(ROW_V1_VIS), h, tin));
             const float sv = kpn_sigmoid(visr);
             if (h == 0) { B.Xt33[hr * 2 + 0] = visr; B.Xt33[hr * 2 + 1] = 0.0f; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x[r] = x[r] + kpn_elu(vb[0][r]); tin[r] = x[r] * sv; }
             kpn_st_chain<4>(B.Xv20 + hr * 32, h, tin);
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_V2_0), h, va);
-            kpn_mfma_layer_regs<16, 1, 4, 0>(wp + kpn_seg_woff(SEG_V2_0), lane, tin, va);
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_V2_0), h, va);
+            kpn_mfma_layer_regs<16, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_V2_0), lane, tin, va);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
             kpn_st_chain<4>(B.Xv21 + hr * 32, h, tin);
-            const float vis = kpn_sigmoid(kpn_row_dot(wp + kpn_row_off(ROW_V2_1), h, tin));
+            const float vis = kpn_sigmoid(kpn_row_dot(wf + kpn_row_off(ROW_V2_1), h, tin));
             const float4 rd = *reinterpret_cast<const float4*>(B.Xrd + hr * 4);
             float oin[20];
 #pragma unroll
@@ -405,21 +449,21 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
                 *reinterpret_cast<float4*>(B.Xo0 + hr * KPN_LD_XO0 + 32) = make_float4(vis, rd.x, rd.y, rd.z);
                 *reinterpret_cast<float4*>(B.Xo0 + hr * KPN_LD_XO0 + 36) = make_float4(rd.w, 0.0f, 0.0f, 0.0f);
             }
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_0), h, va);
-            kpn_mfma_layer_regs<20, 1, 4, 0>(wp + kpn_seg_woff(SEG_O_0), lane, oin, va);
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_O_0), h, va);
+            kpn_mfma_layer_regs<20, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_O_0), lane, oin, va);
             float o8[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) o8[r] = kpn_elu(va[0][r]);
             kpn_st_chain<2>(B.Xo1 + hr * 16, h, o8);
-            kpn_load_bias<1>(wp + kpn_seg_boff(SEG_O_1), h, va);
-            kpn_mfma_layer_regs<8, 1, 4, 0>(wp + kpn_seg_woff(SEG_O_1), lane, o8, va);
+            kpn_load_bias<1>(wf + kpn_seg_boff(SEG_O_1), h, va);
+            kpn_mfma_layer_regs<8, 1, 4, KPN_COLOR_WLDS>(wf + kpn_seg_woff(SEG_O_1), lane, o8, va);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
             {
                 float o4[4] = {tin[0], tin[1], tin[2], tin[3]};
                 kpn_st_chain<1>(B.Xo2 + hr * 8, h, o4);
             }
-            logit[v] = kpn_row_dot(wp + kpn_row_off(ROW_O_2), h, tin);
+            logit[v] = kpn_row_dot(wf + kpn_row_off(ROW_O_2), h, tin);
         }
         // ---------------- reverse: softmax blend of the source colours (model.py:1301) ----------------
         const float* go = d_out + n * 5;
@@ -453,7 +497,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             {
                 float o4[4];
                 kpn_ld_chain<1>(B.Xo2 + hr * 8, h, o4);
-                const float* rw = wp + kpn_row_off(ROW_O_2) + h * 16;
+                const float* rw = wf + kpn_row_off(ROW_O_2) + h * 16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d8[r] = rw[r] * dl * kpn_elu_grad_from_out(o4[r]);
                 kpn_st_chain<1>(B.Do1 + hr * 8, h, d8);
@@ -461,7 +505,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_f32x16 d16[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) d16[0][r] = 0.0f;
-            kpn_mfma_layer_regs<4, 1, 4, 0>(wp + kpn_bseg_woff(BSEG_O_1T), lane, d8, d16);
+            kpn_mfma_layer_regs<4, 1, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_O_1T), lane, d8, d16);
             float d16p[8];
             {
                 float o8[8];
@@ -475,7 +519,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) doin[b][r] = 0.0f;
-            kpn_mfma_layer_regs<8, 2, 4, 0>(wp + kpn_bseg_woff(BSEG_O_0T), lane, d16p, doin);
+            kpn_mfma_layer_regs<8, 2, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_O_0T), lane, d16p, doin);
             float dxb[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dxb[r] = doin[0][r];
@@ -491,7 +535,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             {
                 float t3[16];
                 kpn_ld_chain<4>(B.Xv21 + hr * 32, h, t3);
-                const float* rw = wp + kpn_row_off(ROW_V2_1) + h * 16;
+                const float* rw = wf + kpn_row_off(ROW_V2_1) + h * 16;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dt[r] = rw[r] * ds1 * kpn_elu_grad_from_out(t3[r]);
                 kpn_st_chain<4>(B.Dv20 + hr * 32, h, dt);
@@ -499,7 +543,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_f32x16 dx2[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx2[0][r] = 0.0f;
-            kpn_mfma_layer_regs<16, 1, 4, 0>(wp + kpn_bseg_woff(BSEG_V2_0T), lane, dt, dx2);
+            kpn_mfma_layer_regs<16, 1, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_V2_0T), lane, dt, dx2);
             const float visr = B.Xt33[hr * 2 + 0];
             const float sv = kpn_sigmoid(visr);
             float dsv = 0.0f;
@@ -516,11 +560,11 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_f32x16 dt2[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dt2[0][r] = 0.0f;
-            kpn_mfma_layer_regs<16, 1, 4, 0>(wp + kpn_bseg_woff(BSEG_V1_1T), lane, d33, dt2);
+            kpn_mfma_layer_regs<16, 1, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_V1_1T), lane, d33, dt2);
             {
                 float t2[16];
                 kpn_ld_chain<4>(B.Xv11 + hr * 32, h, t2);
-                const float* rw = wp + kpn_row_off(ROW_V1_VIS) + h * 16;
+                const float* rw = wf + kpn_row_off(ROW_V1_VIS) + h * 16;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dt[r] = (dt2[0][r] + rw[r] * dvr) * kpn_elu_grad_from_out(t2[r]);
                 kpn_st_chain<4>(B.Dv10 + hr * 32, h, dt);
@@ -528,7 +572,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_f32x16 dx1[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dx1[0][r] = 0.0f;
-            kpn_mfma_layer_regs<16, 1, 4, 0>(wp + kpn_bseg_woff(BSEG_V1_0T), lane, dt, dx1);
+            kpn_mfma_layer_regs<16, 1, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_V1_0T), lane, dt, dx1);
             float dxa[16], dw_part = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -543,7 +587,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dh[b][r] = 0.0f;
-            kpn_mfma_layer_regs<16, 2, 4, 0>(wp + kpn_bseg_woff(BSEG_BL_1T), lane, dxa, dh);
+            kpn_mfma_layer_regs<16, 2, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_BL_1T), lane, dxa, dh);
             float da[32];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -559,7 +603,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dxq[b][r] = 0.0f;
-            kpn_mfma_layer_regs<32, 2, 4, 0>(wp + kpn_bseg_woff(BSEG_BL_0BT), lane, da, dxq);
+            kpn_mfma_layer_regs<32, 2, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_BL_0BT), lane, da, dxq);
             float dq[19];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dq[r] = dxq[0][r];
@@ -579,7 +623,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) das[16 * b + r] = dasum[b][r];
-            kpn_mfma_layer_regs<32, 4, 4, 0>(wp + kpn_bseg_woff(BSEG_BL_0AT), lane, das, dmv);
+            kpn_mfma_layer_regs<32, 4, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_BL_0AT), lane, das, dmv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dmean[r] = dmv[0][r]; dvar[r] = dmv[2][r]; }
 #pragma unroll
@@ -652,7 +696,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             kpn_f32x16 de[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) de[0][r] = 0.0f;
-            kpn_mfma_layer_regs<20, 1, 4, 0>(wp + kpn_bseg_woff(BSEG_RE_1T), lane, dq20, de);
+            kpn_mfma_layer_regs<20, 1, 4, KPN_COLOR_WLDS>(wb + kpn_bseg_woff(BSEG_RE_1T), lane, dq20, de);
             float e1[8], de1[8];
             kpn_ld_chain<2>(B.Xe1 + hr * 16, h, e1);
 #pragma unroll
@@ -692,7 +736,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
                 const float dev = de[v] + (v == imin ? demin : 0.0f);
                 dabs += dev * ev[v] * (dotv[v] - 1.0f);
             }
-            dabs = (h == 0) ? dabs * live * wp[kpn_scalar_off() + 3] : 0.0f;  // d|a|/da = sign(ani_al)
+            dabs = (h == 0) ? dabs * live * wf[kpn_scalar_off() + 3] : 0.0f;  // d|a|/da = sign(ani_al)
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) dabs += __shfl_xor(dabs, m);
             dani_acc += dabs;                  // one atomic per wave at the end of the kernel, not one per tile on one address
