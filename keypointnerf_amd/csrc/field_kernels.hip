@@ -600,6 +600,8 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
 #pragma unroll
         for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
+        // (two passes over the rows, the second from L2: keeping up to three views' rows in registers between the passes — 96
+        // registers — was measured 1.8 ms per frame SLOWER: the kernel is register-bound and the compiler spilled 41 dwords)
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
                 if (!((keep >> v) & 1u)) continue;

@@ -97,10 +97,13 @@ __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& 
     for (int j = 0; j < 4; ++j) {
         uint32_t ph, pl;
         float r0, r1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(ph) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph), "v"(x[2 * j]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph), "v"(x[2 * j + 1]));
-        asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(pl) : "v"(r0), "v"(r1));
+        // one statement per pair (hipcc puts an s_nop behind every asm result it sees consumed); the idle states behind the last
+        // conversion cover pl, ph is three instructions older
+        asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+            "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_pk_f16_f32 %1, %2, %3\n\ts_nop 1"
+            : "=&v"(ph), "=&v"(pl), "=&v"(r0), "=&v"(r1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
         h[j] = ph; l[j] = pl;
     }
 }
