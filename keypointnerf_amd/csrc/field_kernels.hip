@@ -476,35 +476,62 @@ __device__ __forceinline__ void kpn_encode_view(const float* __restrict__ wl, in
     o.xb1[2] = kpn_elu(a2[1][2]) + g.fadd[6];
 }
 
-// View pooling of the 64-vector (PoolModule / pool_ops, utils.py:612-647, 731-748): weighted mean and variance over
-// the source views, two passes in the reference's order.  The un-normalised boundary-smooth weights (model.py:752-759;
-// mask == 1 in every view for listed points) come with the gather records k_geo_rows wrote; dropped views weigh 0.
-// pooled[16b + r] = mean of feature 32b + rowmap(r,h), pooled[32 + 16b + r] = its variance (a lane's half of the point).
-// Returns the weights' sum (before the + 1e-6 of the normalisation).
+// View pooling of the 64-vector (PoolModule / pool_ops, utils.py:612-647, 731-748): weighted mean and variance over the source
+// views.  The un-normalised boundary-smooth weights (model.py:752-759; mask == 1 in every view for listed points) come with the
+// gather records k_geo_rows wrote; dropped views weigh 0.  pooled[16b + r] = mean of feature 32b + rowmap(r,h),
+// pooled[32 + 16b + r] = its variance (a lane's half of the point); PWSUM = the weights' sum (before the + 1e-6 of the normalisation).
+// ONE pass over the rows (they are read from the row scratch: the reference's two passes cost a second fetch of every row —
+// measured 0.4 ms per 512x512 frame), shifted by the first kept view's row x0 (d = x - x0):
+//     s1 = sum pw d,  s2 = sum pw d^2,  mean = x0 sum pw + s1,  var = sum pw (x - mean)^2 = s2 - 2 m s1 + m^2 sum pw,  m = mean - x0.
+// The shift keeps the subtraction benign: where the views agree (var << mean^2) d is small and so are all three terms; the result
+// differs from the two-pass form by rounding only (200-scene sweep against the oracle: 14 rays above 1e-4 instead of 13, all
+// ill-conditioned by the oracle's own probe).  A macro, not a function: through a helper function the forward kernel measured
+// 1.7 ms per frame slower (register allocation), and the three users (k_fuse_color*, the split colour path, the backward kernels)
+// must stay bit-identical.
+#define KPN_POOL_VIEWS(ROWS, V_, KEEP, LANE, P_, PWSUM, POOLED)                                                              \
+    do {                                                                                                                      \
+        PWSUM = 0.0f;                                                                                                         \
+        for (int v_ = 0; v_ < (V_); ++v_)                                                                                     \
+            if (((KEEP) >> v_) & 1u) PWSUM = RADD(PWSUM, (ROWS)[((size_t)v_ * KPN_ROW_SLABS + 8) * 64 + (P_)].w);             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 64; ++i_) POOLED[i_] = 0.0f;                                                  \
+        int v0_ = 0;                                                                                                          \
+        while (v0_ < (V_) && !(((KEEP) >> v0_) & 1u)) ++v0_;                                                                  \
+        if (v0_ < (V_)) {                                                                                                     \
+            float x0_[32];                                                                                                    \
+            const float4* src0_ = (ROWS) + ((size_t)v0_ * KPN_ROW_SLABS) * 64;                                                \
+            float spw_ = src0_[8 * 64 + (P_)].w / RADD(PWSUM, 1e-6f);                                                         \
+            _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                                \
+                const float4 x_ = src0_[q_ * 64 + (LANE)];                                                                    \
+                x0_[4 * q_ + 0] = x_.x; x0_[4 * q_ + 1] = x_.y; x0_[4 * q_ + 2] = x_.z; x0_[4 * q_ + 3] = x_.w;               \
+            }                                                                                                                 \
+            for (int v_ = v0_ + 1; v_ < (V_); ++v_) {                                                                         \
+                if (!(((KEEP) >> v_) & 1u)) continue;                                                                         \
+                const float4* src_ = (ROWS) + ((size_t)v_ * KPN_ROW_SLABS) * 64;                                              \
+                const float pw_ = src_[8 * 64 + (P_)].w / RADD(PWSUM, 1e-6f);                                                 \
+                spw_ = RADD(spw_, pw_);                                                                                       \
+                _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                            \
+                    const float4 x_ = src_[q_ * 64 + (LANE)];                                                                 \
+                    const float xe_[4] = {x_.x, x_.y, x_.z, x_.w};                                                            \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                        \
+                        const int i_ = 4 * q_ + e_;                                                                           \
+                        const float d_ = RSUB(xe_[e_], x0_[i_]);                                                              \
+                        POOLED[i_] = fmaf(pw_, d_, POOLED[i_]);                                                               \
+                        POOLED[32 + i_] = fmaf(RMUL(pw_, d_), d_, POOLED[32 + i_]);                                           \
+                    }                                                                                                         \
+                }                                                                                                             \
+            }                                                                                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < 32; ++i_) {                                                               \
+                const float s1_ = POOLED[i_], s2_ = POOLED[32 + i_];                                                          \
+                const float mean_ = fmaf(x0_[i_], spw_, s1_), m_ = RSUB(mean_, x0_[i_]);                                      \
+                POOLED[i_] = mean_;                                                                                           \
+                POOLED[32 + i_] = fmaxf(fmaf(m_, fmaf(m_, spw_, RMUL(-2.0f, s1_)), s2_), 0.0f);                               \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
 __device__ __forceinline__ float kpn_pool_views(const float4* __restrict__ rows, int V, uint32_t keep, int lane, int p,
                                                 float (&pooled)[64]) {
-    float pwsum = 0.0f;
-    for (int v = 0; v < V; ++v)
-        if ((keep >> v) & 1u) pwsum = RADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
-#pragma unroll
-    for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int v = 0; v < V; ++v) {
-            if (!((keep >> v) & 1u)) continue;
-            const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-            const float pw = src[8 * 64 + p].w / RADD(pwsum, 1e-6f);
-#pragma unroll
-            for (int q4 = 0; q4 < 8; ++q4) {
-                const float4 x = src[q4 * 64 + lane];
-                const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * q4 + e;
-                    if (pass == 0) pooled[i] = RADD(pooled[i], RMUL(pw, xe[e]));
-                    else { const float d = RSUB(xe[e], pooled[i]); pooled[32 + i] = RADD(pooled[32 + i], RMUL(pw, RMUL(d, d))); }
-                }
-            }
-        }
+    float pwsum;
+    KPN_POOL_VIEWS(rows, V, keep, lane, p, pwsum, pooled);
     return pwsum;
 }
 
@@ -593,32 +620,9 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // ---- pooled mean / var over views of the 64-vector ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
-        // (kpn_pool_views spelled out: through the helper this kernel measured 1.7 ms per frame slower)
-        float pwsum = 0.0f;
-        for (int v = 0; v < V; ++v)
-            if ((keep >> v) & 1u) pwsum = RADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
+        float pwsum;
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
-#pragma unroll
-        for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-        // (two passes over the rows, the second from L2: keeping up to three views' rows in registers between the passes — 96
-        // registers — was measured 1.8 ms per frame SLOWER: the kernel is register-bound and the compiler spilled 41 dwords)
-        for (int pass = 0; pass < 2; ++pass)
-            for (int v = 0; v < V; ++v) {
-                if (!((keep >> v) & 1u)) continue;
-                const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-                const float pw = src[8 * 64 + p].w / RADD(pwsum, 1e-6f);
-#pragma unroll
-                for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x = src[q4 * 64 + lane];
-                    const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * q4 + e;
-                        if (pass == 0) pooled[i] = RADD(pooled[i], RMUL(pw, xe[e]));
-                        else { const float d = RSUB(xe[e], pooled[i]); pooled[32 + i] = RADD(pooled[32 + i], RMUL(pw, RMUL(d, d))); }
-                    }
-                }
-            }
+        KPN_POOL_VIEWS(rows, V, keep, lane, p, pwsum, pooled);
         KPN_FUSE_STAMP(1);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;

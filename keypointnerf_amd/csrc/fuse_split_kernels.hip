@@ -50,30 +50,9 @@ __global__ __launch_bounds__(512, KPN_SPLIT_OCC) void k_pool_geo(kpn_scene_dev s
         // ---- pooled mean / var over views of the 64-vector ----
         const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
-        // (kpn_pool_views spelled out: through the helper this kernel measured 1.7 ms per frame slower)
-        float pwsum = 0.0f;
-        for (int v = 0; v < V; ++v)
-            if ((keep >> v) & 1u) pwsum = RADD(pwsum, rows[((size_t)v * KPN_ROW_SLABS + 8) * 64 + p].w);  // h=0 lane's record
+        float pwsum;
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
-#pragma unroll
-        for (int i = 0; i < 64; ++i) pooled[i] = 0.0f;
-        for (int pass = 0; pass < 2; ++pass)
-            for (int v = 0; v < V; ++v) {
-                if (!((keep >> v) & 1u)) continue;
-                const float4* src = rows + ((size_t)v * KPN_ROW_SLABS) * 64;
-                const float pw = src[8 * 64 + p].w / RADD(pwsum, 1e-6f);
-#pragma unroll
-                for (int q4 = 0; q4 < 8; ++q4) {
-                    const float4 x = src[q4 * 64 + lane];
-                    const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 4 * q4 + e;
-                        if (pass == 0) pooled[i] = RADD(pooled[i], RMUL(pw, xe[e]));
-                        else { const float d = RSUB(xe[e], pooled[i]); pooled[32 + i] = RADD(pooled[32 + i], RMUL(pw, RMUL(d, d))); }
-                    }
-                }
-            }
+        KPN_POOL_VIEWS(rows, V, keep, lane, p, pwsum, pooled);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
         {
