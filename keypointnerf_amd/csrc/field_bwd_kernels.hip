@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
 // One launch serves several layers ("jobs", blockIdx.y): the small layers of the colour head would each fill a
 // fraction of the chip on their own.  grid (row workers, jobs); a workgroup = one row slice of one job, its waves =
 // the job's 64-column groups (dY is fetched from HBM once).  Every wave writes its partial tile block in raw
-// register order; k_weight_grad_reduce sums the workers in a fixed order (deterministic, no atomics).
+// register order; k_weight_grad_reduce sums the workers in a fixed order (no atomics: bit-reproducible for a given row order,
+// i.e. for a given valid list — scripts/soak_backward.py).
 //   partial: [column groups][workers][MV*2*16][64 lanes];  dbp: [workers][MV][64 lanes]
 #define KPN_WGRAD_MAX_JOBS 20
 struct kpn_wgrad_job {
@@ -642,7 +643,7 @@ __device__ __forceinline__ int kpn_grad_col(int cmap, int c) {
     return c;
 }
 // Fixed-order sum of the workers' partial blocks, added to the plain-layout gradient (no atomics: the weight
-// gradient is deterministic).  grid (element groups of 32, column groups, jobs); a workgroup owns 32 consecutive
+// gradient is reproducible for a given row order).  grid (element groups of 32, column groups, jobs); a workgroup owns 32 consecutive
 // elements; its 8 thread-octets stride over the workers and combine through LDS.
 __global__ __launch_bounds__(256) void k_weight_grad_reduce(kpn_wgrad_jobs jobs, int nworkers) {
     const kpn_wgrad_job& J = jobs.j[blockIdx.z];
