@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
     const int nwork = ntiles * sc.V;
-    const float pe_pi = 3.14159274101257324f;
     __shared__ __attribute__((aligned(16))) float bias_s[3][128];
     // Per wave: 32 rows x up to 128 features (+ pad).  Every dump below is staged here and written out with the LANES ALONG THE
     // FEATURES (one instruction = two whole 512-B rows): from the registers a lane holds ONE row, and a store instruction issued
@@ -196,7 +195,7 @@ __global__ __launch_bounds__(256, KPN_BWD_OCC) void k_geo_rows_bwd(kpn_scene_dev
                 const float d2 = RADD(RADD(RMUL(dx_, dx_), RMUL(dy, dy)), RMUL(dz, dz));
                 const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                kpn_sincos(RMUL(dz, pe_pi), s1, c1);
+                kpn_sincos_pi(dz, s1, c1);
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
                 const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
                 x[0] = dz * w;

@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
     int t0, t1;
     if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
     const int nwork = (t1 - t0) * sc.V;
-    const float pe_pi = 3.14159274101257324f;  // float32(pi), spatial.py:42-47
     // the four bias blocks (448 floats) sit in LDS for the lifetime of the persistent workgroup: a layer
     // starts with a ds_read instead of an exposed L2 round trip
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
                 const float d2 = RADD(RADD(RMUL(dx, dx), RMUL(dy, dy)), RMUL(dz, dz));
                 const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                kpn_sincos(RMUL(dz, pe_pi), s1, c1);
+                kpn_sincos_pi(dz, s1, c1);
                 // sin/cos(2y), sin/cos(4y): the reference's arguments are exactly 2y and 4y
                 // (float32(2*pi) == 2*float32(pi)), so the double-angle identities apply to them
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
@@ -249,7 +248,6 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
     int t0, t1;
     if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
     const int nwork = (t1 - t0) * sc.V;
-    const float pe_pi = 3.14159274101257324f;
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
     {
         const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev 
                 const float d2 = RADD(RADD(RMUL(dx, dx), RMUL(dy, dy)), RMUL(dz, dz));
                 const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
                 float s1, c1;
-                kpn_sincos(RMUL(dz, pe_pi), s1, c1);
+                kpn_sincos_pi(dz, s1, c1);
                 const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
                 const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
                 x[0] = dz * w;

@@ -405,7 +405,6 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
     if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
     const int nbt = t1 - t0;                               // tiles of this batch
     const int nwork = ((nbt + 1) >> 1) * sc.V;
-    const float pe_pi = 3.14159274101257324f;
     const float neg_inv_two_sigma2 = -1.0f / sc.two_sigma2;   // exp(-d2 / 2 sigma^2) as one multiply per keypoint
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
     {
@@ -497,52 +496,42 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64 + 8 * h;
             // The keypoint encoding of step n (weight w = exp(-d^2 / 2 sigma^2), sin/cos of pi z, doubled twice) is computed ONE
-            // STEP AHEAD in ten small stages that ride in the nearly empty slices of the step before (an encoding step has no
-            // activation to compute): [parity of the step][tile] holds the finished dz, w, sin, cos.
+            // STEP AHEAD in four small stages that ride in the nearly empty slices of the step before (an encoding step has no
+            // activation to compute): [parity of the step][tile] holds the finished dz, w, sin, cos.  sin / cos of pi z are
+            // v_sin_f32 / v_cos_f32 of z / 2 revolutions (kpn_sincos_pi, kpn_device.h: as accurate as the 28-instruction
+            // Cody-Waite + minimax form this replaced; measured 1.2 % of the kernel — the encoding steps were not VALU-bound).
+            // Tried and dropped for the geometry steps: the taps fetched COALESCED, four whole texels per
+            // instruction landing in LDS (global_load_lds_dwordx4, the texel index of a point by ds_bpermute, a rotated chunk order
+            // for conflict-free reads): correct, 5 % SLOWER — 510 more instructions per work item in a kernel that is issue-bound,
+            // although with every lane gathering the same texels (-DKPN_DBG_H2_SAMETAP) the kernel runs 12 % faster.
             float fdz[2][2], fw[2][2], fs1[2][2], fc1[2][2];
             float kcv[2][3] = {{kc[0], kc[1], kc[2]}, {kc[3], kc[4], kc[5]}};   // keypoints of steps 0 and 1 (this half's 12)
-            float tdx[2], tdy[2], ty[2], targ[2], tk[2], tr[2], tr2[2], tsp[2], tcp[2], tg[2], ts2[2], tc2[2];
-            int tqi[2];
+            float tdx[2], tdy[2], ty[2], targ[2], ts2[2], tc2[2];
             float4 raw[2][8];                               // geo0: the four taps of two float4 of channels
-            auto pe_stage = [&](auto ni, auto ti, auto gi) {   // stage gi (0..9) of the encoding of keypoint step ni, tile ti
+            auto pe_stage = [&](auto ni, auto ti, auto gi) {   // stage gi (0..9; 4..9 empty) of the encoding of keypoint step ni, tile ti
                 constexpr int n = decltype(ni)::value, t = decltype(ti)::value, g = decltype(gi)::value, b = n & 1;
                 if constexpr (g == 0) {
                     // the keypoint's camera-frame coordinates were fetched two steps ago (a load followed by its use costs a full
                     // L2 round trip when no other wave shares the SIMD); tile 1 is the last user: it refills the slot for step n+2
                     tdx[t] = RSUB(cx[t], kcv[b][0]); tdy[t] = RSUB(cy[t], kcv[b][1]); fdz[b][t] = RSUB(cz[t], kcv[b][2]);
-                    ty[t] = RMUL(fdz[b][t], pe_pi);
+                    ty[t] = fdz[b][t] * 0.5f;               // pi z in revolutions
                     if constexpr (t == 1 && n + 2 < 12) { kcv[b][0] = kc[(n + 2) * 3 + 0]; kcv[b][1] = kc[(n + 2) * 3 + 1]; kcv[b][2] = kc[(n + 2) * 3 + 2]; }
                 } else if constexpr (g == 1) {
                     const float d2 = RADD(RADD(RMUL(tdx[t], tdx[t]), RMUL(tdy[t], tdy[t])), RMUL(fdz[b][t], fdz[b][t]));
                     targ[t] = d2 * neg_inv_two_sigma2;
                 } else if constexpr (g == 2) {
                     fw[b][t] = kpn_fast_exp(targ[t]);
-                    tk[t] = rintf(ty[t] * 0.636619772367581343f);
-                } else if constexpr (g == 3) {              // Cody-Waite reduction by pi/2 (kpn_sincos, kpn_device.h)
-                    float r = fmaf(tk[t], -1.5703125f, ty[t]);
-                    r = fmaf(tk[t], -4.837512969970703125e-4f, r);
-                    tr[t] = fmaf(tk[t], -7.54978995489188216e-8f, r);
-                    tr2[t] = tr[t] * tr[t];
-                } else if constexpr (g == 4) {
-                    tsp[t] = fmaf(tr2[t], fmaf(tr2[t], -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
-                    tg[t] = tr2[t] * tr[t];
-                } else if constexpr (g == 5) {
-                    tsp[t] = fmaf(tg[t], tsp[t], tr[t]);
-                    tcp[t] = fmaf(tr2[t], fmaf(tr2[t], 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
-                } else if constexpr (g == 6) {
-                    tcp[t] = fmaf(tr2[t] * tr2[t], tcp[t], fmaf(tr2[t], -0.5f, 1.0f));
-                } else if constexpr (g == 7) {              // quadrant k mod 4 without compares (a v_cmp result needs two wait
-                    // states before v_cndmask may read it, and nothing else is in these slices): swap sin and cos for odd k
-                    const int qd = (int)tk[t];
-                    tqi[t] = qd;
-                    const uint32_t m = (uint32_t)(-(qd & 1));
-                    const uint32_t sb = __builtin_bit_cast(uint32_t, tsp[t]), cb = __builtin_bit_cast(uint32_t, tcp[t]);
-                    tsp[t] = __builtin_bit_cast(float, (cb & m) | (sb & ~m));
-                    tcp[t] = __builtin_bit_cast(float, (sb & m) | (cb & ~m));
-                } else if constexpr (g == 8) {              // sin: negative in quadrants 2, 3
-                    fs1[b][t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, tsp[t]) ^ (((uint32_t)tqi[t] << 30) & 0x80000000u));
-                } else {                                    // cos: negative in quadrants 1, 2
-                    fc1[b][t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, tcp[t]) ^ (((uint32_t)(tqi[t] + 1) << 30) & 0x80000000u));
+#ifndef KPN_SIMT_EMU
+                    fs1[b][t] = __builtin_amdgcn_sinf(ty[t]);
+#else
+                    fs1[b][t] = (float)sin(6.28318530717958647692 * (double)ty[t]);
+#endif
+                } else if constexpr (g == 3) {
+#ifndef KPN_SIMT_EMU
+                    fc1[b][t] = __builtin_amdgcn_cosf(ty[t]);
+#else
+                    fc1[b][t] = (float)cos(6.28318530717958647692 * (double)ty[t]);
+#endif
                 }
             };
             auto geo_loads = [&](auto si, auto ti, auto fi) {   // the taps of float4 f (0/1) of geo step s: channels 16(s-12) + 8h + 4f ..

@@ -69,6 +69,22 @@ __device__ __forceinline__ void kpn_sincos(float y, float& s, float& c) {
     s = (q & 2) ? -ss : ss;
     c = ((q + 1) & 2) ? -cc : cc;
 }
+// sin(pi z), cos(pi z) for the keypoint encoding: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, and z / 2 is exact.
+// Measured on the MI355X (scripts/sincos_probe.hip, against float64, |z| <= 8): max abs error 1.25e-7 for the pair, 5.4e-7 / 9.7e-7
+// after one / two angle doublings — the polynomial form above, which rounds z * pi first as the reference does, is at
+// 4.2e-7 / 9.8e-7 / 2.0e-6 for |z| <= 2 and grows with |z|.  Against the REFERENCE (sin of the rounded fp32 argument,
+// spatial.py:36-37) the hardware form is off by that argument rounding, <= 1.5e-6 at 4 pi z for |z| <= 1.5 — the same order as
+// the doubling formulas' error before — for 3 instructions instead of ~28 per (point, keypoint).
+__device__ __forceinline__ void kpn_sincos_pi(float z, float& s, float& c) {
+#ifndef KPN_SIMT_EMU
+    const float r = z * 0.5f;
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+#else
+    s = (float)sin(3.14159265358979323846 * (double)z);
+    c = (float)cos(3.14159265358979323846 * (double)z);
+#endif
+}
 __device__ __forceinline__ float kpn_elu(float x) {
 #ifdef KPN_ABLATE_ELU  // timing experiment only: wrong results
     return x;
