@@ -655,8 +655,18 @@ __global__ __launch_bounds__(256) void k_weight_grad_reduce(kpn_wgrad_jobs jobs,
     if (64 * z >= J.Kc || blockIdx.x * 32 >= TILE_E + MV * 32) return;  // uniform per workgroup
     float s = 0.0f;
     if (e < TILE_E) {
+        // 64 workers per thread: sixteen loads in flight, added in the fixed order (one load per add, as the loop it replaces,
+        // exposed a whole HBM round trip per worker: 104 us per call however few workers there were)
         const float* src = J.partial + (size_t)z * nworkers * TILE_E + e;
-        for (int w = wl; w < nworkers; w += 8) s += src[(size_t)w * TILE_E];
+        int w = wl;
+        for (; w + 8 * 15 < nworkers; w += 8 * 16) {
+            float a[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = src[(size_t)(w + 8 * k) * TILE_E];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += a[k];
+        }
+        for (; w < nworkers; w += 8) s += src[(size_t)w * TILE_E];
     } else if (z == 0 && e < TILE_E + MV * 32) {
         const int q = e - TILE_E, a = q / 32, i = q % 32;
         for (int w = wl; w < nworkers; w += 8) s += J.dbp[((size_t)w * MV + a) * 64 + i] + J.dbp[((size_t)w * MV + a) * 64 + 32 + i];
