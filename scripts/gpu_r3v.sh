@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 closing evidence run: smoke, full GPU suite, driver-style bench line + rocprofv3 kernel table of the same command,
 # training bench (field part and through the drop-in) + kernel table, k_geo_rows_bwd phase cycles, orbit with and without encoders
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=${1:-r3v}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; TAG=${1:-r3z}
 (timeout 600 python __graft_entry__.py --smoke) > gpurun_out/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke_$TAG.log
 (timeout 1500 python -m pytest tests -m gpu -q) > gpurun_out/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_$TAG.log
 (timeout 1200 python bench.py) > gpurun_out/bench_$TAG.json 2>gpurun_out/bench_$TAG.err; echo "bench rc=$?"; tail -1 gpurun_out/bench_$TAG.json | cut -c1-400
