@@ -89,7 +89,14 @@ __device__ __forceinline__ float kpn_elu(float x) {
 #ifdef KPN_ABLATE_ELU  // timing experiment only: wrong results
     return x;
 #endif
-    return x > 0.0f ? x : (kpn_fast_exp(x) - 1.0f);
+    // ELU(x) = median(x, e^x - 1, 0): for x > 0 the order is 0 < x <= e^x - 1, for x < 0 it is x <= e^x - 1 < 0 — one v_med3_f32
+    // instead of v_cmp + v_cndmask (and no VCC wait states); where rounding swaps the two near 0 they differ by < 1e-7.
+    const float t = kpn_fast_exp(x) - 1.0f;
+#ifndef KPN_SIMT_EMU
+    return __builtin_amdgcn_fmed3f(x, t, 0.0f);
+#else
+    return fmaxf(fminf(x, t), fminf(fmaxf(x, t), 0.0f));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
