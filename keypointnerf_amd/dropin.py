@@ -37,6 +37,8 @@ from .weights import plain_tensor_from_module
 _OUT_KEYS = ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")
 _SEAMS = ("batch_render_pifu_nerf", "render_pifu_nerf", "query", "rgba2out", "importance_sample", "ray_bbox_intersection")
 _HOT_PREFIXES = ("mlp_geo.", "mlp_tex.", "ibr_compress_gfeat.")
+# rays of one stochastic render whose pass state is kept for the backward (the shipped patch is 64 x 64 = 4096, configs/zju.json:36-37)
+_KEEP_STATE_MAX_RAYS = 16384
 
 
 def _version_key(tensors):
@@ -83,7 +85,12 @@ class _State:
         self.weights_key = None
         self.plans = {}
         self.feats = None            # (encoder key, (img, image key), feat_geo, feat_tex): encoder outputs of the last source set
-        self.attached = None         # (encoder key, image key) at the module's last attach_geo_feat(im) without return_val
+        # the module's own attach_im_feat(im) (no return_val): encoder key at that moment + the very feat_geo / feat_tex OBJECTS it
+        # left on the module.  The reference overwrites net.feat_geo / net.feat_tex on EVERY attach_*_feat call, return_val or not
+        # (src/model.py:664,678), while net.im only changes without return_val: the shortcut in encoder_features therefore also
+        # requires that the module still holds these very objects.
+        self.attached = None         # (encoder key, feat_geo object)
+        self.attached_tex = None     # feat_tex object computed by attach_tex_feat(im) for the SAME im, else None
 
     def packed_weights(self):
         params = [p for n, p in self.net.named_parameters() if n.startswith(_HOT_PREFIXES)]
@@ -145,9 +152,20 @@ class _State:
         return img0.numel() == img_in.numel() and img0.device == img_in.device and bool(torch.equal(img0.reshape(img_in.shape), img_in))
 
     def note_attached(self, im):
-        """Called by the wrapped attach_geo_feat (install): the module now holds feat_geo / feat_tex of `im`, computed with the
-        encoder state of this moment (the reference keeps its own clone in net.im, src/model.py:653-657)."""
-        self.attached = (self.encoder_key(), _version_key([im]))
+        """Called by the wrapped attach_geo_feat (install) after a call WITHOUT return_val: the module now holds net.im = im.clone()
+        and feat_geo of `im`, computed with the encoder state of this moment (src/model.py:653-666).  feat_tex is noted by the
+        wrapped attach_tex_feat when it is computed for the same images."""
+        self.attached = (self.encoder_key(), getattr(self.net, "feat_geo", None))
+        self.attached_tex = None
+
+    def note_attached_tex(self, im):
+        """Wrapped attach_tex_feat without return_val: feat_tex belongs to the attached source set only if `im` is net.im's content
+        (a bare attach_tex_feat(B) after attach_im_feat(A) must not pair F_tex(B) with F_geo(A))."""
+        net = self.net
+        im0 = getattr(net, "im", None)
+        ok = (self.attached is not None and im0 is not None and im0.numel() == im.numel() and im0.device == im.device
+              and bool(torch.equal(im0.reshape(im.shape), im)))
+        self.attached_tex = getattr(net, "feat_tex", None) if ok else None
 
     def encoder_features(self, img_in):
         """feat_geo / feat_tex of the source images.  render_novel_views runs both encoders once per source set
@@ -162,10 +180,13 @@ class _State:
         ekey = self.encoder_key()
         if ekey is not None:
             im0 = getattr(net, "im", None)
-            if (self.attached is not None and self.attached[0] == ekey and im0 is not None and getattr(net, "feat_geo", None) is not None
-                    and (getattr(net, "tex_encoder", None) is None or getattr(net, "feat_tex", None) is not None)
+            # the attached maps: same encoder state, the module still holds the very objects attach_im_feat left (any later
+            # attach_*_feat(other, return_val=True) — render_pifu_nerf, an eval forward — replaces them), same images
+            fg, ft = getattr(net, "feat_geo", None), getattr(net, "feat_tex", None)
+            if (self.attached is not None and self.attached[0] == ekey and im0 is not None and fg is not None and fg is self.attached[1]
+                    and (getattr(net, "tex_encoder", None) is None or (ft is not None and ft is self.attached_tex))
                     and self._same_images((im0, None), img_in)):
-                return net.feat_geo, net.feat_tex
+                return fg, ft
             if self.feats is not None and self.feats[0] == ekey and self._same_images(self.feats[1], img_in):
                 return self.feats[2], self.feats[3]
         g = net.attach_geo_feat(img_in, return_val=True)
@@ -261,8 +282,11 @@ def install(net, rows_mode=None):
             [float(cam_in["znear"]), float(cam_in["zfar"]), float(cam_in.get("nml_scale", 100.0)), encoder_sigma(net)],
             tar["K"], tar["RT"], config["bounds"], float(tar["znear"]), float(tar["zfar"]), grids.to(torch.int32), u_c, u_f,
             noise_c, noise_f, int(keep_c), int(keep_f), std, int(Sc), int(Sf),
-            # training: keep the forward's pass state so that loss.backward() does not repeat the forward
-            bool(torch.is_grad_enabled() and (plain.requires_grad or feat_geo[0].requires_grad or feat_tex.requires_grad)))
+            # training: keep the forward's pass state (about 1 KB per field evaluation) so that loss.backward() does not repeat
+            # the forward — within the training budget only: a whole validation frame rendered with gradients enabled
+            # (net.eval() without no_grad) stays differentiable, its backward repeats the forward instead of pinning tens of GB
+            bool(torch.is_grad_enabled() and R <= _KEEP_STATE_MAX_RAYS
+                 and (plain.requires_grad or feat_geo[0].requires_grad or feat_tex.requires_grad)))
         out = {}
         for k, v in zip(_OUT_KEYS, res):                            # (1,3,R) / (1,R) in pixel-list order
             out[k] = v.view(1, 3, out_h, out_w) if k.startswith("tex") else v.view(1, out_h, out_w)
@@ -364,9 +388,17 @@ def install(net, rows_mode=None):
             st.note_attached(im)
         return r
 
+    def attach_tex_feat(self, im, return_val=False):
+        r = cls.attach_tex_feat(self, im, return_val)
+        if not return_val:
+            st.note_attached_tex(im)
+        return r
+
     net._kpnerf_reference_methods = {k: net.__dict__.get(k) for k in _SEAMS}
     if hasattr(cls, "attach_geo_feat"):
         net.attach_geo_feat = types.MethodType(attach_geo_feat, net)
+    if hasattr(cls, "attach_tex_feat"):
+        net.attach_tex_feat = types.MethodType(attach_tex_feat, net)
     net.query = types.MethodType(query, net)
     net.batch_render_pifu_nerf = batch_render_pifu_nerf            # static in the reference: called as net.f(net=net, ...)
     net.render_pifu_nerf = render_pifu_nerf
@@ -378,7 +410,7 @@ def install(net, rows_mode=None):
 
 
 def uninstall(net):
-    for k in _SEAMS + ("attach_geo_feat",):
+    for k in _SEAMS + ("attach_geo_feat", "attach_tex_feat"):
         if k in net.__dict__:
             del net.__dict__[k]
     for k in ("_kpnerf_state", "_kpnerf_reference_methods"):

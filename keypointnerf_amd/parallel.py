@@ -125,7 +125,9 @@ class FrameGatherer:
         k = self.rounds % self.depth
         if self.work[k] is not None:
             self.work[k].wait()                       # the buffer's previous gather (two rounds ago) has long finished
-        self.staging[k].copy_(img, non_blocking=True)
+        # device staging (RCCL): the copy is stream-ordered in front of the gather.  Host staging (gloo): pageable memory and a
+        # host-side read by the backend — the copy must have completed when gather() looks at the buffer, so it is synchronous
+        self.staging[k].copy_(img, non_blocking=self.staging[k].is_cuda)
         bucket = list(self.dest[k].unbind(0)) if self.rank == 0 else None
         if self.asynchronous:
             try:

@@ -165,25 +165,35 @@ def _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
 
 # One training iteration calls the forward op and then the backward op with the SAME parameters and maps: the packed weights
 # (weight-norm fold + operand order + fp16 / bf16 streams) and the prepared scene (NCHW -> NHWC of every map) of the forward call
-# are kept for the backward call instead of being built twice.  Keyed on storage + version counter of every tensor (autograd
-# hands the backward op new tensor objects over the same storage), so an in-place change in between is a miss, never a stale hit.
-_iter_cache = {"key": None, "scene": None, "w": None}
+# are kept for the backward call instead of being built twice.  Autograd hands the backward op NEW tensor objects over the same
+# storage, so the key is (storage address, version counter, shape, device) per tensor — and the entry HOLDS the forward call's
+# input tensors: while it lives their storage cannot be freed, so an equal address means the same storage, and an in-place change
+# in between moves the version counter: a miss, never a stale hit.  The backward op drops the entry when it is done (nothing of an
+# iteration stays resident after it); one entry per thread.
+import threading
+
+_iter_cache = threading.local()
 
 
 def _tensor_key(t):
     if t is None:
         return None
-    return (t.data_ptr(), t._version if not t.is_inference() else -1, tuple(t.shape), str(t.device))
+    return (t.data_ptr(), t._version if not t.is_inference() else -1, tuple(t.shape), str(t.device), t.dtype)
+
+
+def _iter_cache_clear():
+    _iter_cache.key = _iter_cache.scene = _iter_cache.w = _iter_cache.pinned = None
 
 
 def _scene_and_weights(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
     tensors = (plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask)
     key = tuple(_tensor_key(t) for t in tensors) + (tuple(scal),)
-    if any(t is not None and t.is_inference() for t in tensors) or key != _iter_cache["key"]:
-        _iter_cache["scene"] = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal)
-        _iter_cache["w"] = ops.PackedWeights.from_plain(plain, device=geo0.device)
-        _iter_cache["key"] = key
-    return _iter_cache["scene"], _iter_cache["w"]
+    if any(t is not None and t.is_inference() for t in tensors) or key != getattr(_iter_cache, "key", None):
+        _iter_cache.scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal)
+        _iter_cache.w = ops.PackedWeights.from_plain(plain, device=geo0.device)
+        _iter_cache.key = key
+        _iter_cache.pinned = tensors
+    return _iter_cache.scene, _iter_cache.w
 
 
 @_lib.custom_op("kpnerf::render_rays_train", mutates_args=(), device_types="cuda")
@@ -234,6 +244,7 @@ def render_rays_train_backward(plain: torch.Tensor, geo0: torch.Tensor, geo1: to
     d_plain, d_g0, d_g1, d_tx = ops.render_rays_train_backward(
         scene, w, {"K": K, "RT": RT, "znear": znear, "zfar": zfar}, bounds, pix, u_c, u_f, keep_c, keep_f, grads,
         noise_coarse=noise_c, noise_fine=noise_f, rand_noise_std=noise_std, n_coarse=n_coarse, n_fine=n_fine, state=state)
+    _iter_cache_clear()   # stream-ordered: the launches above hold nothing but device pointers the allocator keeps valid for them
     return d_plain, d_g0.contiguous(), d_g1.contiguous(), d_tx.contiguous()
 
 

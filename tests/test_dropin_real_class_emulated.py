@@ -109,6 +109,38 @@ def test_encoders_run_once_per_source_set_and_again_when_their_state_changes(emu
         uninstall(net)
 
 
+@torch.no_grad()
+def test_attached_maps_are_not_served_after_the_module_replaced_them(emulated):
+    """The reference overwrites net.feat_geo / net.feat_tex on EVERY attach_*_feat call, also with return_val=True
+    (src/model.py:664,678), while net.im only changes without return_val.  Sequence: attach_im_feat(A); render(img_in=B) — the
+    encoders run with return_val=True, so the module now holds F(B) although net.im is still A; render(img_in=A) must NOT take the
+    attached shortcut (it would return F(B) for A).  Also: a bare attach_tex_feat(B) after attach_im_feat(A) must not pair
+    F_geo(A) with F_tex(B)."""
+    from keypointnerf_amd.dropin import install, uninstall
+    net, s = _net_and_scene()
+    A = s["img"]
+    B = (s["img"] * 0.5 + 0.1).clone()
+    kw = dict(net=net, cam_in=s["cam"], cam_tar=s["cam_tar"], tar_img=None, sp_data=dict(s["sp_data"]),
+              objcenter=torch.zeros(1, 3), fine=True, uniform=True, objrad=250., blur=3, level=1, sample_per_ray_c=8,
+              sample_per_ray_f=8, src_foreground_mask=s["src_foreground_mask"], bounds=s["bounds"], mask_at_box=torch.ones(1, 16, 16))
+    install(net)
+    try:
+        net.attach_im_feat(A)
+        want_a = net.render_pifu_nerf(img_in=A, **kw)                # the attached maps of A
+        got_b = net.render_pifu_nerf(img_in=B, **kw)                 # replaces net.feat_geo / feat_tex by F(B)
+        again_a = net.render_pifu_nerf(img_in=A, **kw)
+        assert not torch.equal(want_a["tex_fg_fine"], got_b["tex_fg_fine"])
+        for k in want_a:
+            assert torch.equal(want_a[k], again_a[k]), k             # A is rendered from F(A), not from the module's F(B)
+        net.attach_im_feat(A)
+        net.attach_tex_feat(B)                                       # bare: feat_tex is now F_tex(B), net.im still A
+        mixed = net.render_pifu_nerf(img_in=A, **kw)
+        for k in want_a:
+            assert torch.equal(want_a[k], mixed[k]), k
+    finally:
+        uninstall(net)
+
+
 def test_compute_error_matches_the_reference_for_its_other_lambdas(emulated):
     """losses.compute_error against the reference's compute_error (src/utils.py:97-171) beyond the shipped lambdas: l2 / lp /
     mask loss switched on, an ssim weight and `*top*` keys present (both without effect in the reference), weights of 0 —
