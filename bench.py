@@ -77,16 +77,49 @@ def parse():
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="0 = size the CPU sample for ~15 s")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank renders its own frame of the orbit per step (frames sharded, the production job); "
-                         "strong = ONE frame per step, split into N bands of image rows (SURVEY 8(e))")
+                         "strong = ONE frame per step, its rows dealt round-robin to the N ranks (SURVEY 8(e))")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: gather each frame before the next one starts (default: the "
                     "gather of frame i overlaps the rendering of frame i + 1)")
     ap.add_argument("--no-configs4", action="store_true", help="skip secondary.configs4_full (4096^2 rays, 10 views, 128 flat samples: ~15 s + set-up)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
+def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, ref):
+    """The HIP frame against the oracle's rays at the pixels `pix` (x, y): worst |difference| per output and the verdict of the
+    parity gate (tests/parity_gate.py: <= 1e-4 on every ray unless the oracle's own conditioning probe explains the ray; the
+    probe is run on the rays above the bar only).  `frame`: {key: (3,H,W) / (H,W) numpy arrays}.  The checker, not the product."""
+    import numpy as np
+    from tests import parity_gate
+    keys = [k for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine") if k in ref and k in frame]
+    got = {k: (frame[k][:, pix[:, 1], pix[:, 0]].T if frame[k].ndim == 3 else frame[k][pix[:, 1], pix[:, 0]]) for k in keys}
+    err = {k: np.abs(got[k] - ref[k]) for k in keys}
+    ray_err = {k: (e.max(-1) if e.ndim == 2 else e) for k, e in err.items()}
+    above = np.zeros(pix.shape[0], bool)
+    for k in keys:
+        above |= ~(ray_err[k] <= parity_gate.RGBA_TOL)
+    res = {"rays": int(pix.shape[0]), "max_abs_rgb": float(max(np.nanmax(ray_err[k]) for k in keys if k.startswith("tex"))),
+           "max_abs_alpha": float(max(np.nanmax(ray_err[k]) for k in keys if k.startswith("alpha"))),
+           "rays_above_1e-4": int(above.sum()), "widened": 0, "unexplained": 0, "finite": bool(all(np.isfinite(got[k]).all() for k in keys)),
+           "what": "HIP frame vs the C oracle (pinned to the reference's outputs) on these rays; gate = tests/parity_gate.py"}
+    if above.any():
+        idx = np.nonzero(above)[0]
+        sub = {k: got[k][idx] for k in keys}
+        subref = {k: ref[k][idx] for k in keys}
+        env = lambda: oracle.render_envelope(osc, wflat, cam_tar, bounds, pix[idx], Sc, Sf, fine=fine)
+        try:
+            rep = parity_gate.check_rays(sub, subref, env, keys=keys, max_widened_fraction=1.0, what="bench frame")
+            res["widened"] = len(rep["widened"])
+        except AssertionError as e:
+            res["unexplained"] = int(above.sum())
+            res["error"] = str(e)[:400]
+    res["ok"] = bool(res["finite"] and res["unexplained"] == 0 and res["widened"] <= max(1, pix.shape[0] // 500))
+    return res
+
+
+def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True, frame=None):
     """Oracle (C restatement, OpenMP over points) on a strided sub-lattice of the SAME frame, sized from a
-    short probe so that the timed run is about `target_s` seconds of CPU work."""
+    short probe so that the timed run is about `target_s` seconds of CPU work.  With `frame` (the HIP frame of the timed
+    region, numpy) the oracle's rays are also COMPARED with it: -> (baseline, parity)."""
     import numpy as np
     from oracle import oracle
     osc = oracle.OracleScene(scene_cpu)
@@ -97,9 +130,11 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
         ys, xs = np.meshgrid(np.arange(n) * step, np.arange(n) * step, indexing="ij")
         return np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.int32), step
 
+    last = {}
+
     def run(pix):
         t0 = time.perf_counter()
-        oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples, fine=fine)
+        last["ref"] = oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples, fine=fine)
         return time.perf_counter() - t0
 
     pix, _ = lattice(32)
@@ -109,9 +144,14 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True):
     n = max(32, n // 32 * 32)
     pix, step = lattice(n)
     dt = run(pix)
-    return {"value": pix.shape[0] / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+    base = {"value": pix.shape[0] / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"{pix.shape[0]} rays ({n}x{n} lattice, step {step}) of the same frame, {args.samples}+{args.samples} "
                       f"samples/ray, {dt:.1f} s of wall time, C oracle with OpenMP over points on {os.cpu_count()} hardware threads"}
+    parity = None
+    if frame is not None:
+        parity = frame_parity(frame, oracle, osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples, fine, last["ref"])
+        parity["sample"] = f"the {pix.shape[0]} rays of the cpu_baseline lattice ({n}x{n}, step {step}) of the timed {args.res}x{args.res} frame"
+    return base, parity
 
 
 def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1, with_kernel=False):
@@ -139,7 +179,7 @@ def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1, wi
     return dt * 1e3, rows.value / steps
 
 
-def time_configs4(L, ops, torch, dev, sd, mode):
+def time_configs4(L, ops, torch, dev, sd, mode, with_parity=True):
     """BASELINE configs[4] at FULL size — 4096 x 4096 rays, 10 source views of 4096^2, 128 flat samples per ray (no fine pass),
     dense mask, random weights: the roofline-measurement config.  One timed step (about 1.3e10 rows), the rows
     kernel's launch times taken inside the library like the headline's."""
@@ -163,10 +203,36 @@ def time_configs4(L, ops, torch, dev, sd, mode):
     achieved = rows.value * L.kpn_flops_per_row() / max(1e-9, ms.value * 1e-3) / 1e12
     peak = rows_peak_tflops(mode)
     valid = rows.value / (views * res * res * samples)
+    parity = None
+    if with_parity:   # 1,024 rays of this very frame against the oracle (a 32 x 32 lattice over the 4096^2 target)
+        try:
+            import numpy as np
+            from oracle import oracle
+            ys, xs = np.meshgrid(np.arange(32) * 128 + 64, np.arange(32) * 128 + 64, indexing="ij")
+            pix = np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.int32)
+            scene_cpu = to_device(scene, "cpu")
+            osc, wflat = oracle.OracleScene(scene_cpu), oracle.flat_weights(sd)
+            ref = oracle.render_rays(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, samples, samples, fine=False)
+            px, py = torch.from_numpy(pix[:, 0]).long().to(dev), torch.from_numpy(pix[:, 1]).long().to(dev)
+            frame = {"tex_fg": out["tex_fg"][0][:, py, px].cpu().numpy(), "alpha": out["alpha"][0][py, px].cpu().numpy()}
+            keys = ("tex_fg", "alpha")
+            got = {"tex_fg": frame["tex_fg"].T, "alpha": frame["alpha"]}
+            from tests import parity_gate
+            try:
+                rep = parity_gate.check_rays(got, ref, lambda: oracle.render_envelope(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, samples, samples, fine=False, ref=ref),
+                                             keys=keys, max_widened_fraction=0.01, what="configs[4] subset")
+                parity = {"rays": int(pix.shape[0]), "max_abs_rgb": rep["max_err"]["tex_fg"], "max_abs_alpha": rep["max_err"]["alpha"],
+                          "rays_above_1e-4": rep["above_bar"], "widened": len(rep["widened"]), "unexplained": 0, "ok": True}
+            except AssertionError as e:
+                parity = {"rays": int(pix.shape[0]), "ok": False, "error": str(e)[:400]}
+            parity["sample"] = "1,024 rays (32 x 32 lattice, step 128) of this 4096 x 4096 frame vs the C oracle, V = 10, 128 flat samples"
+            del scene_cpu, osc
+        except Exception as e:  # noqa: BLE001
+            parity = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     r = {"workload": "configs[4]: 4096x4096 rays, 10 source views 4096x4096, 128 flat samples/ray, dense mask, random weights; one step, no warm-up",
          "ms_per_step": dt * 1e3, "rays_per_sec": res * res / dt, "sampled_points_per_sec": res * res * samples / dt,
          "fully_evaluated_points_per_sec": res * res * samples * valid / dt, "valid_fraction_of_field_evaluations": valid,
-         "valid_rows": rows.value, "render_workspace_bytes": plan.nbytes, "mean_alpha": float(out["alpha"].mean()), "setup_s": t_setup,
+         "valid_rows": rows.value, "render_workspace_bytes": plan.nbytes, "mean_alpha": float(out["alpha"].mean()), "setup_s": t_setup, "parity": parity,
          "roofline": {"kernel": ROWS_KERNEL[mode], "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                       "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value), "kernel_time_share": ms.value * 1e-3 / dt}}
     del plan, ps, scene, out
@@ -260,7 +326,7 @@ def main():
 
     from keypointnerf_amd import lib as kl
     from keypointnerf_amd import ops
-    from keypointnerf_amd.parallel import FrameGatherer, band_of_rank, gather_frames_to_root, orbit_target_camera
+    from keypointnerf_amd.parallel import FrameGatherer, orbit_target_camera, rows_of_rank
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
 
     if args.no_coarse_reuse:
@@ -281,10 +347,11 @@ def main():
     ref_evals_per_ray = args.samples * (3 if fine else 1)          # the reference: Sc coarse + (Sc + Sf) fine
     evals_per_ray = args.samples * (2 if fine and not args.no_coarse_reuse else (3 if fine else 1))   # performed here
     strong = world > 1 and args.scaling == "strong"
-    y0, nrows = band_of_rank(res, rank, world) if strong else (0, res)
+    # strong: row y of the frame -> rank y mod world (interleaved: every rank gets the same share of the subject)
+    y0, step_y, nrows = rows_of_rank(res, rank, world) if strong else (0, 0, res)
     if strong and res % world:
         sys.exit("bench.py: --scaling strong needs the frame height to be a multiple of the rank count (equal bands gather into one frame)")
-    plan = ops.RenderPlan(ps, (0, y0, 1, res, nrows), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
+    plan = ops.RenderPlan(ps, (0, y0, 1, res, nrows, step_y), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
     gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     gatherer = FrameGatherer(world, rank, (3, nrows, res), device=gdev) if world > 1 else None
 
@@ -316,6 +383,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the frame of the last timed step, for the comparison with the oracle further down (world 1: rank 0's own camera)
+    frame_np = {k: v[0].cpu().numpy() for k, v in out.items() if k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")} if (world == 1 and rank == 0) else None
     gather_ms = None
     if world > 1:                             # the exchange alone (after the timed region): one synchronous round, averaged
         img = out["tex_fg_fine" if fine else "tex_fg"][0]
@@ -385,7 +454,10 @@ def main():
                        "fully_evaluated_points_per_sec": value * evals_per_ray * valid_frac,
                        "render_workspace_bytes": plan.nbytes, "scene_workspace_bytes": ps.ws.numel() * 4,
                        "peak_device_bytes_allocated": peak_alloc,
-                       "mean_alpha_fine": alpha_mean, "parallelism": (f"one frame split into {world} bands of rows" if strong else f"frames sharded over {world} rank(s)") + ", one process per GPU"
+                       # batches of rows the fp32-range kernels evaluated again (range guard of the two-fp16-piece kernels): 0 = the
+                       # whole run stayed on the default kernels
+                       "range_guard_batches_redone": ops.range_guard_count(), "range_guard": bool(L.kpn_get_range_guard()),
+                       "mean_alpha_fine": alpha_mean, "parallelism": (f"one frame, rows dealt round-robin to {world} ranks (row y -> rank y mod {world}), de-interleaved on rank 0" if strong else f"frames sharded over {world} rank(s)") + ", one process per GPU"
                                       + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
                        "dist_world_size": (dist.get_world_size() if world > 1 else 1),
                        "dist_backend": (args.dist_backend if world > 1 else None),
@@ -453,7 +525,9 @@ def main():
                     sec["configs4_full"] = {"error": f"{type(e).__name__}: {e}"}
             line["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            port = cpu_baseline(args, scene_cpu, sd, fine=fine)
+            port, parity = cpu_baseline(args, scene_cpu, sd, fine=fine, frame=frame_np)
+            # the timed frame itself, compared with the oracle on the rays the CPU baseline renders anyway
+            line["parity"] = parity
             rj = os.path.join(ROOT, "profiles", "reference_cpu_pytorch.json")
             if os.path.exists(rj):
                 # The headline CPU baseline is the UNMODIFIED reference (PyTorch CPU, src/model.py) on a configs[1] tile, timed where

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KPN_ABI_VERSION 1
+#define KPN_ABI_VERSION 2
 #define KPN_N_KPT 24      /* configs/zju.json:44 sp_args.n_kpt */
 #define KPN_MAX_VIEWS 16
 
@@ -164,8 +164,8 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
  * fp32 accumulation and the same parity bar against the reference goldens:
  *   3 = v_mfma_f32_32x32x16_f16 with every fp32 operand carried as two fp16 pieces (x - fp16(x) is formed exactly by one
  *       v_fma_mix_f32) and four products per term set; two 32-point tiles per wavefront, one wavefront per SIMD
- *       (k_geo_rows_f2).  The default.  Operands must stay within fp16's range: a pre-activation beyond 454 (natural units)
- *       or a packed weight beyond 65504 makes the row NaN (never silently wrong); kpn_packed_f16_range_check counts such weights.
+ *       (k_geo_rows_f2).  The default.  Operands must stay within fp16's range (a pre-activation beyond 454 in natural units,
+ *       a packed weight or a feature-map value beyond 65504 is not representable): the RANGE GUARD below sees to that.
  *   2 = v_mfma_f32_32x32x16_bf16, three bf16 pieces, six products (k_geo_rows_h2): the same structure in fp32's exponent range.
  *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands, k_geo_rows).
  *   (1, an earlier one-tile-per-wavefront kernel, is refused: not part of the shipped library.)
@@ -178,9 +178,24 @@ int kpn_get_geo_rows_mode(void);
  * v_mfma_f32_32x32x2_f32 (k_fuse_color).  Process-wide; initial value from the environment variable KPN_FUSE_MODE. */
 int kpn_set_fuse_mode(int32_t mode);
 int kpn_get_fuse_mode(void);
-/* *beyond = number of packed weights that fp16 cannot hold (0 = rows mode 3 / fuse mode 1 are usable with these weights).
- * Reads four floats back from the device and synchronises `stream`. */
+/* *beyond = number of packed weights that fp16 cannot hold (0 = rows mode 3 / fuse mode 1 run on these weights; otherwise the
+ * range guard routes every pass to the fp32-range kernels).  Reads four floats back from the device and synchronises `stream`. */
 int kpn_packed_f16_range_check(const float* packed_weights_dev, void* stream, int32_t* beyond);
+/* RANGE GUARD of the two-fp16-piece kernels (rows mode 3, fuse mode 1) — on by default, no host synchronisation involved:
+ *   - what is known before a pass is tested ON THE DEVICE by the kernels themselves: the packers' count of weights beyond fp16's
+ *     range (above) and max |value| of the source images / feature maps, which kpn_scene_prepare records in the scene workspace;
+ *     when either is out of range the fp16 kernels return at once and the fp32-range kernels (rows mode 2, fuse mode 0),
+ *     launched behind them for every batch of rows, do the work;
+ *   - activations cannot be known before: an operand beyond fp16's range turns every accumulator it touches into a NaN, no
+ *     activation of these kernels turns a NaN back into a number, and the per-point kernel flags a batch in which a point's
+ *     [sdf, rad, rgb] is not finite; the fp32-range kernels then evaluate that batch again.
+ * Results are never NaN where the reference's are finite.  The cost when nothing is out of range: two launches per batch that
+ * return at once.  kpn_set_range_guard(0) (or the environment variable KPN_NO_RANGE_GUARD=1) switches it off for timing
+ * comparisons.  kpn_range_guard_count: number of batches the fp32-range kernels evaluated again on the current device since
+ * the library was loaded (0 = everything ran on the fp16 kernels); synchronises `stream`. */
+int kpn_set_range_guard(int32_t on);
+int kpn_get_range_guard(void);
+int kpn_range_guard_count(void* stream, int64_t* batches_host);
 
 /* KeypointNeRF.query (+ query_color + IBRRenderingHead), src/model.py:690-843,1239-1302, eval mode.
  * pts (N,3), view (N,3) -> out (N,5), valid (N).
@@ -210,6 +225,9 @@ typedef struct kpn_render_args {
     int32_t chunk_rays;         /* rays per internal pass (0 = default) */
     float* tex_fg; float* depth; float* alpha;
     float* tex_fg_fine; float* depth_fine; float* alpha_fine; float* sdf;
+    int32_t step_y;             /* 0: rows advance by `step` like the columns (the reference's grids); > 0: py = y0 + iy*step_y —
+                                 * one frame's rows dealt round-robin to the ranks of a render job (rank r of W: y0 = r,
+                                 * step_y = W), SURVEY 8(e) */
 } kpn_render_args;
 
 /* Note on the fine pass: z_fine = sort(cat(z_coarse, z_new)) (src/model.py:1076) repeats the coarse samples; their field

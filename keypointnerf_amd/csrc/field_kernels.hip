@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (!kpn_batch_gate(batch, sc, wp)) return;
     const int count = *count_ptr;
     const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
     int t0, t1;
@@ -227,164 +228,6 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_geo_rows with split-bf16 operands on v_mfma_f32_32x32x16_bf16 (kpn_mfma16_layer): same rows, same row scratch,
-// fp32-class arithmetic (every product term above 2^-24 relative is kept), about twice the matrix rate.
-// NOT PART OF THE SHIPPED LIBRARY since round 3: the kernel emits a wrong half-tile about once per 1e6-1e7 evaluations at
-// two waves per SIMD for a reason that was never isolated; k_geo_rows_h2 superseded it.  It is kept
-// for that investigation only and builds with -DKPN_WITH_MODE1 -DKPN_H2_LOG2ACT=0 (it reads the unfolded split-bf16 streams).
-#ifdef KPN_WITH_MODE1
-static_assert(!KPN_H2_LOG2ACT, "k_geo_rows_h reads split-bf16 streams without the folded activation scale");
-#ifndef KPN_GEOH_OCC
-#define KPN_GEOH_OCC 2
-#endif
-__global__ __launch_bounds__(256, KPN_GEOH_OCC) void k_geo_rows_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
-                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                       int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
-    const int lane = threadIdx.x & 63;
-    const int p = lane & 31, h = lane >> 5;
-    const int count = *count_ptr;
-    const int ntiles = (count + KPN_TILE - 1) / KPN_TILE;
-    int t0, t1;
-    if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
-    const int nwork = (t1 - t0) * sc.V;
-    __shared__ __attribute__((aligned(16))) float bias_s[4][128];
-    {
-        const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
-        for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
-            const int sg = i >> 7, k = i & 127;
-            bias_s[sg][k] = k < kpn_seg_bfloats(segs[sg]) ? wp[kpn_seg_boff(segs[sg]) + k] : 0.0f;
-        }
-    }
-    __syncthreads();
-#ifdef KPN_DBG_STATIC   // bisection of the 2-waves-per-SIMD failure: no ticket atomics
-    for (int wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < nwork; wi += (gridDim.x * blockDim.x) >> 6) {
-#else
-    for (;;) {
-        int wi = 0;
-        if (lane == 0) wi = atomicAdd(tickets + 0, 1);
-        wi = __shfl(wi, 0);
-        if (wi >= nwork) break;
-#endif
-        const int tr = wi / sc.V, v = wi - tr * sc.V;
-        int ci = (t0 + tr) * KPN_TILE + p;
-        if (ci >= count) ci = count - 1;
-        const int64_t n = list[ci];
-        float P[3], D[3];
-        kpn_get_point(ps, n, P, D);
-        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-        const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
-        float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
-        if (!((sc.keep >> v) & 1u)) {
-            float4 rec0, rec1;
-            kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) dst[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
-            dst[8 * 64] = rec0;
-            dst[9 * 64] = rec1;
-            continue;
-        }
-        // ---- layers1.0 ----
-        kpn_f32x16 a0[4];
-        {
-            const float* E = tb + KPN_TBL_EXT;
-            const float cx = RADD(kpn_dot3(P[0], P[1], P[2], E[0], E[1], E[2]), E[3]);
-            const float cy = RADD(kpn_dot3(P[0], P[1], P[2], E[4], E[5], E[6]), E[7]);
-            const float cz = RADD(kpn_dot3(P[0], P[1], P[2], E[8], E[9], E[10]), E[11]);
-            const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
-            kpn_load_bias<4>(bias_s[0], h, a0);
-            kpn_mfma16_layer<12, 4>(wp + kpn_hseg_off(HSEG_G1_0A), lane, [&](auto gi, float (&x)[8]) {
-                constexpr int j = decltype(gi)::value;
-                const float dx = RSUB(cx, kc[j * 3 + 0]), dy = RSUB(cy, kc[j * 3 + 1]), dz = RSUB(cz, kc[j * 3 + 2]);
-                const float d2 = RADD(RADD(RMUL(dx, dx), RMUL(dy, dy)), RMUL(dz, dz));
-                const float w = kpn_fast_exp(-d2 / sc.two_sigma2);
-                float s1, c1;
-                kpn_sincos_pi(dz, s1, c1);
-                const float s2 = 2.0f * s1 * c1, c2 = 1.0f - 2.0f * s1 * s1;
-                const float s4 = 2.0f * s2 * c2, c4 = 1.0f - 2.0f * s2 * s2;
-                x[0] = dz * w;
-                x[1] = s1 * w; x[2] = c1 * w;
-                x[3] = s2 * w; x[4] = c2 * w;
-                x[5] = s4 * w; x[6] = c4 * w;
-                x[7] = 0.0f;
-#ifdef KPN_DBG_NOPE
-                x[0] = 0.01f * (float)j; x[1] = 0.02f; x[2] = -0.03f; x[3] = 0.04f * cz; x[4] = 0.05f; x[5] = -0.06f; x[6] = 0.07f;
-#endif
-            }, a0);
-            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g0h, sc.g0w);
-            const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64;
-            kpn_mfma16_layer<4, 4>(wp + kpn_hseg_off(HSEG_G1_0B), lane, [&](auto gi, float (&x)[8]) {
-                constexpr int g = decltype(gi)::value;
-#if defined(KPN_DBG_NOGATHER) || defined(KPN_DBG_NOGEO0)
-                const float4 f0 = make_float4(0.1f, -0.2f, 0.3f, 0.05f * (float)g), f1 = make_float4(-0.1f, 0.2f, 0.15f, -0.05f * (float)h);
-                (void)g0; (void)tp;
-#else
-                const float4 f0 = kpn_tap4(g0, 64, 16 * g + 8 * h, tp), f1 = kpn_tap4(g0, 64, 16 * g + 8 * h + 4, tp);
-#endif
-                x[0] = f0.x; x[1] = f0.y; x[2] = f0.z; x[3] = f0.w; x[4] = f1.x; x[5] = f1.y; x[6] = f1.z; x[7] = f1.w;
-            }, a0);
-        }
-        // chained step s of a 128-vector: registers 8(s%2)..+7 of block s/2
-        kpn_f32x16 a1[4];
-        kpn_load_bias<4>(bias_s[1], h, a1);
-        kpn_mfma16_layer<8, 4>(wp + kpn_hseg_off(HSEG_G1_1), lane, [&](auto gi, float (&x)[8]) {
-            constexpr int s = decltype(gi)::value;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a0[s / 2][(s % 2) * 8 + i]);
-        }, a1);
-        kpn_f32x16 a2[4];
-        {
-            const kpn_taps tp = kpn_make_taps(q.xn, q.yn, sc.g1h, sc.g1w);
-#if defined(KPN_DBG_NOGATHER) || defined(KPN_DBG_NOGEO1)
-            const float4 f = make_float4(0.1f, -0.2f, 0.3f, 0.05f);
-            (void)tp;
-#else
-            const float4 f = kpn_tap4(sc.geo1 + (size_t)v * sc.g1h * sc.g1w * 8, 8, 4 * h, tp);
-#endif
-            kpn_load_bias<4>(bias_s[2], h, a2);
-            kpn_mfma16_layer<9, 4>(wp + kpn_hseg_off(HSEG_G1_2), lane, [&](auto gi, float (&x)[8]) {
-                constexpr int s = decltype(gi)::value;
-                if constexpr (s < 8) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a1[s / 2][(s % 2) * 8 + i]);
-                } else {
-                    x[0] = f.x; x[1] = f.y; x[2] = f.z; x[3] = f.w; x[4] = 0.0f; x[5] = 0.0f; x[6] = 0.0f; x[7] = 0.0f;
-                }
-            }, a2);
-        }
-        {
-            kpn_f32x16 acc[2];
-            float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
-            kpn_load_bias<2>(bias_s[3], h, acc);
-            kpn_mfma16_layer<8, 2>(wp + kpn_hseg_off(HSEG_G1_3), lane, [&](auto gi, float (&x)[8]) {
-                constexpr int s = decltype(gi)::value;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = kpn_softplus100(a2[s / 2][(s % 2) * 8 + i]);
-#ifndef KPN_DBG_NOREC
-                if constexpr (s == 1) kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
-#endif
-            }, acc);
-#ifdef KPN_DBG_EXPORT   // bisection: block 1 of the rows carries an earlier layer's accumulator instead of the result
-#if KPN_DBG_EXPORT == 0
-            acc[1] = a0[1];
-#elif KPN_DBG_EXPORT == 1
-            acc[1] = a1[1];
-#else
-            acc[1] = a2[1];
-#endif
-#endif
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd)
-                    dst[(b * 4 + qd) * 64] =
-                        make_float4(acc[b][4 * qd + 0], acc[b][4 * qd + 1], acc[b][4 * qd + 2], acc[b][4 * qd + 3]);
-            dst[8 * 64] = rec0;
-            dst[9 * 64] = rec1;
-        }
-    }
-}
-#endif  // KPN_WITH_MODE1
 
 // ---------------------------------------------------------------------------------------------
 // Per-view inputs of the IBR head for this lane's point (query_color, model.py:806-832), in two steps:
@@ -581,9 +424,11 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
     const int p = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (!kpn_batch_gate(batch, sc, wp)) return;
     const int count = *count_ptr;
     int t0, t1;
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;   // before the LDS staging
+    if (batch.cond == KPN_RUN_IF_UNSAFE && batch.redone != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(batch.redone, 1);
     const int ntiles = t1 - t0;
     const int V = sc.V;
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
@@ -649,7 +494,8 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // inside the visual hull of a trained density comes in runs along the rays, i.e. in whole tiles of the ray-ordered
         // valid list — compress and the colour head (77 % of this kernel) are skipped.
         if (zero_skip && mode == 1 && ps.noise == nullptr) {
-            const unsigned long long live = __ballot(h == 0 && ci_raw < count && rad > 0.0f);
+            // (a NaN counts as live: it must reach the range guard at the end of the tile, not be skipped as "density 0")
+            const unsigned long long live = __ballot(h == 0 && ci_raw < count && !(rad <= 0.0f));
             if (live == 0ull) {
                 if (h == 0 && ci_raw < count) {
                     float* o = out + n * 5;
@@ -801,6 +647,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             head(gv, iv);
         }
         KPN_FUSE_STAMP(5);
+        const float r0 = c0 / lden, r1 = c1 / lden, r2 = c2 / lden;
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;
             if (mode == 1) {  // eval_func with mask = 1 (model.py:981-996)
@@ -808,7 +655,14 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
                 o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw;
             }
             else { o[0] = sdf_raw; o[1] = rad; }
-            o[2] = c0 / lden; o[3] = c1 / lden; o[4] = c2 / lden;
+            o[2] = r0; o[3] = r1; o[4] = r2;
+        }
+        // The range guard (kpn_field_shared.h): an operand of this kernel or of the rows kernel beyond fp16's range has become a
+        // NaN by now (looked for BEFORE the relu above, which would drop it).  One flag per batch; the fp32-range kernels
+        // launched behind this one evaluate the batch again when it is set.
+        if (batch.bad != nullptr && batch.cond != KPN_RUN_IF_UNSAFE) {
+            const float chk = fabsf(sdf_raw) + fabsf(rad) + fabsf(r0) + fabsf(r1) + fabsf(r2);
+            if (__ballot(h == 0 && ci_raw < count && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
         }
     }
 }

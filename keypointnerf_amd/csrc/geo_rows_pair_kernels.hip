@@ -108,22 +108,28 @@ inline kpn_f32x16 kpn_sc_bf16x3::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) {
 inline kpn_f32x16 kpn_sc_f16x2::mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c) { return kpn_mfma_f16(a, b, c); }
 #endif
 
-// Softplus(beta 100, threshold 20) in LOG2 UNITS (KPN_H2_LOG2ACT, kpn_common.h; the default): the packer folds 100 log2(e)
-// into the weights and biases of the layer that PRODUCES a pre-activation and ln(2)/100 into the weights of the layer that
-// CONSUMES the activation (kpn_hseg_factor), so that the accumulators hold u = 100 log2(e) x and the next layer wants
-// y' = 100 log2(e) softplus(x) = log2(1 + 2^u): v_exp_f32, +1, v_log_f32 and nothing else.  The reference's threshold branch
-// (x if 100 x > 20, src/utils.py:523-524) is max(u, .): beyond the threshold 1 + 2^u = 2^u in fp32 and below it the two
-// differ by less than an ulp; the clamp at 126 keeps 2^u finite for any u (the max then returns u itself).
-// With KPN_H2_LOG2ACT=0 (A/B builds) the same blocks carry the two multiplications per value of the natural-unit form.
+// Softplus(beta 100, threshold 20) in LOG2 UNITS (kpn_common.h KPN_H2_LOG2ACT): the packer folds 100 log2(e) into the weights
+// and biases of the layer that PRODUCES a pre-activation and ln(2)/100 into the weights of the layer that CONSUMES the activation
+// (kpn_hseg_factor), so that the accumulators hold u = 100 log2(e) x and the next layer wants y' = 100 log2(e) softplus(x) =
+// log2(1 + 2^u), computed as
+//       max(u, 0) + log2(1 + 2^-|u|)
+// — v_exp_f32 with the -|.| source modifiers, +1, v_log_f32, v_max_f32, v_add_f32: as many instructions as the round-3 form
+// max(u, log2(1 + 2^min(u, 126))), no clamp (2^-|u| <= 1), and beyond the reference's threshold branch (x if 100 x > 20,
+// src/utils.py:523-524) the second term is below an ulp of u.  And it KEEPS a NaN: v_min_f32 / v_max_f32 return the numeric
+// operand when the other is a NaN, so the old form turned a NaN pre-activation — which is what an operand beyond fp16's range
+// makes of every accumulator it touches (h = inf, l = -inf, inf - inf) — into a finite 126; here 2^-|NaN| is a NaN and the sum
+// carries it to the stored row, where the per-point kernel's range guard finds it (kpn_field_shared.h kpn_batch).
 
 // ---- staged production of one operand pair (two fp32 values -> three bf16 pieces each = one dword per piece), in SIX slices.
 // With ACT the values go through the activation first; issue slots per slice (transcendental = 2): 6 6 5 4 4 2
-//   0: read u0 u1, clamp both, exp 0     1: exp 1, 1 + e0, 1 + e1, log 0     2: log 1, max 0, max 1, hi pieces
+//   0: read u0 u1, exp 0, exp 1          1: max 0, 1 + e0, 1 + e1, log 0     2: log 1, max 1, add 0, add 1, hi pieces
 //   3: unpack hi 0/1, residual 0/1       4: mid pieces, unpack 0/1, residual 0   5: residual 1, lo pieces
 // Without ACT: 0: x0 = v0()   1: x1 = v1()   2: hi pieces   3..5 as above.
 // fp16 double split (kpn_sc_f16x2), FOUR slices, issue slots 6 6 5 3 (measured: a pair's 4 MFMAs + these slices run at 32.1
 // cycles per MFMA, scripts/f16_split_probe.hip):
-//   0, 1: as above     2: log 1, max 0, max 1, hi pieces (v_cvt_pk_f16_f32)     3: x0 - h0, x1 - h1 (v_fma_mix_f32), lo pieces
+//   0, 1: as above     2: log 1, max 1, add 0, add 1, hi pieces (v_cvt_pk_f16_f32)     3: x0 - h0, x1 - h1 (v_fma_mix_f32), lo pieces
+// (issue slots 6 5 6 3).  A transcendental's result is never read by the next VALU instruction: another instruction or an MFMA
+// always sits between.
 struct kpn_h2_pair { float x0, x1, e0, e1; uint32_t pk; };
 template <class SC, bool ACT, int Q, int J, class V0, class V1>
 __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC::NP], V0&& v0, V1&& v1) {
@@ -131,12 +137,12 @@ __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC
     if constexpr (F16 && Q == 2) {
         if constexpr (ACT) {
 #ifndef KPN_SIMT_EMU
-            static_assert(KPN_H2_LOG2ACT, "the fp16 scheme carries the activation in log2 units");
-            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3\n\tv_cvt_pk_f16_f32 %4, %0, %1"
+            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %1, 0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_cvt_pk_f16_f32 %4, %0, %1"
                          : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
 #else
             p.e1 = kpn_log2(p.e1);
-            p.x0 = fmaxf(p.x0, p.e0); p.x1 = fmaxf(p.x1, p.e1);
+            p.x1 = fmaxf(p.x1, 0.0f);
+            p.x0 = p.x0 + p.e0; p.x1 = p.x1 + p.e1;
             p.pk = kpn_emu_cvt_pk_f16(p.x0, p.x1);
 #endif
         } else {
@@ -161,49 +167,31 @@ __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC
         if constexpr (ACT) {
             const float a0 = v0(), a1 = v1();             // two accumulator elements (AGPRs)
 #ifndef KPN_SIMT_EMU
-#if KPN_H2_LOG2ACT
             asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\t"
-                         "v_min_f32 %2, 0x42fc0000, %0\n\tv_min_f32 %3, 0x42fc0000, %1\n\tv_exp_f32 %2, %2"
+                         "v_exp_f32 %2, -|%0|\n\tv_exp_f32 %3, -|%1|"
                          : "=&v"(p.x0), "=&v"(p.x1), "=&v"(p.e0), "=&v"(p.e1) : "a"(a0), "a"(a1));
-#else
-            asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\t"
-                         "v_mul_f32 %2, 0x431044fe, %0\n\tv_mul_f32 %3, 0x431044fe, %1\n\t"
-                         "v_min_f32 %2, 0x42fc0000, %2\n\tv_min_f32 %3, 0x42fc0000, %3\n\tv_exp_f32 %2, %2"
-                         : "=&v"(p.x0), "=&v"(p.x1), "=&v"(p.e0), "=&v"(p.e1) : "a"(a0), "a"(a1));
-#endif
 #else
             p.x0 = a0; p.x1 = a1;
-            const float s = KPN_H2_LOG2ACT ? 1.0f : KPN_H2_ACT_SCALE;
-            p.e0 = fminf(p.x0 * s, 126.0f); p.e1 = fminf(p.x1 * s, 126.0f);
-            p.e0 = kpn_exp2(p.e0);
+            p.e0 = kpn_exp2(-fabsf(p.x0)); p.e1 = kpn_exp2(-fabsf(p.x1));
 #endif
         } else { p.x0 = v0(); KPN_H2_USE(p.x0); }
     } else if constexpr (Q == 1) {
         if constexpr (ACT) {
 #ifndef KPN_SIMT_EMU
-            asm volatile("v_exp_f32 %1, %1\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_log_f32 %0, %0" : "+v"(p.e0), "+v"(p.e1));
+            asm volatile("v_max_f32 %2, 0, %2\n\tv_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_log_f32 %0, %0" : "+v"(p.e0), "+v"(p.e1), "+v"(p.x0));
 #else
-            p.e1 = kpn_exp2(p.e1); p.e0 = 1.0f + p.e0; p.e1 = 1.0f + p.e1; p.e0 = kpn_log2(p.e0);
+            p.x0 = fmaxf(p.x0, 0.0f); p.e0 = 1.0f + p.e0; p.e1 = 1.0f + p.e1; p.e0 = kpn_log2(p.e0);
 #endif
         } else { p.x1 = v1(); KPN_H2_USE(p.x1); }
     } else if constexpr (Q == 2) {
         if constexpr (ACT) {
 #ifndef KPN_SIMT_EMU
-#ifdef KPN_ABLATE_ACT   // timing experiment (wrong results): the activation's instructions without its effect
-            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %2, %2, %2\n\tv_max_f32 %3, %3, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
+            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %1, 0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
                          : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
-#elif KPN_H2_LOG2ACT
-            asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
-                         : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
-#else
-            asm volatile("v_log_f32 %3, %3\n\tv_mul_f32 %2, 0x3be32166, %2\n\tv_max_f32 %0, %0, %2\n\t"
-                         "v_mul_f32 %3, 0x3be32166, %3\n\tv_max_f32 %1, %1, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %1"
-                         : "+v"(p.x0), "+v"(p.x1), "+v"(p.e0), "+v"(p.e1), "=&v"(p.pk));
-#endif
 #else
             p.e1 = kpn_log2(p.e1);
-            const float s = KPN_H2_LOG2ACT ? 1.0f : KPN_H2_ACT_UNSCALE;
-            p.x0 = fmaxf(p.x0, p.e0 * s); p.x1 = fmaxf(p.x1, p.e1 * s);
+            p.x1 = fmaxf(p.x1, 0.0f);
+            p.x0 = p.x0 + p.e0; p.x1 = p.x1 + p.e1;
             p.pk = kpn_emu_cvt_pk(p.x0, p.x1);
 #endif
         } else {
@@ -397,6 +385,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
 #pragma unroll
     for (int i = 0; i < KPN_H2_PAD; ++i) asm volatile("s_nop 0");
 #endif
+    if (!kpn_batch_gate(batch, sc, wp)) return;            // the range guard (kpn_field_shared.h): wave-uniform, before anything else
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int count = *count_ptr;

@@ -7,20 +7,20 @@
 #include "kpn_field_shared.h"
 #include "geo_rows_pair_kernels.hip"
 
-// not part of the C ABI: called by run_field (kpn_api.hip) for kpn_set_geo_rows_mode(2) and (3)
+// not part of the C ABI: called by run_field (kpn_api.hip) for rows modes 2 and 3
 extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_geo_rows_pair(
     int mode, int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp, const int* list, const int* count,
-    int* tickets, float* xscr, int batch_index, int tiles_cap) {
+    int* tickets, float* xscr, const kpn_batch* batch) {
     if (mode == 3)
-        KPN_LAUNCH(k_geo_rows_f2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, kpn_batch{batch_index, tiles_cap});
+        KPN_LAUNCH(k_geo_rows_f2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, *batch);
     else
-        KPN_LAUNCH(k_geo_rows_h2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, kpn_batch{batch_index, tiles_cap});
+        KPN_LAUNCH(k_geo_rows_h2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, *batch);
 }
 // the gather records of the same batch (the pair-tile kernels do not write them)
 extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_row_records(
     int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const int* list, const int* count, float* xscr,
-    int batch_index, int tiles_cap) {
-    KPN_LAUNCH(k_row_records, dim3(blocks), dim3(256), stream, *sc, *ps, list, count, xscr, kpn_batch{batch_index, tiles_cap});
+    const kpn_batch* batch) {
+    KPN_LAUNCH(k_row_records, dim3(blocks), dim3(256), stream, *sc, *ps, list, count, xscr, *batch);
 }
 
 #ifdef KPN_H2_TIMING

@@ -14,14 +14,13 @@
 // kernels (ray_kernels.hip / field_kernels.hip)
 #include "ray_kernels.hip"
 #include "field_kernels.hip"
-#include "fuse_split_kernels.hip"
 #ifdef KPN_SIMT_EMU
 #include "geo_rows_pair_kernels.hip"   // the device build compiles this kernel as its own translation unit (geo_rows_pair_tu.hip)
 #else
 extern "C" void kpn_internal_launch_row_records(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const int* list,
-                                                const int* count, float* xscr, int batch_index, int tiles_cap);
+                                                const int* count, float* xscr, const kpn_batch* batch);
 extern "C" void kpn_internal_launch_geo_rows_pair(int mode, int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
-                                                  const int* list, const int* count, int* tickets, float* xscr, int batch_index, int tiles_cap);
+                                                  const int* list, const int* count, int* tickets, float* xscr, const kpn_batch* batch);
 #endif
 #include "field_bwd_kernels.hip"
 #include "fuse_bwd_kernels.hip"
@@ -586,7 +585,7 @@ extern "C" int kpn_pack_weights_device(const float* plain_dev, float* packed_dev
 // ---------------------------------------------------------------------------------------------
 // scene
 namespace {
-struct SceneLayout { size_t table, rgbm, geo0, geo1, tex, total; };  // float offsets
+struct SceneLayout { size_t table, rgbm, geo0, geo1, tex, flags, total; };  // float offsets
 SceneLayout scene_layout(const kpn_scene_desc* d) {
     SceneLayout L;
     size_t o = 0;
@@ -595,6 +594,7 @@ SceneLayout scene_layout(const kpn_scene_desc* d) {
     L.geo0 = o; o += align_up((size_t)d->n_views * d->geo0_h * d->geo0_w * 64, 64);
     L.geo1 = o; o += align_up((size_t)d->n_views * d->geo1_h * d->geo1_w * 8, 64);
     L.tex = o; o += align_up((size_t)d->n_views * d->tex_h * d->tex_w * 8, 64);
+    L.flags = o; o += align_up((size_t)KPN_SCENE_FLAG_FLOATS, 64);   // [0] = max |value| of the images and maps (kpn_common.h)
     L.total = o;
     return L;
 }
@@ -619,6 +619,7 @@ kpn_scene_dev scene_dev(const kpn_scene_desc* d, const void* ws) {
     s.two_sigma2 = (float)(2.0 * ((double)d->sigma * (double)d->sigma));  // spatial.py:114
     s.keep = 0xFFFFFFFFu;
     s.table = base + L.table; s.rgbm = base + L.rgbm; s.geo0 = base + L.geo0; s.geo1 = base + L.geo1; s.tex = base + L.tex;
+    s.flags = base + L.flags;
     return s;
 }
 }  // namespace
@@ -634,14 +635,15 @@ extern "C" int kpn_scene_prepare(const kpn_scene_desc* d, void* scene_ws, void* 
     const SceneLayout L = scene_layout(d);
     float* base = static_cast<float*>(scene_ws);
     const int V = d->n_views;
-    KPN_LAUNCH(k_scene_table, dim3(1), dim3(64), stream, V, d->KRT, d->extrin, d->kpt3d, base + L.table);
+    float* flags = base + L.flags;   // zeroed by k_scene_table (first on the stream), raised by the copies behind it
+    KPN_LAUNCH(k_scene_table, dim3(1), dim3(64), stream, V, d->KRT, d->extrin, d->kpt3d, base + L.table, flags);
     const int64_t HW = (int64_t)d->src_h * d->src_w;
     KPN_LAUNCH(k_pack_rgbm, grid1d(V * HW, 256), dim3(256), stream, (int64_t)(V * HW), HW, d->img,
-               d->disable_fg_mask ? (const uint8_t*)nullptr : d->fg_mask, base + L.rgbm);
+               d->disable_fg_mask ? (const uint8_t*)nullptr : d->fg_mask, base + L.rgbm, flags);
     const int64_t hw0 = (int64_t)d->geo0_h * d->geo0_w, hw1 = (int64_t)d->geo1_h * d->geo1_w, hwt = (int64_t)d->tex_h * d->tex_w;
-    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hw0 * 64, 256), dim3(256), stream, (int64_t)(V * hw0 * 64), 64, hw0, d->geo0, base + L.geo0);
-    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hw1 * 8, 256), dim3(256), stream, (int64_t)(V * hw1 * 8), 8, hw1, d->geo1, base + L.geo1);
-    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hwt * 8, 256), dim3(256), stream, (int64_t)(V * hwt * 8), 8, hwt, d->tex, base + L.tex);
+    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hw0 * 64, 256), dim3(256), stream, (int64_t)(V * hw0 * 64), 64, hw0, d->geo0, base + L.geo0, flags);
+    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hw1 * 8, 256), dim3(256), stream, (int64_t)(V * hw1 * 8), 8, hw1, d->geo1, base + L.geo1, flags);
+    KPN_LAUNCH(k_nchw_to_nhwc, grid1d(V * hwt * 8, 256), dim3(256), stream, (int64_t)(V * hwt * 8), 8, hwt, d->tex, base + L.tex, flags);
     return check_launch("kpn_scene_prepare");
 }
 
@@ -662,7 +664,7 @@ extern "C" int kpn_make_rays(const float* K, const float* RT, float znear, float
     KPN_REQUIRE(K && RT && bounds && dirs && cam_pos && near_o && far_o, "null pointer");
     KPN_REQUIRE(nx > 0 && ny > 0 && step > 0, "bad pixel grid");
     KPN_LAUNCH(k_make_rays, grid1d((int64_t)nx * ny, 256), dim3(256), stream, K, RT, znear, zfar, bounds, (int)x0, (int)y0,
-               (int)step, (int)nx, (int)ny, (const int*)nullptr, dirs, cam_pos, near_o, far_o);
+               (int)step, (int)step, (int)nx, (int)ny, (const int*)nullptr, dirs, cam_pos, near_o, far_o);
     return check_launch("kpn_make_rays");
 }
 
@@ -739,7 +741,9 @@ size_t row_scratch_cap_bytes() {
     }
     return g_row_scratch_cap;
 }
-const int kMaxBatches = 60;   // ticket pairs that fit the 512-byte counter block
+const int kMaxBatches = 60;
+const size_t kCounterBytes = 2048;   // (8 + 8 * kMaxBatches) ints
+static_assert((8 + 8 * kMaxBatches) * sizeof(int) <= kCounterBytes, "counter block");
 // passes of at most this many points always get their worst-case scratch (never batched): the backward entry points
 // read a pass's rows again and work in passes of kBwdChunk points
 #ifdef KPN_SIMT_EMU
@@ -747,11 +751,13 @@ const int64_t kUncappedPoints = 2048;
 #else
 const int64_t kUncappedPoints = 262144;
 #endif
-struct QueryLayout { size_t count, list, xscr, lat, list2, total; int tiles_cap, nbatch; };  // byte offsets
+struct QueryLayout { size_t count, list, xscr, total; int tiles_cap, nbatch; };  // byte offsets
 QueryLayout query_layout(int64_t N, int V) {
     QueryLayout L;
     size_t o = 0;
-    L.count = o; o += 1024;  // [0] valid count, [1 + 4b .. 3 + 4b] work tickets of batch b's persistent kernels, [4 + 4b] its live count
+    // [0] valid count; batch b owns ints [8 + 8b, 16 + 8b): [0] rows ticket, [1] per-point ticket, [4] / [5] the same for the
+    // fp32-range kernels launched behind them (range guard), [6] the batch's "non-finite result" flag
+    L.count = o; o += kCounterBytes;
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
     const size_t tile_bytes = (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4);
@@ -765,14 +771,8 @@ QueryLayout query_layout(int64_t N, int V) {
     L.tiles_cap = (int)cap;
     L.nbatch = (int)((ntiles + cap - 1) / cap);
     L.xscr = o; o += align_up(cap * tile_bytes, 256);
-    L.lat = o; o += align_up(cap * (size_t)(4 * 64 * sizeof(float4)), 256);   // compressed latent per tile (split colour path)
-    L.list2 = o; o += align_up(cap * (size_t)KPN_TILE * sizeof(int), 256);      // points of a batch with density > 0
     L.total = o;
     return L;
-}
-int fuse_split_mode() {   // 0: k_fuse_color (default); 1: k_pool_geo + k_color_head, an A/B knob read per call
-    const char* e = getenv("KPN_FUSE_SPLIT");
-    return e ? atoi(e) : 0;
 }
 int field_grid_blocks() {
     // persistent grid: 256 CUs x 2 blocks of 256 threads (launch_bounds(256,2) -> 8 waves per CU)
@@ -796,14 +796,14 @@ struct ProfState {
 static ProfState g_prof;
 #endif
 
+// Rows kernel of layers1 (kpn_set_geo_rows_mode):
 // 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, k_geo_rows)
-// 1: split-bf16 operands on v_mfma_f32_32x32x16_bf16, one tile per wave, two waves per SIMD (k_geo_rows_h): NOT in the
-//    shipped library (unexplained rare wrong tiles); investigation builds only (-DKPN_WITH_MODE1)
 // 2: three bf16 pieces per operand, six products, two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): fp32-class results
 //    (every product term above 2^-24 relative is kept) in fp32's exponent range
 // 3: two fp16 pieces per operand, four products, same kernel structure (k_geo_rows_f2): the default — the same accuracy class
-//    with 1.5x fewer MFMAs and a third of the split instructions; operands must stay within fp16's range (a pre-activation
-//    beyond 454 in natural units makes the row NaN, loudly; packed weights are checked: kpn_packed_f16_range_check)
+//    with 1.5x fewer MFMAs and a third of the split instructions; operands must stay within fp16's range, which the range guard
+//    below takes care of
+// (1 was the one-tile-per-wave split-bf16 kernel of round 1: not part of the library, scripts/mode1_investigation/)
 #ifndef KPN_DEFAULT_GEO_ROWS_MODE
 #define KPN_DEFAULT_GEO_ROWS_MODE 3
 #endif
@@ -819,10 +819,7 @@ int geo_rows_mode() {
     if (g_geo_rows_mode < 0) {
         const char* e = getenv("KPN_GEO_ROWS_MODE");
         g_geo_rows_mode = e ? atoi(e) : KPN_DEFAULT_GEO_ROWS_MODE;
-#ifndef KPN_WITH_MODE1
-        if (g_geo_rows_mode == 1) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
-#endif
-        if (g_geo_rows_mode < 0 || g_geo_rows_mode > 3) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
+        if (g_geo_rows_mode != 0 && g_geo_rows_mode != 2 && g_geo_rows_mode != 3) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
     }
     return g_geo_rows_mode;
 }
@@ -858,6 +855,61 @@ static inline int mask_points_per_thread(int64_t N) {
     while (ppt > 1 && N / (256 * (int64_t)ppt) < min_groups) ppt >>= 1;
     return ppt;
 }
+// ---- the range guard of the two-fp16-piece kernels (kpn_field_shared.h kpn_batch) ----
+// On (the default) whenever rows mode 3 or fuse mode 1 is selected: those kernels stand aside on the device when the weights or
+// the maps are beyond fp16's range, the per-point kernel flags a batch with a non-finite result, and the fp32-range kernels (rows
+// mode 2, or 0 if selected; fuse mode 0) launched behind them evaluate such a batch again — two launches per batch that return
+// at once otherwise.  KPN_NO_RANGE_GUARD=1 / kpn_set_range_guard(0): the round-3 behaviour (an operand beyond fp16's range makes
+// the point NaN), for timing comparisons.
+int g_range_guard = -1;
+int range_guard() {
+    if (g_range_guard < 0) { const char* e = getenv("KPN_NO_RANGE_GUARD"); g_range_guard = (e && atoi(e) != 0) ? 0 : 1; }
+    return g_range_guard;
+}
+// batches evaluated again by the fp32-range kernels since the library was loaded, per device (a device int the per-point kernel
+// of such a launch increments; read by kpn_range_guard_count)
+int* g_redone_dev[64] = {nullptr};
+int* redone_counter() {
+    int dev = 0;
+#ifndef KPN_SIMT_EMU
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+#endif
+    if (!g_redone_dev[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 64) != hipSuccess) return nullptr;
+#ifndef KPN_SIMT_EMU
+        if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+#else
+        memset(p, 0, 64);
+#endif
+        g_redone_dev[dev] = static_cast<int*>(p);
+    }
+    return g_redone_dev[dev];
+}
+
+void launch_rows(int rows_mode, const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, const int* list, const int* count,
+                 int* tickets, float* xscr, const kpn_batch& batch, void* stream) {
+    if (rows_mode >= 2) {
+#ifdef KPN_SIMT_EMU
+        if (rows_mode == 3) KPN_LAUNCH(k_geo_rows_f2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
+        else KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
+#else
+        kpn_internal_launch_geo_rows_pair(rows_mode, pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, &batch);
+#endif
+    } else {
+        KPN_LAUNCH(k_geo_rows, dim3(field_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
+    }
+}
+void launch_fuse(int fmode, const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, const int* list, const int* count,
+                 int* tickets, const float* xscr, int mode, int park_x, float* out, const kpn_batch& batch, int zero_skip, void* stream) {
+    const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 / 141 KB of weights sit in LDS
+    static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
+    if (fmode == 1)
+        KPN_LAUNCH(k_fuse_color_h, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
+    else
+        KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
+}
+
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
               uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0) {
     const QueryLayout L = query_layout(N, sc.V);
@@ -865,81 +917,56 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
-    hipMemsetAsync(count, 0, 256 * sizeof(int), (hipStream_t)stream);
+    hipMemsetAsync(count, 0, kCounterBytes, (hipStream_t)stream);
     const int ppt = mask_points_per_thread(N);
     KPN_LAUNCH(k_mask_compact, grid1d(N, 256 * ppt), dim3(256), stream, sc, ps, N, mode, lean, ppt, wp + kpn_scalar_off(), out, valid, list, count);
-    const int blocks = field_grid_blocks();
-    const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 KB of weights sit in LDS
-    static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
     if (keep_rows && L.nbatch > 1) return fail(KPN_EWORKSPACE, "a pass whose rows a backward call reads again must fit the row scratch");
+    const int rmode = geo_rows_mode(), fmode = out ? fuse_mode() : 0;
+    // which launches stand under the range guard: the two-fp16-piece ones; `redo`: the fp32-range pair behind them
+    const bool guard = range_guard() && out && (rmode == 3 || fmode == 1);
+    int* redone = guard ? redone_counter() : nullptr;
+    const int safe_rmode = rmode == 3 ? 2 : rmode;
+    // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going to read
+    // them again (keep_rows).  zero-density short path: render passes only (lean), never when a backward pass reads the rows again
+    const char* zs = getenv("KPN_NO_ZERO_SKIP");   // A/B knob, read per call
+    const int zero_skip = (lean && !keep_rows && !(zs && atoi(zs))) ? 1 : 0;
+    const int park_x = keep_rows ? 0 : 1;
     for (int b = 0; b < L.nbatch; ++b) {
-        const kpn_batch batch{b, L.tiles_cap};
-        int* tickets = count + 1 + 4 * b;
+        int* slots = count + 8 + 8 * b;
+        int* bad = guard ? slots + 6 : nullptr;
+        const kpn_batch b_rows{b, L.tiles_cap, (guard && rmode == 3) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr};
+        const kpn_batch b_rec{b, L.tiles_cap, KPN_RUN_ALWAYS, nullptr, nullptr};
+        const kpn_batch b_fuse{b, L.tiles_cap, (guard && fmode == 1) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr};
 #ifndef KPN_SIMT_EMU
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
 #endif
-        if (geo_rows_mode() >= 2)
-#ifdef KPN_SIMT_EMU
-        {
-            if (geo_rows_mode() == 3) KPN_LAUNCH(k_geo_rows_f2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
-            else KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
-        }
-#else
-            kpn_internal_launch_geo_rows_pair(geo_rows_mode(), pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, batch.index, batch.tiles_cap);
-#endif
-#ifdef KPN_WITH_MODE1
-        else if (geo_rows_mode() == 1)
-            KPN_LAUNCH(k_geo_rows_h, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
-#endif
-        else
-            KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets, xscr, batch);
-        const bool pair_rows = geo_rows_mode() >= 2;
+        launch_rows(rmode, sc, ps, wp, list, count, slots + 0, xscr, b_rows, stream);
 #ifndef KPN_SIMT_EMU
         if (prof) {
             (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], (hipStream_t)stream);
             (void)hipMemcpyAsync(g_prof.counts_host + g_prof.used, count, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
-            g_prof.batch[g_prof.used] = batch;
+            g_prof.batch[g_prof.used] = b_rows;
             g_prof.V = sc.V;
             ++g_prof.used;
         }
 #endif
-        if (pair_rows) {   // the colour head's gather records (the pair-tile rows kernels leave them to k_row_records)
+        if (rmode >= 2) {   // the colour head's gather records (the pair-tile rows kernels leave them to k_row_records)
 #ifdef KPN_SIMT_EMU
-            KPN_LAUNCH(k_row_records, dim3(8), dim3(256), stream, sc, ps, (const int*)list, (const int*)count, xscr, batch);
+            KPN_LAUNCH(k_row_records, dim3(8), dim3(256), stream, sc, ps, (const int*)list, (const int*)count, xscr, b_rec);
 #else
-            kpn_internal_launch_row_records(2048, stream, &sc, &ps, list, count, xscr, batch.index, batch.tiles_cap);
+            kpn_internal_launch_row_records(2048, stream, &sc, &ps, list, count, xscr, &b_rec);
 #endif
         }
-        // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going
-        // to read them again (keep_rows)
-        if (fuse_split_mode() >= 1 && out) {
-            float* lat = reinterpret_cast<float*>(base + L.lat);
-            const bool compact = fuse_split_mode() == 2 && lean && !keep_rows;   // render passes only
-            int* count2 = compact ? tickets + 3 : nullptr;
-            int* list2 = compact ? reinterpret_cast<int*>(base + L.list2) : nullptr;
-            // measured on the bench frame: one 512-thread workgroup per CU 53.7 ms, two 384-thread
-            // workgroups per CU (3 waves per SIMD) 54.6 ms, the fused kernel 52.3 ms
-            static const int pblocks = [] { const char* e = getenv("KPN_SPLIT_BLOCKS"); return e ? atoi(e) : fuse_grid_blocks(); }();
-            static const int pthreads = [] { const char* e = getenv("KPN_SPLIT_THREADS"); return e ? atoi(e) : 512; }();
-            KPN_LAUNCH(k_pool_geo, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                       (const float*)xscr, mode, lat, out, batch, count2, list2);
-            if (compact)
-                KPN_LAUNCH(k_color_head<true>, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                           (const float*)xscr, keep_rows ? 0 : 1, (const float*)lat, out, batch, (const int*)count2, (const int*)list2);
-            else
-                KPN_LAUNCH(k_color_head<false>, dim3(pblocks), dim3(pthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                           (const float*)xscr, keep_rows ? 0 : 1, (const float*)lat, out, batch, (const int*)nullptr, (const int*)nullptr);
-        } else {
-            // zero-density short path: render passes only (lean), never when a backward pass reads the rows again
-            const char* zs = getenv("KPN_NO_ZERO_SKIP");   // A/B knob, read per call
-            const int zero_skip = (lean && !keep_rows && !(zs && atoi(zs))) ? 1 : 0;
-            if (fuse_mode() == 1)
-                KPN_LAUNCH(k_fuse_color_h, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                           (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch, zero_skip);
-            else
-                KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, (const int*)list, (const int*)count, tickets,
-                           (const float*)xscr, mode, keep_rows ? 0 : 1, out, batch, zero_skip);
+        if (!out) continue;   // rows only (the backward entry points run their own per-point kernels)
+        launch_fuse(fmode, sc, ps, wp, list, count, slots, xscr, mode, park_x, out, b_fuse, zero_skip, stream);
+        if (guard) {
+            // The same batch again in fp32's exponent range, IF the kernels above stood aside or flagged it: the rows first (the
+            // per-point kernel has parked its x' vectors over them; the gather records are intact), then the per-point kernel.
+            const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr};
+            const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone};
+            launch_rows(safe_rmode, sc, ps, wp, list, count, slots + 4, xscr, r_rows, stream);
+            launch_fuse(0, sc, ps, wp, list, count, slots + 4, xscr, mode, park_x, out, r_fuse, zero_skip, stream);
         }
     }
     return check_launch("field query");
@@ -947,11 +974,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
 }  // namespace
 
 extern "C" int kpn_set_geo_rows_mode(int32_t mode) {
-#ifdef KPN_WITH_MODE1
-    KPN_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (fp32 MFMA), 1 (split-bf16, one tile per wave), 2 (three bf16 pieces) or 3 (two fp16 pieces)");
-#else
-    KPN_REQUIRE(mode == 0 || mode == 2 || mode == 3, "mode must be 0 (fp32 MFMA), 2 (three bf16 pieces) or 3 (two fp16 pieces); mode 1 is not part of this build");
-#endif
+    KPN_REQUIRE(mode == 0 || mode == 2 || mode == 3, "mode must be 0 (fp32 MFMA), 2 (three bf16 pieces) or 3 (two fp16 pieces); mode 1 is not part of the library");
     g_geo_rows_mode = mode;
     return KPN_OK;
 }
@@ -962,6 +985,25 @@ extern "C" int kpn_set_fuse_mode(int32_t mode) {
     return KPN_OK;
 }
 extern "C" int kpn_get_fuse_mode(void) { return fuse_mode(); }
+extern "C" int kpn_set_range_guard(int32_t on) { g_range_guard = on ? 1 : 0; return KPN_OK; }
+extern "C" int kpn_get_range_guard(void) { return range_guard(); }
+// Batches of (point, view) rows that the fp32-range kernels evaluated again on the current device since the library was loaded
+// (0 = every pass ran on the two-fp16-piece kernels).  Synchronises `stream`.
+extern "C" int kpn_range_guard_count(void* stream, int64_t* batches_host) {
+    KPN_REQUIRE(batches_host != nullptr, "null pointer");
+    *batches_host = 0;
+    int* c = redone_counter();
+    if (!c) return fail(KPN_ELAUNCH, "could not allocate the range guard's counter");
+    int v = 0;
+#ifndef KPN_SIMT_EMU
+    if (hipMemcpyAsync(&v, c, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(KPN_ELAUNCH, "could not read the range guard's counter");
+#else
+    (void)stream; v = *c;
+#endif
+    *batches_host = v;
+    return KPN_OK;
+}
 
 // Number of packed layers1 weights whose magnitude (after the folded activation scale) is beyond fp16's range, i.e. that rows
 // mode 3 cannot represent (use mode 2 or 0 for such weights).  Reads four floats back from the device: synchronises `stream`.
@@ -1329,7 +1371,7 @@ RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
 int check_render(const kpn_render_args* a) {
     KPN_REQUIRE(a != nullptr, "render args null");
     KPN_REQUIRE(a->K && a->RT && a->bounds, "null camera/bounds");
-    KPN_REQUIRE(a->nx > 0 && a->ny > 0 && a->step > 0, "bad pixel grid");
+    KPN_REQUIRE(a->nx > 0 && a->ny > 0 && a->step > 0 && a->step_y >= 0, "bad pixel grid");
     KPN_REQUIRE(a->n_coarse >= 3 && a->n_coarse <= 128, "sample_per_ray_c must be in [3,128]");
     KPN_REQUIRE(!a->fine || (a->n_fine >= 1 && a->n_fine <= 128), "sample_per_ray_f must be in [1,128]");
     KPN_REQUIRE((int64_t)a->nx * a->ny < (1ll << 31), "too many rays");
@@ -1383,7 +1425,7 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
     const int64_t R = (int64_t)a->nx * a->ny;
     const int Sc = a->n_coarse, Sf = a->fine ? a->n_fine : 0, Sfull = Sc + Sf;
     KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
-               (int)a->step, (int)a->nx, (int)a->ny, t ? (const int*)t->pix : (const int*)nullptr, F(L.dirs), F(L.cam_pos),
+               (int)a->step, (int)(a->step_y > 0 ? a->step_y : a->step), (int)a->nx, (int)a->ny, t ? (const int*)t->pix : (const int*)nullptr, F(L.dirs), F(L.cam_pos),
                F(L.nearv), F(L.farv));
     for (int64_t r0 = 0; r0 < R; r0 += L.chunk) {
         const int64_t n = (R - r0) < L.chunk ? (R - r0) : L.chunk;
@@ -1543,7 +1585,7 @@ int train_impl(const kpn_scene_desc* d, const void* scene_ws, const float* wp, c
     float* farv = state ? reinterpret_cast<float*>(sbase + S.farv) : F(L.farv);
     if (run_forward)
         KPN_LAUNCH(k_make_rays, grid1d(R, 256), dim3(256), stream, a->K, a->RT, a->znear, a->zfar, a->bounds, (int)a->x0, (int)a->y0,
-                   (int)a->step, (int)a->nx, (int)a->ny, (const int*)t->pix, dirs_all, cam_pos, nearv, farv);
+                   (int)a->step, (int)a->step, (int)a->nx, (int)a->ny, (const int*)t->pix, dirs_all, cam_pos, nearv, farv);
     const float std_ = t->rand_noise_std;
     int64_t ci = 0;
     for (int64_t r0 = 0; r0 < R; r0 += L.chunk, ++ci) {

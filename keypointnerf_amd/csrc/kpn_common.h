@@ -204,7 +204,17 @@ struct kpn_scene_dev {
     const float* geo0;
     const float* geo1;
     const float* tex;
+    // [0] = max |value| over the source images and the three feature maps (set by kpn_scene_prepare; NaN if one holds a NaN):
+    // the kernels that carry operands as two fp16 pieces stand aside when it is beyond fp16's range (kpn_f16_inputs_unsafe)
+    const float* flags;
 };
+// Operands of the two-fp16-piece kernels (k_geo_rows_f2, k_fuse_color_h) must stay within fp16's range.  What is known before a
+// pass — the packed weights (the packers count the ones beyond it: kpn_pack_flags_off()) and the maps (kpn_scene_prepare's
+// max |value|) — is tested here, on the device, by the kernels themselves: no host round trip.  Activations are not known before
+// the pass: a non-finite result is caught behind the kernels (kpn_batch::bad) and the batch evaluated again by the fp32-range
+// kernels (run_field, kpn_api.hip).
+#define KPN_F16_INPUT_LIMIT 60000.0f
+#define KPN_SCENE_FLAG_FLOATS 16
 
 // ---------------------------------------------------------------------------------------------
 // MFMA weight segments.  One segment = one Linear layer (or a column slice of one) streamed as the
@@ -352,6 +362,9 @@ constexpr int kpn_bh_off(int i) {
 // behind everything: [0] = number of fp16-stream weights whose magnitude is beyond fp16's range (as a float; 0 = usable)
 #define KPN_PACK_FLAG_FLOATS 4
 constexpr int kpn_pack_flags_off() { return kpn_bh_off(BH_COUNT); }
+__device__ __forceinline__ bool kpn_f16_inputs_unsafe(const kpn_scene_dev& sc, const float* __restrict__ wp) {
+    return wp[kpn_pack_flags_off()] != 0.0f || !(sc.flags[0] <= KPN_F16_INPUT_LIMIT);
+}
 constexpr int kpn_packed_floats() { return kpn_pack_flags_off() + KPN_PACK_FLAG_FLOATS; }
 // The split-bf16 streams carry the Softplus(beta = 100) of layers1 in log2 units (geo_rows_pair_kernels.hip, KPN_H2_LOG2ACT):
 // a layer whose OUTPUT goes through the activation is scaled by 100 log2(e) (weights here, biases when the kernel stages

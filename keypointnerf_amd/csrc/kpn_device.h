@@ -89,14 +89,14 @@ __device__ __forceinline__ float kpn_elu(float x) {
 #ifdef KPN_ABLATE_ELU  // timing experiment only: wrong results
     return x;
 #endif
-    // ELU(x) = median(x, e^x - 1, 0): for x > 0 the order is 0 < x <= e^x - 1, for x < 0 it is x <= e^x - 1 < 0 — one v_med3_f32
-    // instead of v_cmp + v_cndmask (and no VCC wait states); where rounding swaps the two near 0 they differ by < 1e-7.
+    // ELU(x) = x if x > 0 else e^x - 1 (torch.nn.ELU), selected by the SIGN BIT: v_ashrrev_i32 + v_bfi_b32 — no v_cmp / VCC wait
+    // states.  Round 3 used one v_med3_f32 (median(x, e^x - 1, 0)); a median drops NaNs (v_med3_f32 returns min3 when an input is a
+    // NaN, and min3 returns the numeric operand), so an overflowed fp16 operand of k_fuse_color_h — NaN in every accumulator it
+    // touches — came out of the next ELU as 0 and the point as a finite, wrong colour.  A select keeps the NaN (x = NaN: either
+    // branch is a NaN), so it reaches the per-point outputs, where the range guard looks for it (kpn_field_shared.h kpn_batch).
     const float t = kpn_fast_exp(x) - 1.0f;
-#ifndef KPN_SIMT_EMU
-    return __builtin_amdgcn_fmed3f(x, t, 0.0f);
-#else
-    return fmaxf(fminf(x, t), fminf(fmaxf(x, t), 0.0f));
-#endif
+    const int m = __float_as_int(x) >> 31;                          // all ones for a negative x
+    return __int_as_float((m & __float_as_int(t)) | (~m & __float_as_int(x)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,157 +422,6 @@ __device__ __forceinline__ void kpn_blayer(const float* __restrict__ wp, int lan
         }
         KPN_SCHED_BARRIER();
     });
-}
-
-// One Linear layer on v_mfma_f32_32x32x16_bf16 with split-bf16 operands (kpn_common.h HSEG_*): KS16 steps of 16 k.
-// in_fn(kpn_ic<s>, float (&x)[8]) produces the 8 fp32 values this lane supplies in step s; they are split into three
-// bf16 pieces on the fly; the weights arrive pre-split.  Six products per (step, output block) keep every term above
-// 2^-24 relative: fp32-class accuracy at (measured, clean loop) about twice the fp32-MFMA rate.
-#ifndef KPN_GUARD_NOPS
-#define KPN_GUARD_NOPS "s_nop 7"
-#endif
-// hipcc 7.2 under-protects v_mfma_f32_32x32x16_bf16: the software wait states it inserts between the instruction and
-// its neighbours are too few on the MI355X when two waves share a SIMD.  Established by experiment (scripts/
-// soak_determinism.py): (1) with the accumulators read by VALU code right after a layer's last MFMAs, about one tile in
-// 10^5 came out wrong, nondeterministically — an idle tail of 64 cycles before the accumulators are touched removes
-// it completely (result RAW); (2) with the scheduler free to interleave the activation / split VALU code among the
-// MFMAs, ~0.1 % of the points were wrong even with that tail (VALU-written operand registers feeding the next MFMAs,
-// dead operand registers recycled by a VALU write in the next slot).  kpn_mfma16_layer therefore fences every such
-// boundary by hand: phases kept apart by scheduling barriers, an arrival statement before the MFMAs (weights landed,
-// a few idle cycles after the last operand write), a guard after them (operands stay live, 8 idle cycles), and the tail.
-__device__ __forceinline__ void kpn_mfma16_arrive(kpn_bf16x8& a0, kpn_bf16x8& a1, kpn_bf16x8& a2, kpn_bf16x8& a3, kpn_bf16x8& a4,
-                                                  kpn_bf16x8& a5, kpn_bf16x8& b0, kpn_bf16x8& b1, kpn_bf16x8& b2) {
-#ifndef KPN_SIMT_EMU
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(b0), "+v"(b1), "+v"(b2));
-#else
-    (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5; (void)b0; (void)b1; (void)b2;
-#endif
-}
-// idle tail after a layer's last MFMAs, before anything reads the accumulators
-template <int NOB>
-__device__ __forceinline__ void kpn_mfma16_tail(kpn_f32x16 (&acc)[NOB]) {
-#ifndef KPN_SIMT_EMU
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[ob]));
-#else
-    (void)acc;
-#endif
-}
-#ifndef KPN_GUARD_NOPS
-#define KPN_GUARD_NOPS "s_nop 7"
-#endif
-// Explicit arrival of a half's weight registers ("s_waitcnt vmcnt(0)" tied to them) before its MFMAs: belt and braces
-// next to the compiler's own waitcnt insertion (see the note on phase separation in kpn_mfma16_layer).
-__device__ __forceinline__ void kpn_mfma16_arrive(kpn_bf16x8& a0, kpn_bf16x8& a1, kpn_bf16x8& a2, kpn_bf16x8& a3, kpn_bf16x8& a4,
-                                                  kpn_bf16x8& a5) {
-#ifndef KPN_SIMT_EMU
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
-#else
-    (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5;
-#endif
-}
-#ifndef KPN_GUARD_NOPS
-#define KPN_GUARD_NOPS "s_nop 7"
-#endif
-__device__ __forceinline__ void kpn_mfma16_guard(kpn_f32x16& acc0, kpn_f32x16& acc1, const kpn_bf16x8& a0, const kpn_bf16x8& a1,
-                                                 const kpn_bf16x8& a2, const kpn_bf16x8& a3, const kpn_bf16x8& a4, const kpn_bf16x8& a5,
-                                                 const kpn_bf16x8& b0, const kpn_bf16x8& b1, const kpn_bf16x8& b2) {
-#ifndef KPN_SIMT_EMU
-    asm volatile(KPN_GUARD_NOPS : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(b0), "v"(b1), "v"(b2));
-#else
-    (void)acc0; (void)acc1; (void)a0; (void)a1; (void)a2; (void)a3; (void)a4; (void)a5; (void)b0; (void)b1; (void)b2;
-#endif
-}
-template <int KS16, int NOB, bool SEPARATE = true, class InFn>
-__device__ __forceinline__ void kpn_mfma16_layer(const float* __restrict__ hseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
-    // software pipeline: the B pieces of step s+1 are produced (VALU: activation + split) while the MFMAs of step s
-    // issue; the A pieces are fetched in two halves of the output blocks so that the loads of one half fly while the
-    // other half's MFMAs issue (a full double buffer of 3*NOB dwordx4 does not fit the register file)
-    static_assert(NOB <= 4, "two halves of at most two output blocks");
-    constexpr int H0 = (NOB + 1) / 2, H1 = NOB - H0;
-    kpn_bf16x8 xp[2][3];
-    kpn_bf16x8 wa[3][H0], wb[3][H1 > 0 ? H1 : 1];
-    auto load_half = [&](int s, int ob0, int n, auto& w) {
-        const float* gp = hseg + (size_t)s * (3 * NOB * 64 * 4);
-#ifndef KPN_MFMA16_PLAIN
-        KPN_PIN_POINTER(gp);
-#endif
-        const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-            for (int k = 0; k < n; ++k) w[pc][k] = kpn_as_bf16x8(src[((ob0 + k) * 3 + pc) * 64]);
-    };
-    auto mfma_half = [&](int ob0, int n, auto& w, const kpn_bf16x8 (&x)[3]) {
-#pragma unroll
-        for (int k = 0; k < n; ++k) {
-            acc[ob0 + k] = KPN_MFMA16(w[0][k], x[0], acc[ob0 + k]);
-            acc[ob0 + k] = KPN_MFMA16(w[0][k], x[1], acc[ob0 + k]);
-            acc[ob0 + k] = KPN_MFMA16(w[1][k], x[0], acc[ob0 + k]);
-            acc[ob0 + k] = KPN_MFMA16(w[1][k], x[1], acc[ob0 + k]);
-            acc[ob0 + k] = KPN_MFMA16(w[0][k], x[2], acc[ob0 + k]);
-            acc[ob0 + k] = KPN_MFMA16(w[2][k], x[0], acc[ob0 + k]);
-        }
-    };
-    // The guard keeps a half's A and B operand registers live up to its last MFMA and then idles 8 cycles before any of
-    // them can be recycled (the compiler otherwise lets a VALU instruction overwrite a 4-VGPR MFMA source in the very
-    // next issue slot; cheap insurance: 16 of ~770 cycles per step).
-    auto arrive_half = [&](auto nn, auto& w, kpn_bf16x8 (&x)[3]) {
-#ifdef KPN_MFMA16_PLAIN
-#ifdef KPN_MFMA16_PLAIN_WAIT0   // bisection: every outstanding memory operation has completed before a half's MFMAs
-        __builtin_amdgcn_s_waitcnt(0);
-#endif
-        (void)w; (void)x; return;
-#endif
-        if constexpr (decltype(nn)::value == 2) kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
-        else kpn_mfma16_arrive(w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0], x[0], x[1], x[2]);
-    };
-    auto guard_half = [&](int ob0, auto nn, const auto& w, const kpn_bf16x8 (&x)[3]) {
-#ifdef KPN_MFMA16_PLAIN
-        (void)ob0; (void)w; (void)x; return;
-#endif
-        if constexpr (decltype(nn)::value == 2)
-            kpn_mfma16_guard(acc[ob0], acc[ob0 + 1], w[0][0], w[1][0], w[2][0], w[0][1], w[1][1], w[2][1], x[0], x[1], x[2]);
-        else
-            kpn_mfma16_guard(acc[ob0], acc[ob0], w[0][0], w[1][0], w[2][0], w[0][0], w[1][0], w[2][0], x[0], x[1], x[2]);
-    };
-    {
-        float x[8];
-        in_fn(kpn_ic<0>{}, x);
-        kpn_split3(x, xp[0][0], xp[0][1], xp[0][2]);
-    }
-    load_half(0, 0, H0, wa);
-    if constexpr (H1 > 0) load_half(0, H0, H1, wb);
-    kpn_static_for<0, KS16>([&](auto si) {
-        constexpr int s = decltype(si)::value;
-        constexpr int cur = s & 1, nxt = cur ^ 1;
-        if constexpr (s + 1 < KS16) {
-            float x[8];
-            in_fn(kpn_ic<s + 1>{}, x);
-            kpn_split3(x, xp[nxt][0], xp[nxt][1], xp[nxt][2]);
-        }
-        // VALU phase (above) and MFMA phase (below) are kept apart: see the note at kpn_mfma16_arrive.  The other wave
-        // of the SIMD fills the matrix pipe meanwhile.
-#if !defined(KPN_MFMA16_PLAIN) || defined(KPN_MFMA16_PLAIN_BARRIERS)
-        if constexpr (SEPARATE) KPN_SCHED_BARRIER();
-#endif
-        arrive_half(kpn_ic<H0>{}, wa, xp[cur]);
-        mfma_half(0, H0, wa, xp[cur]);
-        guard_half(0, kpn_ic<H0>{}, wa, xp[cur]);
-        if constexpr (s + 1 < KS16) load_half(s + 1, 0, H0, wa);
-        if constexpr (H1 > 0) {
-            arrive_half(kpn_ic<H1>{}, wb, xp[cur]);
-            mfma_half(H0, H1, wb, xp[cur]);
-            guard_half(H0, kpn_ic<H1>{}, wb, xp[cur]);
-            if constexpr (s + 1 < KS16) load_half(s + 1, H0, H1, wb);
-        }
-#if !defined(KPN_MFMA16_PLAIN) || defined(KPN_MFMA16_PLAIN_BARRIERS)
-        if constexpr (SEPARATE) KPN_SCHED_BARRIER();
-#endif
-    });
-#ifndef KPN_MFMA16_PLAIN
-    kpn_mfma16_tail<NOB>(acc);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------

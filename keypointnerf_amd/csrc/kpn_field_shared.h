@@ -21,7 +21,23 @@ struct kpn_points {
 // nb = ceil(ntiles / tiles_cap) batches (k_geo_rows + k_fuse_color per batch, the scratch reused); the host cannot know
 // nb without a sync, so it launches the worst-case number of batches and the surplus ones return at once.  Tiles are
 // split evenly: batch b owns [ntiles*b/nb, ntiles*(b+1)/nb).
-struct kpn_batch { int index, tiles_cap; };
+//
+// Range guard of the two-fp16-piece kernels (kpn_common.h kpn_f16_inputs_unsafe): `cond` says when a launch does its work —
+//   KPN_RUN_ALWAYS   : a kernel in fp32's exponent range (or the caller chose to run without the guard);
+//   KPN_RUN_IF_SAFE  : a two-fp16-piece kernel: stands aside when the weights or the maps are beyond fp16's range;
+//   KPN_RUN_IF_UNSAFE: the fp32-range kernels launched BEHIND them for the same batch: work only when those stood aside or when
+//                      the per-point kernel met a non-finite result (`bad` = the batch's flag in the pass's counter block; an
+//                      overflowed operand becomes NaN in every accumulator it touches and no activation of these kernels turns a
+//                      NaN into a number, so it reaches the per-point outputs).  Otherwise they return at once (3-4 us).
+// Never a NaN where the reference is finite, and no host synchronisation to get there.
+enum { KPN_RUN_ALWAYS = 0, KPN_RUN_IF_SAFE = 1, KPN_RUN_IF_UNSAFE = 2 };
+struct kpn_batch { int index, tiles_cap; int cond; int* bad; int* redone; };   // redone: counter of batches evaluated again (diagnostic)
+__device__ __forceinline__ bool kpn_batch_gate(const kpn_batch& b, const kpn_scene_dev& sc, const float* __restrict__ wp) {
+    if (b.cond == KPN_RUN_ALWAYS) return true;
+    const bool unsafe = kpn_f16_inputs_unsafe(sc, wp);
+    if (b.cond == KPN_RUN_IF_SAFE) return !unsafe;
+    return unsafe || (b.bad != nullptr && *b.bad != 0);
+}
 __device__ __forceinline__ bool kpn_batch_range(const kpn_batch& b, int ntiles, int& t0, int& t1) {
     const int nb = (ntiles + b.tiles_cap - 1) / b.tiles_cap;
     if (b.index >= nb) return false;

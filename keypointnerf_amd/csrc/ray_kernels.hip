@@ -12,9 +12,25 @@
 // ---------------------------------------------------------------------------------------------
 // per-view table: KRT rows, extrinsic rows, camera centre = inverse(KRT)[:3,3] (model.py:823-824),
 // keypoints in the camera frame (spatial.py:85).  One thread per view; double Gauss-Jordan.
+// The running max |value| of everything kpn_scene_prepare copies (scene flags[0], zeroed by k_scene_table, which runs first on
+// the stream): as int bit patterns |x| orders like the floats, and a NaN sits above +inf.  One atomic per wavefront, and only while
+// the wave's maximum is above what is already there (a few per launch).  Every thread of the wave must call it.
+__device__ __forceinline__ void kpn_note_absmax(float* __restrict__ flags, float a) {
+    int u = __float_as_int(a) & 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(u, o); u = w > u ? w : u; }
+    int* f = reinterpret_cast<int*>(flags);
+    if ((threadIdx.x & 63) == 0 && u > *reinterpret_cast<volatile int*>(f)) atomicMax(f, u);
+}
+__device__ __forceinline__ float kpn_absmax2(float a, float b) {   // max(|a|, |b|) that keeps a NaN (fmaxf would drop it)
+    const int x = __float_as_int(a) & 0x7fffffff, y = __float_as_int(b) & 0x7fffffff;
+    return __int_as_float(x > y ? x : y);
+}
+
 __global__ void k_scene_table(int V, const float* __restrict__ KRT, const float* __restrict__ extrin,
-                              const float* __restrict__ kpt3d, float* __restrict__ table) {
+                              const float* __restrict__ kpt3d, float* __restrict__ table, float* __restrict__ flags) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < KPN_SCENE_FLAG_FLOATS) flags[v] = 0.0f;
     if (v >= V) return;
     float* tb = table + (size_t)v * KPN_TBL_STRIDE;
     const float* M = KRT + v * 16;
@@ -46,26 +62,35 @@ __global__ void k_scene_table(int V, const float* __restrict__ KRT, const float*
 
 // (V,3,H,W) image + (V,H,W) mask bytes -> (V,H,W,4) [r,g,b,fg]
 __global__ void k_pack_rgbm(int64_t npix_total, int64_t HW, const float* __restrict__ img,
-                            const uint8_t* __restrict__ mask, float* __restrict__ out) {
+                            const uint8_t* __restrict__ mask, float* __restrict__ out, float* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix_total) return;
-    const int64_t v = i / HW, p = i - v * HW;
-    float4 o;
-    o.x = img[(v * 3 + 0) * HW + p];
-    o.y = img[(v * 3 + 1) * HW + p];
-    o.z = img[(v * 3 + 2) * HW + p];
-    o.w = mask ? (mask[i] ? 1.0f : 0.0f) : 1.0f;
-    reinterpret_cast<float4*>(out)[i] = o;
+    float amax = 0.0f;
+    if (i < npix_total) {
+        const int64_t v = i / HW, p = i - v * HW;
+        float4 o;
+        o.x = img[(v * 3 + 0) * HW + p];
+        o.y = img[(v * 3 + 1) * HW + p];
+        o.z = img[(v * 3 + 2) * HW + p];
+        o.w = mask ? (mask[i] ? 1.0f : 0.0f) : 1.0f;
+        reinterpret_cast<float4*>(out)[i] = o;
+        amax = kpn_absmax2(kpn_absmax2(o.x, o.y), o.z);
+    }
+    kpn_note_absmax(flags, amax);
 }
 
 // (V,C,h,w) -> (V,h,w,C); one thread per output element (writes coalesced)
-__global__ void k_nchw_to_nhwc(int64_t total, int C, int64_t hw, const float* __restrict__ in, float* __restrict__ out) {
+__global__ void k_nchw_to_nhwc(int64_t total, int C, int64_t hw, const float* __restrict__ in, float* __restrict__ out,
+                               float* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const int64_t vp = i / C;
-    const int64_t v = vp / hw, p = vp - v * hw;
-    out[i] = in[(v * C + c) * hw + p];
+    float x = 0.0f;
+    if (i < total) {
+        const int c = (int)(i % C);
+        const int64_t vp = i / C;
+        const int64_t v = vp / hw, p = vp - v * hw;
+        x = in[(v * C + c) * hw + p];
+        out[i] = x;
+    }
+    kpn_note_absmax(flags, x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -119,9 +144,9 @@ __global__ void k_ray_bbox(int64_t R, const float* __restrict__ bounds, const fl
     near_o[r] = n; far_o[r] = f; hit_o[r] = (uint8_t)h;
 }
 
-// model.py:1026-1043 for the pixel grid px = x0+ix*step, py = y0+iy*step
+// model.py:1026-1043 for the pixel grid px = x0+ix*step, py = y0+iy*stepy
 __global__ void k_make_rays(const float* __restrict__ K, const float* __restrict__ RT, float znear, float zfar,
-                            const float* __restrict__ bounds, int x0, int y0, int step, int nx, int ny,
+                            const float* __restrict__ bounds, int x0, int y0, int step, int stepy, int nx, int ny,
                             const int* __restrict__ pix, float* __restrict__ dirs, float* __restrict__ cam_pos,
                             float* __restrict__ near_o, float* __restrict__ far_o) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +167,7 @@ __global__ void k_make_rays(const float* __restrict__ K, const float* __restrict
     const int iy = (int)(r / nx), ix = (int)(r - (int64_t)iy * nx);
     // eval: strided grid (model.py:1019-1022); train: explicit patch pixels (x,y) (model.py:1008-1017)
     const float gx = pix ? (float)pix[r * 2 + 0] : (float)(x0 + ix * step);
-    const float gy = pix ? (float)pix[r * 2 + 1] : (float)(y0 + iy * step), gz = 1.0f;
+    const float gy = pix ? (float)pix[r * 2 + 1] : (float)(y0 + iy * stepy), gz = 1.0f;
     float cr[3], cn[3], cf[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -38,7 +38,7 @@ class RenderArgs(ctypes.Structure):
     """struct kpn_render_args"""
     _fields_ = [(n, c_p) for n in ("K", "RT", "bounds")] + [("znear", c_f), ("zfar", c_f)] + \
                [(n, c_i32) for n in ("x0", "y0", "step", "nx", "ny", "n_coarse", "n_fine", "fine", "chunk_rays")] + \
-               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")]
+               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")] + [("step_y", c_i32)]
 
 
 class TrainArgs(ctypes.Structure):
@@ -86,6 +86,9 @@ _SIGNATURES = {
     "kpn_packed_f16_range_check": (ctypes.c_int, [c_p, c_p, c_p]),
     "kpn_set_fuse_mode": (ctypes.c_int, [c_i32]),
     "kpn_get_fuse_mode": (ctypes.c_int, []),
+    "kpn_set_range_guard": (ctypes.c_int, [c_i32]),
+    "kpn_get_range_guard": (ctypes.c_int, []),
+    "kpn_range_guard_count": (ctypes.c_int, [c_p, c_p]),
     "kpn_ssim_scratch_bytes": (c_sz, [c_i32, c_i32]),
     "kpn_ssim": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     "kpn_query_workspace_bytes": (c_sz, [c_i64, c_i32]),
@@ -112,7 +115,7 @@ _SIGNATURES = {
     "kpn_set_row_scratch_cap_bytes": (ctypes.c_int, [ctypes.c_size_t]),
     "kpn_selftest_mfma": (ctypes.c_int, [c_p, c_p, c_p]),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KpnError(RuntimeError):

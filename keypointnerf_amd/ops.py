@@ -57,13 +57,9 @@ class PackedWeights:
             raise ValueError("unexpected hot-path parameter count")
         packed = np.zeros(L.kpn_packed_weight_floats(), np.float32)
         L.check(L.kpn_pack_weights(plain.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p)))
-        # the packer's count of layers1 weights beyond fp16's range (include/kpnerf.h kpn_packed_f16_range_check): the default rows
-        # kernel (mode 3) would turn them into inf — say so here, where it costs nothing (device-side packing: packed_f16_range_check)
+        # the packers' count of weights beyond fp16's range (include/kpnerf.h kpn_packed_f16_range_check).  Nothing to do here:
+        # the two-fp16-piece kernels read the same count on the device and leave the work to the fp32-range kernels (range guard)
         self.f16_beyond = int(packed[-4])
-        if self.f16_beyond and L.kpn_get_geo_rows_mode() == 3:
-            import warnings
-            warnings.warn(f"{self.f16_beyond} layers1 weights exceed fp16's range: the default rows kernel would return NaN rows; "
-                          "call keypointnerf_amd.ops.set_geo_rows_mode(2) (three bf16 pieces, fp32's exponent range) for these weights")
         self.tensor = torch.from_numpy(packed).to(device)
 
     @classmethod
@@ -330,9 +326,12 @@ class RenderPlan:
 
     def __init__(self, scene, grid, n_coarse, n_fine, fine=True, chunk_rays=0, device=None):
         L = kl.get_library()
-        x0, y0, step, nx, ny = (int(g) for g in grid)
+        # grid = (x0, y0, step, nx, ny) as the reference's strided grids, or (x0, y0, step, nx, ny, step_y): rows advance by step_y
+        # (a frame's rows dealt round-robin to the ranks of a render job: parallel.rows_of_rank)
+        x0, y0, step, nx, ny = (int(g) for g in grid[:5])
+        step_y = int(grid[5]) if len(grid) > 5 else 0
         dv = device or scene.ws.device
-        self.grid, self.fine = (x0, y0, step, nx, ny), bool(fine)
+        self.grid, self.fine = (x0, y0, step, nx, ny, step_y), bool(fine)
         self.out = {"tex_fg": torch.empty(1, 3, ny, nx, dtype=_f32, device=dv), "depth": torch.empty(1, ny, nx, dtype=_f32, device=dv),
                     "alpha": torch.empty(1, ny, nx, dtype=_f32, device=dv)}
         if fine:
@@ -341,7 +340,7 @@ class RenderPlan:
                              "alpha_fine": torch.empty(1, ny, nx, dtype=_f32, device=dv),
                              "sdf": torch.empty(1, ny, nx, dtype=_f32, device=dv)})
         a = kl.RenderArgs()
-        a.x0, a.y0, a.step, a.nx, a.ny = x0, y0, step, nx, ny
+        a.x0, a.y0, a.step, a.nx, a.ny, a.step_y = x0, y0, step, nx, ny, step_y
         a.n_coarse, a.n_fine, a.fine, a.chunk_rays = int(n_coarse), int(n_fine), int(bool(fine)), int(chunk_rays)
         for k, v in self.out.items():
             setattr(a, k, v.data_ptr())
@@ -490,6 +489,20 @@ def set_fuse_mode(mode):
 
 def get_fuse_mode():
     return int(kl.get_library().kpn_get_fuse_mode())
+
+
+def set_range_guard(on):
+    """The range guard of the two-fp16-piece kernels (include/kpnerf.h kpn_set_range_guard): on by default."""
+    kl.get_library().check(kl.get_library().kpn_set_range_guard(int(bool(on))))
+
+
+def range_guard_count():
+    """Batches of rows the fp32-range kernels evaluated again since the library was loaded (synchronises the current stream):
+    0 = every pass ran on the default (two-fp16-piece) kernels."""
+    L = kl.get_library()
+    n = ctypes.c_int64(0)
+    L.check(L.kpn_range_guard_count(_stream(), ctypes.byref(n)))
+    return int(n.value)
 
 
 def packed_f16_range_check(packed):

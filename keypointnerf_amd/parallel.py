@@ -150,6 +150,23 @@ class FrameGatherer:
                 self.work[k] = None
 
 
+def rows_of_rank(height, rank, world):
+    """Strong scaling of ONE frame by INTERLEAVED rows: image row y belongs to rank y mod world, i.e. rank r renders the grid
+    (y0 = r, step_y = world, ny = ceil((height - r) / world)).  The subject sits in the middle of the frame (a third of the
+    field evaluations are valid, concentrated there): contiguous bands leave the outer ranks nearly idle, rows dealt round-robin
+    give every rank the same share of the subject (tests/test_parallel_gloo.py checks the valid-row counts of the bench scene).
+    Returns (y0, step_y, ny)."""
+    return rank, world, (height - rank + world - 1) // world
+
+
+def deinterleave_rows(bands):
+    """bands: the ranks' (C, H/W, Wd) bands of one frame in rank order (a (W, C, H/W, Wd) tensor or a list) -> (C, H, Wd): row y of
+    the frame is row y // W of band y mod W.  Needs height % world == 0 (equal bands gather into one buffer)."""
+    b = torch.stack(list(bands), 0) if not isinstance(bands, torch.Tensor) else bands
+    W, C, n, Wd = b.shape
+    return b.permute(1, 2, 0, 3).reshape(C, n * W, Wd)
+
+
 def band_of_rank(height, rank, world):
     """Strong scaling of ONE frame: contiguous bands of image rows, rank r owns rows [y0, y0 + n)."""
     base, extra = divmod(height, world)

@@ -284,6 +284,31 @@ def query_backward(oscene, wflat, pts, view, d_out, apply_eval_func=False, keep=
     return d_w, d_g0, d_g1, d_tx
 
 
+def render_rays_train_backward(oscene, wflat, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std, grads):
+    """loss.backward() through the train branch of batch_render_pifu_nerf (reference src/model.py:1045-1096 under autograd),
+    composed from the pinned pieces: kpo_render_rays_train for the sample depths (drawn under no_grad, :1038,1118: no gradient
+    through them), kpo_query_ex for the field values at them, kpo_rgba2out_backward for both compositing calls (:1065,1085) and
+    kpo_query_backward for both field evaluations with their own dropout masks and noise.  `grads`: output name -> array like
+    the output ((R,3) / (R,)); missing = zero.  Returns (d_w flat, d_geo0, d_geo1, d_tex) like query_backward."""
+    pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+    R = pix.shape[0]
+    fwd = render_rays_train(oscene, wflat, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std)
+    dirs, cam_pos, _, _ = make_rays(cam_tar, bounds, pix)
+    total = None
+    for z, keep, noise, names in ((fwd["z_c"], keep_c, noise_c, ("tex_fg", "depth", "alpha", None)),
+                                  (fwd["z_f"], keep_f, noise_f, ("tex_fg_fine", "depth_fine", "alpha_fine", "sdf"))):
+        S = z.shape[1]
+        pts = (cam_pos[None, None, :] + dirs[:, None, :] * z[:, :, None]).astype(np.float32).reshape(-1, 3)   # :1057
+        view = np.broadcast_to(dirs[:, None, :], (R, S, 3)).reshape(-1, 3)
+        nz = _f32(noise).reshape(-1)
+        rgba, _ = query_ex(oscene, wflat, pts, view, apply_eval_func=True, keep=keep, noise=nz, noise_std=noise_std)
+        g = [None if (n is None or grads.get(n) is None) else _f32(grads[n]) for n in names]
+        d_rgba = rgba2out_backward(rgba.reshape(R, S, 5), z, d_color=g[0], d_depth=g[1], d_alpha=g[2], d_sdf=g[3])
+        part = query_backward(oscene, wflat, pts, view, d_rgba.reshape(-1, 5), apply_eval_func=True, keep=keep, noise=nz, noise_std=noise_std)
+        total = part if total is None else tuple(a + b for a, b in zip(total, part))
+    return total
+
+
 def ssim(pred_chw, gt_chw, box=None):
     """skimage 0.19 structural_similarity(pred, gt, multichannel=True) restated (reference src/zju_evaluator.py:44 calls
     it on float32 HWC crops): per channel 7x7 scipy.ndimage.uniform_filter (the filter skimage calls), fp32 arithmetic,

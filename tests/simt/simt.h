@@ -240,6 +240,14 @@ static inline kpn_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, k
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMax(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 // (fast-math intrinsics such as __expf are wrapped by kpn_common.h: glibc owns those names on the host)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }

@@ -105,8 +105,8 @@ def query(lib, hs, packed, pts, view, mode=0):
 
 
 def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays=0):
-    """grid = (x0, y0, step, nx, ny)."""
-    x0, y0, step, nx, ny = grid
+    """grid = (x0, y0, step, nx, ny[, step_y])."""
+    x0, y0, step, nx, ny = grid[:5]
     K, RT, b = f32(cam_tar["K"]).reshape(4, 4), f32(cam_tar["RT"]).reshape(4, 4), f32(bounds).reshape(2, 3)
     R = nx * ny
     o = {"tex_fg": np.full((3, ny, nx), np.nan, np.float32), "depth": np.full((ny, nx), np.nan, np.float32),
@@ -118,6 +118,7 @@ def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays
     a.K, a.RT, a.bounds = K.ctypes.data, RT.ctypes.data, b.ctypes.data
     a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
     a.x0, a.y0, a.step, a.nx, a.ny = x0, y0, step, nx, ny
+    a.step_y = grid[5] if len(grid) > 5 else 0
     a.n_coarse, a.n_fine, a.fine, a.chunk_rays = Sc, Sf, int(fine), chunk_rays
     for k, v in o.items():
         setattr(a, k, v.ctypes.data)

@@ -1,0 +1,150 @@
+"""Range / precision gate of the default arithmetic (-m gpu): rows mode 3 and fuse mode 1 carry every fp32 operand as two fp16
+pieces — fp32-class only while operands stay inside fp16's exponent range, with an absolute floor of 2^-24 below it.  Round 3
+tested them on O(1) data only (kaiming weights, randn maps).  Here the inputs leave that regime on purpose:
+
+  * feature maps and source images scaled by 2^k, k in -12 .. +17 (the upper end beyond fp16's range);
+  * every hot-path layer's weights scaled by 2^k, k in -12 .. +10 (one layer at a time);
+  * heavy-tailed weights and maps: a few channels of magnitude 1e3, Student-t weights (what trained checkpoints look like
+    next to a kaiming draw).
+
+For each case the frame is rendered by the DEFAULT kernels (with the range guard, keypointnerf_amd/csrc/kpn_field_shared.h) and
+by the fp32-range kernels (rows mode 0, fuse mode 0), and both are compared with the C oracle on the same inputs:
+
+  (1) never a non-finite value where the oracle is finite;
+  (2) the parity gate of tests/parity_gate.py (<= 1e-4 on every ray unless the oracle's own conditioning probe explains the
+      ray) whenever the fp32 kernels pass it themselves — an input that is ill-conditioned for fp32 arithmetic as such (a
+      layer 1024 x its size) is no statement about the two-piece operands;
+  (3) in every case the default kernels' worst error is within 3 x the fp32 kernels' (+ 2e-5): "fp32-class" as a measurement;
+  (4) the range guard's counter moves exactly when it must (an operand beyond fp16's range) and the report
+      (gpurun_out/range_gate.json via scripts/range_gate.py) lists, per case, the error of both kernel sets and whether the
+      fp32-range kernels took over."""
+import numpy as np
+import pytest
+import torch
+
+from tests import parity_gate
+
+pytestmark = pytest.mark.gpu
+
+TAR, SC, SF = (20, 20), 24, 16
+
+
+def _base():
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    scene = make_scene(n_views=3, src_hw=(64, 64), tar_hw=TAR, mask="ellipsoid", seed=4, tar_focal_at_512=800.0)
+    return scene, random_hotpath_state_dict(seed=5)
+
+
+def _scaled_layer(sd, prefix, wn, f):
+    out = {k: v.clone() for k, v in sd.items()}
+    key = prefix + (".weight_g" if wn else ".weight")
+    out[key] = out[key] * f
+    return out
+
+
+def range_cases():
+    """(name, scene, state dict, must the fp32-range kernels take over?) — None = either is fine."""
+    from keypointnerf_amd.synthetic import HOTPATH_LAYERS
+    scene, sd = _base()
+    cases = [("base", scene, sd, False)]
+    for k in (-12, -8, -4, 4, 8, 12, 15, 17):
+        f = 2.0 ** k
+        s = dict(scene)
+        s["feat_geo"] = [scene["feat_geo"][0] * f, scene["feat_geo"][1] * f]
+        s["feat_tex"] = scene["feat_tex"] * f
+        # randn maps reach ~4.5: beyond 60000 from 2^14 on
+        cases.append((f"maps x 2^{k}", s, sd, True if k >= 15 else (False if k <= 8 else None)))
+    for k in (-12, -6, 6, 17):
+        s = dict(scene)
+        s["img"] = scene["img"] * (2.0 ** k)
+        cases.append((f"images x 2^{k}", s, sd, True if k >= 17 else False))
+    for _, prefix, _, wn in HOTPATH_LAYERS:
+        for k in (-12, -6, 4, 10):
+            cases.append((f"{prefix} x 2^{k}", scene, _scaled_layer(sd, prefix, wn, 2.0 ** k), None if k > 0 else False))
+    # heavy tails: a few channels of magnitude 1e3 in every map, Student-t (3 dof) multipliers on all weights
+    g = torch.Generator().manual_seed(11)
+    s = dict(scene)
+    g0, g1, tx = scene["feat_geo"][0].clone(), scene["feat_geo"][1].clone(), scene["feat_tex"].clone()
+    g0[:, [3, 17, 40]] *= 1.0e3
+    g1[:, [2]] *= 1.0e3
+    tx[:, [1, 6]] *= 1.0e3
+    s["feat_geo"], s["feat_tex"] = [g0, g1], tx
+    cases.append(("maps with 1e3-magnitude channels", s, sd, None))
+    heavy = {}
+    for kname, v in sd.items():
+        if kname.endswith((".weight", ".weight_v")):
+            t = torch.randn(v.shape, generator=g) / torch.sqrt(torch.randn(3, *v.shape, generator=g).pow(2).mean(0))
+            heavy[kname] = v * (1.0 + 0.5 * t.abs().clamp(max=30.0))
+        else:
+            heavy[kname] = v.clone()
+    cases.append(("Student-t weights", scene, heavy, None))
+    cases.append(("Student-t weights, 1e3-magnitude channels", s, heavy, None))
+    return cases
+
+
+def run_case(ops, scene, sd):
+    """-> dict(err_default, err_fp32, took_over, gate_default (report or exception text), gate_fp32_ok)"""
+    from keypointnerf_amd.synthetic import to_device
+    from oracle import oracle
+    s = to_device(scene, "cuda")
+    th, tw = TAR
+    yy, xx = np.meshgrid(np.arange(th), np.arange(tw), indexing="ij")
+    pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
+    osc, wf = oracle.OracleScene(scene), oracle.flat_weights(sd)
+    ref = oracle.render_rays(osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF)
+    keys = ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")
+    oracle_finite = all(np.isfinite(ref[k]).all() for k in keys)
+    env = {}
+
+    def envelope():
+        if not env:
+            env.update(oracle.render_envelope(osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF, ref=ref))
+        return env
+
+    def render():
+        ps = ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"])
+        out = ops.render_rays(ps, ops.PackedWeights(sd), s["cam_tar"], s["bounds"], grid=(0, 0, 1, tw, th), n_coarse=SC, n_fine=SF)
+        return {k: (out[k][0].permute(1, 2, 0).reshape(-1, 3) if k.startswith("tex") else out[k].reshape(-1)).cpu().numpy() for k in keys}
+
+    def gate(got):
+        try:
+            return parity_gate.check_rays(got, ref, envelope, keys=keys, max_widened_fraction=0.02), None
+        except AssertionError as e:
+            return None, str(e)[:300]
+
+    rm, fm = ops.get_geo_rows_mode(), ops.get_fuse_mode()
+    c0 = ops.range_guard_count()
+    got = render()
+    took_over = ops.range_guard_count() > c0
+    ops.set_geo_rows_mode(0); ops.set_fuse_mode(0)
+    try:
+        got32 = render()
+    finally:
+        ops.set_geo_rows_mode(rm); ops.set_fuse_mode(fm)
+    err = lambda o: {k: float(np.nanmax(np.abs(o[k] - ref[k]))) if np.isfinite(o[k]).all() else float("inf") for k in keys}
+    rep, why = gate(got)
+    rep32, _ = gate(got32)
+    return dict(err_default=err(got), err_fp32=err(got32), took_over=bool(took_over), oracle_finite=oracle_finite,
+                finite=bool(all(np.isfinite(got[k]).all() for k in keys)), gate_default_ok=rep is not None, gate_default_why=why,
+                gate_fp32_ok=rep32 is not None, widened=len(rep["widened"]) if rep else None)
+
+
+def test_default_arithmetic_over_the_operand_range():
+    from keypointnerf_amd import ops
+    assert ops.get_geo_rows_mode() == 3 and ops.get_fuse_mode() == 1
+    bad = []
+    for name, scene, sd, must in range_cases():
+        r = run_case(ops, scene, sd)
+        if r["oracle_finite"] and not r["finite"]:
+            bad.append((name, "non-finite output where the oracle is finite"))
+            continue
+        if not r["oracle_finite"]:
+            continue                                   # the reference itself overflows fp32 here: nothing to compare
+        if r["gate_fp32_ok"] and not r["gate_default_ok"]:
+            bad.append((name, "gate", r["gate_default_why"]))
+        for k, e in r["err_default"].items():
+            if e > max(3.0 * r["err_fp32"][k] + 2e-5, 0.0):
+                bad.append((name, k, e, r["err_fp32"][k]))
+        if must is not None and r["took_over"] != must:
+            bad.append((name, "range guard took over" if r["took_over"] else "range guard did NOT take over"))
+    assert not bad, bad

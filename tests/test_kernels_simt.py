@@ -2,6 +2,7 @@
 C ABI, against the golden vectors of the reference and against the oracle.  This validates kernel logic
 (lane maps, weight permutation, compaction, sampler, compositor) in the GPU-less build container; the
 -m gpu tests repeat the comparison on the real device."""
+import ctypes
 import os
 
 import numpy as np
@@ -620,26 +621,6 @@ def test_ssim_kernel_vs_published_definition(env):
         assert abs(out[0] - expect) < 3e-6, (name, out[0], expect)
 
 
-def test_split_colour_path_is_bit_identical(env, monkeypatch):
-    """KPN_FUSE_SPLIT=1: k_fuse_color as two kernels (pooling + layers2 + compress / colour head; the A/B experiment of
-    DESIGN.md section 9.3) — same arithmetic in the same order: bit-identical field values, eval and train-style calls."""
-    lib, packed, _ = env
-    scene, cfg, g = load_case(CASES[0])
-    hs = sh.HostScene(lib, scene)
-    pts, view = g["query.1.pts"][0][:3000], g["query.1.view"][0][:3000]
-    res = []
-    default_fuse = lib.kpn_get_fuse_mode()
-    lib.check(lib.kpn_set_fuse_mode(0))              # the split kernels are the fp32-weight experiment: compare with k_fuse_color
-    try:
-        for split in ("0", "1"):
-            monkeypatch.setenv("KPN_FUSE_SPLIT", split)
-            res.append([sh.query(lib, hs, packed, pts, view, mode=m) for m in (0, 1)])
-    finally:
-        lib.check(lib.kpn_set_fuse_mode(default_fuse))
-    for (o0, v0), (o1, v1) in zip(res[0], res[1]):
-        assert np.array_equal(v0, v1) and np.array_equal(o0, o1)
-
-
 def test_zero_density_short_path_is_exact(env, monkeypatch):
     """k_fuse_color skips compress + colour head for tiles whose points all have relu(rad) == 0 (render passes): same frame
     bit for bit with the short path switched off (KPN_NO_ZERO_SKIP=1), density head biased so that such tiles exist."""
@@ -658,19 +639,83 @@ def test_zero_density_short_path_is_exact(env, monkeypatch):
             assert np.array_equal(pair[0][k], pair[1][k]), (bias, k)
         res.append(pair[0])
     assert res[0]["alpha_fine"].max() > 0.1 and res[1]["alpha_fine"].max() == 0.0
-    # the same frame through the split kernels with the second compaction (colour head over the live points only); they are the
-    # fp32-weight experiment, so the comparison frame is rendered with k_fuse_color (fuse mode 0)
-    default_fuse = lib.kpn_get_fuse_mode()
-    lib.check(lib.kpn_set_fuse_mode(0))
-    try:
-        packed = sh.pack_weights(lib, random_hotpath_state_dict(seed=3, density_bias=-20.0))
-        monkeypatch.setenv("KPN_NO_ZERO_SKIP", "0")
-        monkeypatch.setenv("KPN_FUSE_SPLIT", "0")
-        ref = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 12, 12), 24, 24)
-        for split in ("1", "2"):
-            monkeypatch.setenv("KPN_FUSE_SPLIT", split)
-            o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 12, 12), 24, 24)
-            for k in ref:
-                assert np.array_equal(o[k], ref[k]), (split, k)
-    finally:
-        lib.check(lib.kpn_set_fuse_mode(default_fuse))
+
+
+
+def _guard_count(lib):
+    n = ctypes.c_int64(-1)
+    lib.check(lib.kpn_range_guard_count(None, ctypes.byref(n)))
+    return int(n.value)
+
+
+def test_range_guard_of_the_fp16_kernels(env):
+    """The two-fp16-piece kernels (rows mode 3, fuse mode 1) carry operands in fp16's range only.  The guard: (a) weights or maps
+    beyond it -> the kernels stand aside ON THE DEVICE and the fp32-range kernels behind them do the work; (b) an ACTIVATION
+    beyond it (known only inside the pass) -> NaN accumulators -> the activations keep the NaN -> the per-point kernel flags the
+    batch -> the fp32-range kernels evaluate it again.  Either way the result is the fp32-range kernels' result — here compared
+    with rows mode 2 + fuse mode 0 selected explicitly (bit-identical: the very same launches) and with the oracle — and the
+    counter says that it happened; in-range inputs leave the counter alone.  With the guard off the same inputs give NaN."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    lib = env[0]
+    assert lib.kpn_get_geo_rows_mode() == 3 and lib.kpn_get_fuse_mode() == 1 and lib.kpn_get_range_guard() == 1
+    scene = make_scene(n_views=3, src_hw=(64, 64), tar_hw=(10, 10), mask="ellipsoid", seed=2, tar_focal_at_512=800.0)
+    sd = random_hotpath_state_dict(seed=3)
+    grid = (0, 0, 1, 10, 10)
+
+    def render(hs, packed):
+        return sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], grid, 12, 8)
+
+    def safe_modes(hs, packed):
+        lib.check(lib.kpn_set_geo_rows_mode(2)); lib.check(lib.kpn_set_fuse_mode(0))
+        try:
+            return render(hs, packed)
+        finally:
+            lib.check(lib.kpn_set_geo_rows_mode(3)); lib.check(lib.kpn_set_fuse_mode(1))
+
+    hs0 = sh.HostScene(lib, scene)
+    c0 = _guard_count(lib)
+    base = render(hs0, sh.pack_weights(lib, sd))
+    assert _guard_count(lib) == c0 and all(np.isfinite(v).all() for v in base.values())   # in range: nothing evaluated again
+
+    cases = {}
+    # (a1) a feature map with values beyond fp16's range (one channel of geo0 times 1e5)
+    big = {k: v for k, v in scene.items()}
+    g0 = scene["feat_geo"][0].clone(); g0[:, 5] *= 1.0e5
+    big["feat_geo"] = [g0, scene["feat_geo"][1]]
+    cases["map beyond fp16"] = (sh.HostScene(lib, big), sd, big)
+    # (a2) packed weights beyond fp16's range (layers1.1 scaled by 2^11: x 100 log2(e) in the packed stream)
+    sd_w = {k: v.clone() for k, v in sd.items()}
+    sd_w["mlp_geo.layers1.layers.1.linear.weight_g"] = sd["mlp_geo.layers1.layers.1.linear.weight_g"] * 2048.0
+    cases["weight beyond fp16"] = (hs0, sd_w, scene)
+    # (b) weights in range, pre-activations not: layers1.0 scaled so that 100 log2(e) |u| passes 65504 for some rows
+    sd_a = {k: v.clone() for k, v in sd.items()}
+    sd_a["mlp_geo.layers1.layers.0.linear.weight_g"] = sd["mlp_geo.layers1.layers.0.linear.weight_g"] * 300.0
+    cases["activation beyond fp16"] = (hs0, sd_a, scene)
+    # (b') the colour head: ray_encoder.2 scaled so that x' and its variance leave the range
+    sd_c = {k: v.clone() for k, v in sd.items()}
+    sd_c["mlp_tex.ray_encoder.2.weight"] = sd["mlp_tex.ray_encoder.2.weight"] * 3.0e3
+    cases["colour head beyond fp16"] = (hs0, sd_c, scene)
+    yy, xx = np.meshgrid(np.arange(10), np.arange(10), indexing="ij")
+    pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
+    for name, (hs, sdx, sc_) in cases.items():
+        packed = sh.pack_weights(lib, sdx)
+        before = _guard_count(lib)
+        got = render(hs, packed)
+        assert _guard_count(lib) > before, name                                    # the fp32-range kernels did evaluate batches
+        want = safe_modes(hs, packed)
+        for k in want:
+            assert np.isfinite(got[k]).all(), (name, k)
+            assert np.array_equal(got[k], want[k]), (name, k)
+        ref = oracle.render_rays(oracle.OracleScene(sc_), oracle.flat_weights(sdx), sc_["cam_tar"], sc_["bounds"], pix, 12, 8)
+        # (a sanity bound only: these are deliberately ill-scaled networks, a layer 300 x to 3000 x its trained size amplifies
+        # every implementation's rounding; the claim above is bit-identity with the fp32-range kernels)
+        for k in ("tex_fg", "tex_fg_fine"):
+            assert np.abs(got[k].transpose(1, 2, 0).reshape(-1, 3) - ref[k]).max() < 2e-3, (name, k)
+        for k in ("alpha", "alpha_fine"):
+            assert np.abs(got[k].reshape(-1) - ref[k]).max() < 2e-3, (name, k)
+        lib.check(lib.kpn_set_range_guard(0))                                        # without the guard: loudly wrong (NaN), as in round 3
+        try:
+            raw = render(hs, packed)
+        finally:
+            lib.check(lib.kpn_set_range_guard(1))
+        assert not all(np.isfinite(v).all() for v in raw.values()), name

@@ -314,3 +314,22 @@ def test_ssim_oracle_vs_published_definition():
     for name, pred, gt, expect in ssim_pin_cases():
         got = oracle.ssim(pred, gt)
         assert abs(got - expect) < 3e-6, (name, got, expect)
+
+
+@pytest.mark.parametrize("case", ["case_k_v3_train_grad", "case_l_v3_train_grad"])
+def test_train_render_backward_composition_vs_reference_autograd(case):
+    """oracle.render_rays_train_backward (the train branch's reverse pass composed from kpo_render_rays_train, kpo_query_ex,
+    kpo_rgba2out_backward and kpo_query_backward) against the reference's own loss.backward() through train-mode
+    batch_render_pifu_nerf (goldens k, l): it is the checker of the GPU test at configs[3] size
+    (tests/test_gpu_parity.py::test_train_render_backward_at_configs3_size), so it is pinned here first."""
+    from tests.golden_io import keep_bits
+    from tests.test_kernels_simt import assert_train_grads_vs_golden, train_grad_inputs
+    scene, cfg, g = load_case(case)
+    sd = load_weights()
+    osc, wflat = oracle.OracleScene(scene), oracle.flat_weights(sd)
+    gi = train_grad_inputs(g)
+    grads = {k: (v.T if v.ndim == 2 else v) for k, v in gi.items()}          # (R,3) / (R,)
+    got = oracle.render_rays_train_backward(osc, wflat, scene["cam_tar"], scene["bounds"], g["pix"], cfg["Sc"], cfg["Sf"], g["u_c"],
+                                            g["noise_c"], g["noise_f"], g["u_f"], keep_bits(g["keep_c"]), keep_bits(g["keep_f"]),
+                                            float(g["noise_std"]), grads)
+    assert_train_grads_vs_golden(list(got), g, sd, 5e-5)
