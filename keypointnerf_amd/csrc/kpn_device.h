@@ -89,14 +89,14 @@ __device__ __forceinline__ float kpn_elu(float x) {
 #ifdef KPN_ABLATE_ELU  // timing experiment only: wrong results
     return x;
 #endif
-    // ELU(x) = x if x > 0 else e^x - 1 (torch.nn.ELU), selected by the SIGN BIT: v_ashrrev_i32 + v_bfi_b32 — no v_cmp / VCC wait
-    // states.  Round 3 used one v_med3_f32 (median(x, e^x - 1, 0)); a median drops NaNs (v_med3_f32 returns min3 when an input is a
-    // NaN, and min3 returns the numeric operand), so an overflowed fp16 operand of k_fuse_color_h — NaN in every accumulator it
-    // touches — came out of the next ELU as 0 and the point as a finite, wrong colour.  A select keeps the NaN (x = NaN: either
-    // branch is a NaN), so it reaches the per-point outputs, where the range guard looks for it (kpn_field_shared.h kpn_batch).
+    // ELU(x) = x if x >= 0 else e^x - 1 (torch.nn.ELU) as compare + select.  Round 3 used one v_med3_f32 (median(x, e^x - 1, 0));
+    // a median drops NaNs (v_med3_f32 returns min3 when an input is a NaN, and min3 returns the numeric operand), so an overflowed
+    // fp16 operand of k_fuse_color_h — NaN in every accumulator it touches — came out of the next ELU as 0 and the point as a
+    // finite, wrong colour.  A select keeps the NaN (x = NaN: the compare is false, x is returned), so it reaches the per-point
+    // outputs, where the range guard looks for it (kpn_field_shared.h kpn_batch).  (A sign-bit select, v_ashrrev + v_bfi, came out
+    // of hipcc as three instructions: v_ashrrev_i32, v_max_i32, v_and_or_b32.)
     const float t = kpn_fast_exp(x) - 1.0f;
-    const int m = __float_as_int(x) >> 31;                          // all ones for a negative x
-    return __int_as_float((m & __float_as_int(t)) | (~m & __float_as_int(x)));
+    return x < 0.0f ? t : x;
 }
 
 // ---------------------------------------------------------------------------------------------
