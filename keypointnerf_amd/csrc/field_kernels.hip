@@ -245,9 +245,7 @@ struct kpn_ibr_view {
 };
 
 // the gather record of (tile t, view v) written by k_geo_rows: own half + partner half (lane ^ 32)
-__device__ __forceinline__ void kpn_gather_view(const float* __restrict__ xscr, int t, int V, int v, int lane, int h,
-                                                kpn_view_gather& o) {
-    const float4* rec = reinterpret_cast<const float4*>(xscr) + ((size_t)(t * V + v) * KPN_ROW_SLABS + 8) * 64;
+__device__ __forceinline__ void kpn_gather_view(const float4* __restrict__ rec, int lane, int h, kpn_view_gather& o) {
     const float4 own0 = rec[lane], own1 = rec[64 + lane], oth0 = rec[lane ^ 32], oth1 = rec[64 + (lane ^ 32)];
     const float4 a0 = h ? oth0 : own0, a1 = h ? oth1 : own1;  // [r,g,b,pw] , [ray_diff(3), dot]
     const float4 t0 = h ? own0 : oth0, t1 = h ? own1 : oth1;  // texture channels 0..3, 4..7
@@ -431,6 +429,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
     if (batch.cond == KPN_RUN_IF_UNSAFE && batch.redone != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(batch.redone, 1);
     const int ntiles = t1 - t0;
     const int V = sc.V;
+    const kpn_tile_layout lay(batch.pool, V);   // ROWS or POOL layout of the scratch (kpn_field_shared.h)
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
     // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
     __shared__ __attribute__((aligned(16))) float wlds[W::floats];
@@ -461,11 +460,22 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 
         KPN_FUSE_STAMP(0);
         // ---- pooled mean / var over views of the 64-vector ----
-        const float4* rows = reinterpret_cast<const float4*>(xscr) + ((size_t)t * V * KPN_ROW_SLABS) * 64;
+        const float4* const scr = reinterpret_cast<const float4*>(xscr);
+        const float4* rows = scr + lay.tile(t) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
         float pwsum;
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
-        KPN_POOL_VIEWS(rows, V, keep, lane, p, pwsum, pooled);
+        if (lay.pool) {    // POOL layout: the rows kernel has pooled already (slabs 0..7 mean, 8..15 variance of this tile)
+#pragma unroll
+            for (int q_ = 0; q_ < 16; ++q_) {
+                const float4 x_ = rows[q_ * 64 + lane];
+                pooled[4 * q_ + 0] = x_.x; pooled[4 * q_ + 1] = x_.y; pooled[4 * q_ + 2] = x_.z; pooled[4 * q_ + 3] = x_.w;
+            }
+            pwsum = 0.0f;
+        } else {
+            KPN_POOL_VIEWS(rows, V, keep, lane, p, pwsum, pooled);
+        }
+        (void)pwsum;
         KPN_FUSE_STAMP(1);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
@@ -477,16 +487,17 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             kpn_fuse_layer<F16, SEG_G2_1, 32, 2>(wl, lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(h0[g / 4][(g % 4) * 4 + i]);
+                for (int i = 0; i < 4; ++i) x[i] = F16 ? kpn_softplus_log2(h0[g / 4][(g % 4) * 4 + i]) : kpn_softplus100(h0[g / 4][(g % 4) * 4 + i]);
             }, h1);
             kpn_load_bias<1>(wl + W::boff(SEG_G2_2), h, o2);
             kpn_fuse_layer<F16, SEG_G2_2, 32, 1>(wl, lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(h1[g / 4][(g % 4) * 4 + i]);
+                for (int i = 0; i < 4; ++i) x[i] = F16 ? kpn_softplus_log2(h1[g / 4][(g % 4) * 4 + i]) : kpn_softplus100(h1[g / 4][(g % 4) * 4 + i]);
             }, o2);
-            sdf_raw = o2[0][0];  // rows 0,1 live in regs 0,1 of the h=0 lanes
-            rad = o2[0][1];
+            // rows 0,1 live in regs 0,1 of the h=0 lanes (the fp16 stream of layers2.2 is packed times 2^10: exact unscale)
+            sdf_raw = F16 ? o2[0][0] * (1.0f / KPN_F16_G22_SCALE) : o2[0][0];
+            rad = F16 ? o2[0][1] * (1.0f / KPN_F16_G22_SCALE) : o2[0][1];
         }
         // Exact zero-density short path (render passes only: park_x doubles as "nobody reads these rows or colours again").
         // A point with relu(rad) == 0 composites with weight 1 - exp(-0 * delta) = 0 exactly, like a masked point, so its
@@ -522,7 +533,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         float emin = 3.0e38f, esum = 0.0f;
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
-                const float dot = rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w;
+                const float dot = scr[(lay.rec(t, v) + 1) * 64 + p].w;
                 const float e = kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f)));
                 if (pass == 0) emin = fminf(emin, e);  // min over ALL views (:1288)
                 else if ((keep >> v) & 1u) esum = RADD(esum, RSUB(e, emin));
@@ -543,15 +554,15 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // x' of a view is needed three times (two statistics passes, the head).  With park_x the first pass parks it
         // in slabs 0..4 of the view's row block — the 64-vector stored there is dead once it has been pooled — and the
         // later passes read it back (5 dwordx4 per lane) instead of re-running the gather and the ray encoder.
-        float4* const park = const_cast<float4*>(rows) + lane;
+        float4* const park = const_cast<float4*>(scr) + lane;
         auto park_store = [&](int v, const kpn_ibr_view& x) {
-            float4* d = park + (size_t)v * KPN_ROW_SLABS * 64;
+            float4* d = park + lay.park(t, v) * 64;
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k * 64] = make_float4(x.xb0[4 * k], x.xb0[4 * k + 1], x.xb0[4 * k + 2], x.xb0[4 * k + 3]);
             d[4 * 64] = make_float4(x.xb1[0], x.xb1[1], x.xb1[2], 0.0f);
         };
         auto park_load = [&](int v, kpn_ibr_view& x) {
-            const float4* d = park + (size_t)v * KPN_ROW_SLABS * 64;
+            const float4* d = park + lay.park(t, v) * 64;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 f = d[k * 64];
@@ -564,13 +575,13 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             for (int v = 0; v < V; ++v) {
                 if (!((keep >> v) & 1u)) continue;
                 if (pass == 0 || !park_x) {
-                    kpn_gather_view(xscr, t, V, v, lane, h, gv);
+                    kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
                     kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
                     if (park_x) park_store(v, iv);
                     stats(pass, gv.rd[3], iv);
                 } else {
                     park_load(v, iv);
-                    stats(pass, rows[((size_t)v * KPN_ROW_SLABS + 9) * 64 + p].w, iv);
+                    stats(pass, scr[(lay.rec(t, v) + 1) * 64 + p].w, iv);
                 }
             }
         KPN_FUSE_STAMP(4);
@@ -641,7 +652,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         };
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
-            kpn_gather_view(xscr, t, V, v, lane, h, gv);
+            kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
             if (park_x) park_load(v, iv);
             else kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);

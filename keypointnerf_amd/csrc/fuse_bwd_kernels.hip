@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
         float emin = 3.0e38f, esum = 0.0f;
         for (int v = 0; v < V; ++v) {
             kpn_view_gather g;
-            kpn_gather_view(xscr, t, V, v, lane, h, g);
+            kpn_gather_view(reinterpret_cast<const float4*>(xscr) + ((size_t)(t * V + v) * KPN_ROW_SLABS + 8) * 64, lane, h, g);
             dotv[v] = g.rd[3];
             rgbv[v][0] = g.rgb[0]; rgbv[v][1] = g.rgb[1]; rgbv[v][2] = g.rgb[2];
             emin = fminf(emin, kpn_fast_exp(RMUL(ani, RSUB(g.rd[3], 1.0f))));

@@ -376,16 +376,24 @@ __device__ unsigned long long kpn_h2_cycles[8];
 #else
 #define KPN_H2_BOUNDS
 #endif
-template <class SC>
+// POOL = false: a work item is (tile pair, view); the 64-vector of every (point, view) goes to the row scratch (ROWS layout,
+//        kpn_field_shared.h) and the per-point kernel pools over the views — what the training passes keep for their backward.
+// POOL = true : a work item is a tile pair walked through ALL its views, pooled on the fly: view v's 64-vectors update a weighted
+//        Welford state (running mean and sum of weighted squared deviations, weights = the boundary-smooth view weights of
+//        model.py:752-759) that lives in LDS (32 KB per wave: a lane's 2 x 64 floats for its two tiles), and only the pooled
+//        mean / variance (PoolModule, utils.py:612-647, 731-748) is written: 128 floats per point instead of V x 64, one
+//        dependent fetch instead of V in the per-point kernel, no pooling arithmetic there.  Welford, not sums of x and x^2: the
+//        views agree to a few per cent on most points, var << mean^2, and the subtraction would cancel.
+template <class SC, bool POOL>
 __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, float* __restrict__ xscr, const kpn_batch& batch) {
     constexpr int NP = SC::NP;
+    if (!kpn_batch_gate(batch, sc, wp)) return;            // the range guard (kpn_field_shared.h): wave-uniform, before anything else
 #if defined(KPN_H2_PAD) && !defined(KPN_SIMT_EMU)   // soak builds: shift every instruction of the kernel by 4 * KPN_H2_PAD bytes
 #pragma unroll
     for (int i = 0; i < KPN_H2_PAD; ++i) asm volatile("s_nop 0");
 #endif
-    if (!kpn_batch_gate(batch, sc, wp)) return;            // the range guard (kpn_field_shared.h): wave-uniform, before anything else
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
     const int count = *count_ptr;
@@ -393,9 +401,15 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
     int t0, t1;
     if (!kpn_batch_range(batch, ntiles, t0, t1)) return;
     const int nbt = t1 - t0;                               // tiles of this batch
-    const int nwork = ((nbt + 1) >> 1) * sc.V;
+    const int nwork = ((nbt + 1) >> 1) * (POOL ? 1 : sc.V);
+    const kpn_tile_layout lay(POOL ? 1 : 0, sc.V);
+    const uint32_t keep_bits = sc.keep & ((sc.V >= 32) ? 0xFFFFFFFFu : ((1u << sc.V) - 1u));
     const float neg_inv_two_sigma2 = -1.0f / sc.two_sigma2;   // exp(-d2 / 2 sigma^2) as one multiply per keypoint
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
+    // POOL: the Welford state of this wave's tile pair, [32 slabs][64 lanes] float4: slabs 0..15 running mean (tile t, block b,
+    // quad q -> slab 8 t + 4 b + q), 16..31 the weighted squared deviations.  Lane-private: no synchronisation.
+    __shared__ __attribute__((aligned(16))) float4 pool_s[POOL ? 4 * 32 * 64 : 1];
+    float4* const pst = pool_s + (POOL ? ((threadIdx.x >> 6) * 32 * 64 + lane) : 0);
     {
         const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
         for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
@@ -411,8 +425,9 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
 #endif
     // The work items are software-pipelined (SC::PREFETCH: the fp16 scheme, which has the registers for it): the NEXT item's
     // ticket is drawn while layers1.0 runs, its two list entries are fetched while layers1.1 runs and its points while
-    // layers1.2 runs, so that the three dependent round trips (atomic -> list -> point: 5-6 k cycles that nothing covered at one
-    // wave per SIMD) are off the critical path.  Clamped indices keep the look-ahead of a ticket beyond the last item in bounds.
+    // layers1.2 runs (POOL: of the item's first view), so that the three dependent round trips (atomic -> list -> point: 5-6 k
+    // cycles that nothing covered at one wave per SIMD) are off the critical path.  Clamped indices keep the look-ahead of a
+    // ticket beyond the last item in bounds.
     int nx_ticket = 0;                    // lane 0: the raw result of the next ticket's atomic
     int nx_wi = 0;
     int64_t nx_n[2] = {0, 0};
@@ -420,7 +435,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
     auto draw_ticket = [&]() { if (lane == 0) nx_ticket = atomicAdd(tickets + 0, 1); };
     auto fetch_list = [&]() {
         nx_wi = __shfl(nx_ticket, 0);
-        const int npair = nx_wi / sc.V;
+        const int npair = POOL ? nx_wi : nx_wi / sc.V;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             int64_t ci = (int64_t)(t0 + 2 * npair + t) * KPN_TILE + p;
@@ -437,30 +452,40 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
         KPN_H2_STAMP(6);
         const int wi = nx_wi;
         if (wi >= nwork) return;
-        const int pair = wi / sc.V, v = wi - pair * sc.V;
+        const int pair = POOL ? wi : wi / sc.V;
+        const int v_begin = POOL ? 0 : wi - pair * sc.V, v_end = POOL ? sc.V : v_begin + 1;
         const bool has1 = 2 * pair + 1 < nbt;              // an odd batch ends in half a pair: tile 1 is computed, not stored
-        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
         float P[2][3], D[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kpn_point_finish(ps, nx_raw[t], P[t], D[t]);
+        bool prefetched = false;                           // the next item's ticket / list / points: under the first computed view
+        float wsum[2] = {0.0f, 0.0f};                      // POOL: the views' weights so far
+        bool first_view = true;
+      for (int v = v_begin; v < v_end; ++v) {
+        const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
         kpn_proj q[2];
         float4* dst[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tr = 2 * pair + t;
-            kpn_point_finish(ps, nx_raw[t], P[t], D[t]);
             q[t] = kpn_project(tb, P[t][0], P[t][1], P[t][2], sc);
-            dst[t] = reinterpret_cast<float4*>(xscr) + ((size_t)(tr * sc.V + v) * KPN_ROW_SLABS) * 64 + lane;
+            dst[t] = reinterpret_cast<float4*>(xscr) + (POOL ? lay.tile(tr) : lay.row(tr, v)) * 64 + lane;
         }
         if (!((sc.keep >> v) & 1u)) {                      // a dropped view: zero rows (its gather records: k_row_records)
+            if constexpr (!POOL) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t == 1 && !has1) break;
+                for (int t = 0; t < 2; ++t) {
+                    if (t == 1 && !has1) break;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) dst[t][k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < 8; ++k) dst[t][k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-            draw_ticket(); fetch_list(); fetch_points();
-            continue;
+            continue;                                      // (POOL: weight 0 in the pooling, nothing to do)
         }
-        if constexpr (SC::PREFETCH) draw_ticket();
+        float wview[2] = {0.0f, 0.0f};                     // POOL: this view's boundary-smooth weight of the two points (model.py:752-758)
+        if constexpr (POOL) { wview[0] = kpn_pix_weight(q[0]); wview[1] = kpn_pix_weight(q[1]); }
+        const bool pf = SC::PREFETCH && !prefetched;
+        if (pf) draw_ticket();
         KPN_H2_STAMP(0);
         // ---- layers1.0 as ONE 16-step chain (HSEG_G1_0A and HSEG_G1_0B are adjacent, same step size): steps 0-11 one
         //      keypoint each (7 encoding values + a zero slot), steps 12-15 eight geo0 channels each ----
@@ -591,7 +616,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                 a0, xa, xb);
         }
         KPN_H2_STAMP(1);
-        if constexpr (SC::PREFETCH) fetch_list();
+        if (pf) fetch_list();
         // chained step s of a 128-vector: registers 8(s%2)..+7 of block s/2
         kpn_f32x16 a2[2][4];
         float4 hraw[2][4];                                  // the four taps of the 4 hd channels of this half (layers1.2, step 8)
@@ -630,7 +655,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             [&](auto ti, auto ei) -> float { return a1[decltype(ti)::value][0][decltype(ei)::value]; },
             a1, xb, xa);
         KPN_H2_STAMP(2);
-        if constexpr (SC::PREFETCH) fetch_points();
+        if (pf) fetch_points();
         kpn_f32x16 acc[2][2];
         kpn_mfma16_layer2<SC, 9, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_xseg_off(HSEG_G1_2, NP), lane,
             [&](auto si, auto ti, auto ei) -> float {
@@ -654,18 +679,73 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             },
             [](auto, auto, auto, auto) {}, [](auto) {}, [](auto, auto) -> float { return 0.0f; }, acc, xb, xa);
         KPN_H2_STAMP(4);
+        prefetched |= pf;
+        if constexpr (!POOL) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t == 1 && !has1) break;
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !has1) break;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd)
-                    dst[t][(b * 4 + qd) * 64] =   // (the fp16 scheme's layers1.3 is packed times 2^10: exact power-of-two unscale)
-                        make_float4(acc[t][b][4 * qd + 0] * SC::out_down, acc[t][b][4 * qd + 1] * SC::out_down,
-                                    acc[t][b][4 * qd + 2] * SC::out_down, acc[t][b][4 * qd + 3] * SC::out_down);
+                    for (int qd = 0; qd < 4; ++qd)
+                        dst[t][(b * 4 + qd) * 64] =   // (the fp16 scheme's layers1.3 is packed times 2^10: exact power-of-two unscale)
+                            make_float4(acc[t][b][4 * qd + 0] * SC::out_down, acc[t][b][4 * qd + 1] * SC::out_down,
+                                        acc[t][b][4 * qd + 2] * SC::out_down, acc[t][b][4 * qd + 3] * SC::out_down);
+            }
+        } else {
+            // Weighted Welford update of the pooled statistics with this view's rows x (weight w = the view's boundary-smooth
+            // weight, un-normalised): W += w, d = x - mean, mean += (w / W) d, M2 += w d (x - mean).  The last kept view
+            // finishes: the reference normalises the weights by (sum + 1e-6) (model.py:759), so with S = sum w, s = S / (S + 1e-6):
+            //     mean_ref = s mu,   var_ref = sum_v pw_v (x_v - mean_ref)^2 = (M2 + S (mu (1 - s))^2) / (S + 1e-6)
+            const bool last_view = (keep_bits >> (v + 1)) == 0u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float w = wview[t];
+                const float wn = wsum[t] + w;
+                const float r = wn > 0.0f ? w / wn : 0.0f;
+                const float inv = 1.0f / (wn + 1e-6f), s_ = wn * inv, om = 1e-6f * inv;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int slab = 8 * t + 4 * b + qd;
+                        float x[4], mu[4], m2[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = acc[t][b][4 * qd + e] * SC::out_down;
+                        if (first_view) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { mu[e] = x[e]; m2[e] = 0.0f; }
+                        } else {
+                            const float4 a = pst[slab * 64], c = pst[(16 + slab) * 64];
+                            const float am[4] = {a.x, a.y, a.z, a.w}, cm[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float d = x[e] - am[e];
+                                mu[e] = fmaf(r, d, am[e]);
+                                m2[e] = fmaf(w * d, x[e] - mu[e], cm[e]);
+                            }
+                        }
+                        if (!last_view) {
+                            pst[slab * 64] = make_float4(mu[0], mu[1], mu[2], mu[3]);
+                            pst[(16 + slab) * 64] = make_float4(m2[0], m2[1], m2[2], m2[3]);
+                        } else if (t == 0 || has1) {
+                            float mr[4], vr[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                mr[e] = mu[e] * s_;
+                                const float dm = mu[e] * om;
+                                vr[e] = fmaxf(fmaf(wn * dm, dm, m2[e]) * inv, 0.0f);
+                            }
+                            dst[t][(4 * b + qd) * 64] = make_float4(mr[0], mr[1], mr[2], mr[3]);
+                            dst[t][(8 + 4 * b + qd) * 64] = make_float4(vr[0], vr[1], vr[2], vr[3]);
+                        }
+                    }
+                wsum[t] = wn;
+            }
+            first_view = false;
         }
-        if constexpr (!SC::PREFETCH) { draw_ticket(); fetch_list(); fetch_points(); }
+      }   // views of the work item
+        if (!prefetched) { draw_ticket(); fetch_list(); fetch_points(); }
     }
 }
 
@@ -673,13 +753,24 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
 __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
-    kpn_geo_rows_pair_body<kpn_sc_bf16x3>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
+    kpn_geo_rows_pair_body<kpn_sc_bf16x3, false>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
 }
 // rows mode 3 (the default): two fp16 pieces, four products
 __global__ KPN_H2_BOUNDS void k_geo_rows_f2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
-    kpn_geo_rows_pair_body<kpn_sc_f16x2>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
+    kpn_geo_rows_pair_body<kpn_sc_f16x2, false>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
+}
+// the same two, pooling over the views inside the kernel (POOL layout of the scratch): the render and query passes
+__global__ KPN_H2_BOUNDS void k_geo_rows_h2p(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
+    kpn_geo_rows_pair_body<kpn_sc_bf16x3, true>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
+}
+__global__ KPN_H2_BOUNDS void k_geo_rows_f2p(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
+    kpn_geo_rows_pair_body<kpn_sc_f16x2, true>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
 }
 
 // The colour head's gather records of a batch (slabs 8, 9 of every (tile, view) block of the row scratch; kpn_row_record_a / _b,
@@ -696,6 +787,7 @@ __global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_point
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;
     const int nbt = t1 - t0;
     const int nwork = ((nbt + 1) >> 1) * sc.V;
+    const kpn_tile_layout lay(batch.pool, sc.V);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int wi = wave; wi < nwork; wi += nwaves) {
         const int pair = wi / sc.V, v = wi - pair * sc.V;       // wave-uniform
@@ -710,7 +802,7 @@ __global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_point
         kpn_row_record_a(sc, tb, v, q, P, D, a0, a1);
         kpn_row_record_b(sc, v, q, b0, b1);
         if (tr < nbt) {                                          // an odd batch ends in half a pair
-            float4* rec = reinterpret_cast<float4*>(xscr) + ((size_t)(tr * sc.V + v) * KPN_ROW_SLABS + 8) * 64;
+            float4* rec = reinterpret_cast<float4*>(xscr) + lay.rec(tr, v) * 64;
             rec[p] = a0; rec[32 + p] = b0; rec[64 + p] = a1; rec[64 + 32 + p] = b1;
         }
     }

@@ -11,7 +11,10 @@
 extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_geo_rows_pair(
     int mode, int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp, const int* list, const int* count,
     int* tickets, float* xscr, const kpn_batch* batch) {
-    if (mode == 3)
+    if (batch->pool) {   // pooling over the views inside the kernel (POOL layout of the scratch)
+        if (mode == 3) KPN_LAUNCH(k_geo_rows_f2p, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, *batch);
+        else KPN_LAUNCH(k_geo_rows_h2p, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, *batch);
+    } else if (mode == 3)
         KPN_LAUNCH(k_geo_rows_f2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, *batch);
     else
         KPN_LAUNCH(k_geo_rows_h2, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, xscr, *batch);

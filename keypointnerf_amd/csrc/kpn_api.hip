@@ -214,12 +214,12 @@ int pack_k2h_host(float* P) {   // returns the number of weights beyond fp16's r
         for (int el = 0; el < k2h_elements(sg); ++el) {
             int src, slot;
             k2h_locate(sg, el, src, slot);
-            const float w = src >= 0 ? P[src] : 0.0f;
+            const float w = (src >= 0 ? P[src] : 0.0f) * kpn_cseg_wfactor(sg);   // log2-unit activations of layers2 (kpn_common.h)
             if (!(fabsf(w) <= 65504.0f)) ++beyond;
             const uint16_t ph = host_f2h(w);
             P16[slot] = ph; P16[slot + 512] = host_f2h(w - host_h2f(ph));
         }
-        memcpy(P + kpn_cseg_boff(sg), P + kpn_seg_boff(sg), sizeof(float) * (size_t)kpn_seg_bfloats(sg));
+        for (int k = 0; k < kpn_seg_bfloats(sg); ++k) P[kpn_cseg_boff(sg) + k] = P[kpn_seg_boff(sg) + k] * kpn_cseg_bfactor(sg);
     }
     return beyond;
 }
@@ -237,7 +237,7 @@ __global__ void k_pack_k2h(float* __restrict__ packed, int n_elem, float* __rest
         const int NOB = kpn_seg_shapes[sg].nob, G = kpn_seg_shapes[sg].g, KS = kpn_seg_shapes[sg].ks;
         const int e = el % 8, lane = (el / 8) % 64, ob = (el / 512) % NOB, c = el / (512 * NOB);
         const int s = 8 * c + e;
-        const float w = s < KS ? packed[kpn_seg_woff(sg) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob] : 0.0f;
+        const float w = (s < KS ? packed[kpn_seg_woff(sg) + ((s / G) * 64 + lane) * (G * NOB) + (s % G) * NOB + ob] : 0.0f) * kpn_cseg_wfactor(sg);
         const int slot = kpn_cseg_woff(sg) * 2 + (((c * NOB + ob) * 2) * 64 + lane) * 8 + e;
 #ifndef KPN_SIMT_EMU
         const _Float16 h = (_Float16)w;
@@ -255,7 +255,7 @@ __global__ void k_pack_k2h(float* __restrict__ packed, int n_elem, float* __rest
     if (t < n_bias) {
         int sg = SEG_G2_0, k = t;
         while (k >= kpn_seg_bfloats(sg)) { k -= kpn_seg_bfloats(sg); ++sg; }
-        packed[kpn_cseg_boff(sg) + k] = packed[kpn_seg_boff(sg) + k];
+        packed[kpn_cseg_boff(sg) + k] = packed[kpn_seg_boff(sg) + k] * kpn_cseg_bfactor(sg);
     } else if (t < n_bias + n_tail) {
         packed[kpn_k2h_tail_off() + (t - n_bias)] = packed[kpn_scalar_off() + (t - n_bias)];
     }
@@ -752,7 +752,10 @@ const int64_t kUncappedPoints = 2048;
 const int64_t kUncappedPoints = 262144;
 #endif
 struct QueryLayout { size_t count, list, xscr, total; int tiles_cap, nbatch; };  // byte offsets
-QueryLayout query_layout(int64_t N, int V) {
+// pool: the POOL layout of the scratch (kpn_field_shared.h): the render / query passes with the pair-tile rows kernels
+int geo_rows_mode();
+bool pool_layout_selected() { return geo_rows_mode() >= 2 && !(getenv("KPN_NO_POOL") && atoi(getenv("KPN_NO_POOL"))); }
+QueryLayout query_layout(int64_t N, int V, bool pool = false) {
     QueryLayout L;
     size_t o = 0;
     // [0] valid count; batch b owns ints [8 + 8b, 16 + 8b): [0] rows ticket, [1] per-point ticket, [4] / [5] the same for the
@@ -760,7 +763,7 @@ QueryLayout query_layout(int64_t N, int V) {
     L.count = o; o += kCounterBytes;
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
-    const size_t tile_bytes = (size_t)V * KPN_ROW_SLABS * 64 * sizeof(float4);
+    const size_t tile_bytes = (size_t)kpn_tile_slabs(pool ? 1 : 0, V) * 64 * sizeof(float4);
     // monotone in N (a render workspace is laid out for its largest pass and used by smaller ones): never fewer tiles
     // than an uncapped pass of kUncappedPoints points needs
     size_t cap = row_scratch_cap_bytes() / tile_bytes;
@@ -891,7 +894,10 @@ void launch_rows(int rows_mode, const kpn_scene_dev& sc, const kpn_points& ps, c
                  int* tickets, float* xscr, const kpn_batch& batch, void* stream) {
     if (rows_mode >= 2) {
 #ifdef KPN_SIMT_EMU
-        if (rows_mode == 3) KPN_LAUNCH(k_geo_rows_f2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
+        if (batch.pool) {
+            if (rows_mode == 3) KPN_LAUNCH(k_geo_rows_f2p, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
+            else KPN_LAUNCH(k_geo_rows_h2p, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
+        } else if (rows_mode == 3) KPN_LAUNCH(k_geo_rows_f2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
         else KPN_LAUNCH(k_geo_rows_h2, dim3(pair_grid_blocks()), dim3(256), stream, sc, ps, wp, list, count, tickets, xscr, batch);
 #else
         kpn_internal_launch_geo_rows_pair(rows_mode, pair_grid_blocks(), stream, &sc, &ps, wp, list, count, tickets, xscr, &batch);
@@ -911,8 +917,12 @@ void launch_fuse(int fmode, const kpn_scene_dev& sc, const kpn_points& ps, const
 }
 
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
-              uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0) {
-    const QueryLayout L = query_layout(N, sc.V);
+              uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0, int allow_pool = 0) {
+    // POOL layout of the scratch (kpn_field_shared.h): the pair-tile rows kernels pool over the views themselves — the eval render
+    // passes and kpn_query; never when a backward pass reads the per-view rows again, never in the train branch (whose kept and
+    // not-kept forward must stay bit-identical)
+    const int pool = (allow_pool && !keep_rows && out && pool_layout_selected()) ? 1 : 0;
+    const QueryLayout L = query_layout(N, sc.V, pool != 0);
     char* base = static_cast<char*>(ws);
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
@@ -934,9 +944,9 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     for (int b = 0; b < L.nbatch; ++b) {
         int* slots = count + 8 + 8 * b;
         int* bad = guard ? slots + 6 : nullptr;
-        const kpn_batch b_rows{b, L.tiles_cap, (guard && rmode == 3) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr};
-        const kpn_batch b_rec{b, L.tiles_cap, KPN_RUN_ALWAYS, nullptr, nullptr};
-        const kpn_batch b_fuse{b, L.tiles_cap, (guard && fmode == 1) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr};
+        const kpn_batch b_rows{b, L.tiles_cap, (guard && rmode == 3) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr, pool};
+        const kpn_batch b_rec{b, L.tiles_cap, KPN_RUN_ALWAYS, nullptr, nullptr, pool};
+        const kpn_batch b_fuse{b, L.tiles_cap, (guard && fmode == 1) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr, pool};
 #ifndef KPN_SIMT_EMU
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
@@ -963,8 +973,8 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         if (guard) {
             // The same batch again in fp32's exponent range, IF the kernels above stood aside or flagged it: the rows first (the
             // per-point kernel has parked its x' vectors over them; the gather records are intact), then the per-point kernel.
-            const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr};
-            const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone};
+            const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr, pool};
+            const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone, pool};
             launch_rows(safe_rmode, sc, ps, wp, list, count, slots + 4, xscr, r_rows, stream);
             launch_fuse(0, sc, ps, wp, list, count, slots + 4, xscr, mode, park_x, out, r_fuse, zero_skip, stream);
         }
@@ -1022,7 +1032,8 @@ extern "C" int kpn_packed_f16_range_check(const float* packed_dev, void* stream,
 
 extern "C" size_t kpn_query_workspace_bytes(int64_t N, int32_t V) {
     if (N <= 0 || V <= 0) return 0;
-    return query_layout(N, V).total;
+    const size_t qa = query_layout(N, V, false).total, qb = query_layout(N, V, pool_layout_selected()).total;
+    return qa > qb ? qa : qb;
 }
 
 extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts,
@@ -1033,9 +1044,9 @@ extern "C" int kpn_query(const kpn_scene_desc* d, const void* scene_ws, const fl
     KPN_REQUIRE(N >= 0 && N < (1ll << 31), "point count out of range");
     if (N == 0) return KPN_OK;  // empty input: nothing to do (pointers may be null)
     KPN_REQUIRE(scene_ws && wp && pts && view && out && ws, "null pointer");
-    if (ws_bytes < query_layout(N, d->n_views).total) return fail(KPN_EWORKSPACE, "query workspace too small");
+    if (ws_bytes < query_layout(N, d->n_views, pool_layout_selected()).total) return fail(KPN_EWORKSPACE, "query workspace too small");
     kpn_points ps{pts, view, nullptr, nullptr, nullptr, 1};
-    return run_field(scene_dev(d, scene_ws), ps, wp, N, mode, out, valid, ws, stream);
+    return run_field(scene_dev(d, scene_ws), ps, wp, N, mode, out, valid, ws, stream, 0, 0, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1364,7 +1375,10 @@ RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
     L.depth = take((size_t)C * 4);
     L.alpha = take((size_t)C * 4);
     L.sdf = take((size_t)C * 4);
-    L.query = take(query_layout(C * Sfull, d->n_views).total);
+    {   // eval passes use the POOL layout of the scratch, the train branch (same workspace) the ROWS layout: room for either
+        const size_t qa = query_layout(C * Sfull, d->n_views, false).total, qb = query_layout(C * Sfull, d->n_views, pool_layout_selected()).total;
+        L.query = take(qa > qb ? qa : qb);
+    }
     L.total = o;
     return L;
 }
@@ -1442,7 +1456,8 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
         const bool no_reuse = nr && atoi(nr);
         const bool reuse = (t == nullptr) && a->fine && !no_reuse;
         float* rgba_coarse = reuse ? F(L.rgba_c) : F(L.rgba);
-        if (int e = run_field(sc, ps, wp, n * Sc, 1, rgba_coarse, nullptr, base + L.query, stream, 1)) return e;   // model.py:1062
+        const int allow_pool = t == nullptr;   // eval: pooled inside the rows kernel; the train branch keeps the per-view rows
+        if (int e = run_field(sc, ps, wp, n * Sc, 1, rgba_coarse, nullptr, base + L.query, stream, 1, 0, allow_pool)) return e;   // model.py:1062
         if (int e = kpn_rgba2out(rgba_coarse, F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
@@ -1455,12 +1470,12 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
             sc.keep = t ? t->keep_fine : 0xFFFFFFFFu;
             if (reuse) {
                 kpn_points pn{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zn), Sf, nullptr, 0.0f};
-                if (int e = run_field(sc, pn, wp, n * Sf, 1, F(L.rgba_n), nullptr, base + L.query, stream, 1)) return e;  // :1082, new samples
+                if (int e = run_field(sc, pn, wp, n * Sf, 1, F(L.rgba_n), nullptr, base + L.query, stream, 1, 0, allow_pool)) return e;  // :1082, new samples
                 if (int e = rgba2out_merged(F(L.rgba_c), F(L.rgba_n), src, F(L.zf), n, Sc, Sf, F(L.color), F(L.depth), F(L.alpha), F(L.sdf), stream)) return e;
             } else {
                 kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
                               (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
-                if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1)) return e;  // :1082
+                if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1, 0, allow_pool)) return e;  // :1082
                 if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             }
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);

@@ -339,6 +339,17 @@ constexpr int kpn_cseg_boff(int seg) {
     return o;
 }
 constexpr int kpn_k2h_tail_off() { return kpn_cseg_boff(SEG_COUNT); }
+// layers2's Softplus(beta = 100) in LOG2 UNITS in the fp16 region, like layers1's in the rows kernels (KPN_H2_LOG2ACT below): a layer
+// whose OUTPUT is activated is packed times 100 log2(e) (weights and the bias copy), a layer whose INPUT is an activation times
+// ln(2) / 100; for layers2.1 the two cancel.  k_fuse_color_h's activation is then max(u, 0) + log2(1 + 2^-|u|): 3 instructions + 2
+// transcendentals per value instead of 7 + 2 (the natural-unit form multiplies three times and compares).
+// layers2.2's weights times ln(2) / 100 would sit near fp16's subnormal floor (2^-24 absolute against inputs of a few hundred log2
+// units): like layers1.3's stream (KPN_F16_ROW_SCALE) it is packed times 2^10 and the kernel multiplies its two outputs by 2^-10.
+#define KPN_F16_G22_SCALE 1024.0f
+constexpr float kpn_cseg_wfactor(int seg) {
+    return seg == SEG_G2_0 ? 144.269504088896341f : (seg == SEG_G2_2 ? 6.93147180559945309e-3f * KPN_F16_G22_SCALE : 1.0f);
+}
+constexpr float kpn_cseg_bfactor(int seg) { return (seg == SEG_G2_0 || seg == SEG_G2_1) ? 144.269504088896341f : (seg == SEG_G2_2 ? KPN_F16_G22_SCALE : 1.0f); }
 constexpr int kpn_k2h_floats() { return kpn_k2h_tail_off() + (kpn_fwd_floats() - kpn_scalar_off()) - kpn_k2h_base(); }
 // ---- the backward chains of layers1 with three bf16 pieces per weight (k_geo_rows_bwd), behind the per-point kernel's region ----
 // The forward segments SEG_G1_0A .. SEG_G1_2 (recomputed in the backward pass) and the transposed segments BSEG_G1_3T .. BSEG_G1_0T

@@ -52,6 +52,10 @@ __device__ __forceinline__ float kpn_softplus100(float x) {
     const float sp = kpn_log2(1.0f + kpn_exp2(x * 144.269504088896341f)) * 6.93147180559945309e-3f;  // ln2/100
     return (x * 100.0f > 20.0f) ? x : sp;
 }
+// the same activation on a pre-activation kept in log2 units, u = 100 log2(e) x (the packers fold the factors into the streams,
+// kpn_common.h kpn_cseg_wfactor / kpn_hseg_factor): 100 log2(e) softplus(x) = log2(1 + 2^u) = max(u, 0) + log2(1 + 2^-|u|).  Keeps a
+// NaN (2^-|NaN| is a NaN), never overflows (2^-|u| <= 1); beyond the reference's threshold branch the second term is below an ulp of u.
+__device__ __forceinline__ float kpn_softplus_log2(float u) { return fmaxf(u, 0.0f) + kpn_log2(1.0f + kpn_exp2(-fabsf(u))); }
 // sin and cos of y (radians), |y| up to a few hundred: quadrant reduction by a three-term Cody-Waite
 // split of pi/2 and degree-7/8 minimax polynomials on [-pi/4, pi/4] (about 1 ulp).  Register-light,
 // unlike the libm sincosf with its Payne-Hanek slow path, which made the keypoint encoding spill.

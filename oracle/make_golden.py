@@ -176,6 +176,55 @@ def run_tiled_case(net, name, n_views, src_hw, tar_hw, mask, level, Sc, Sf, seed
     print(f"{name}: frame {tuple(out['tex_fg_fine'].shape)} -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_real_encoder_case(net, name="case_s_v3_real_encoder_maps", src_hw=(128, 128), tar_hw=(32, 32), Sc=16, Sf=16, seed=31):
+    """render_pifu_nerf WITH the reference's own image encoders (HGFilterV2 / ResBlkEncoder, src/utils.py:199-474, reference init
+    of src/model.py:603-640) on structured source images (smooth shading + edges inside the fg masks, not white noise): the
+    feature maps the field kernels see here are what the encoders actually produce — spatially smooth, O(0.1) in magnitude,
+    channel-correlated — instead of the randn maps of every other fixture.  The maps the encoders returned are recorded in place
+    of the synthetic ones; the frame goes through the reference tile loop at level 1."""
+    scene = make_scene(n_views=3, src_hw=src_hw, tar_hw=tar_hw, mask="ellipsoid", seed=seed, tar_focal_at_512=800.0)
+    H, W = src_hw
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    fg = scene["src_foreground_mask"].reshape(3, 1, H, W).float()
+    base = torch.stack([0.5 + 0.4 * torch.sin(6.0 * xx + 2.0 * yy), 0.5 + 0.4 * torch.cos(5.0 * yy - xx), 0.3 + 0.5 * xx * yy], 0)
+    stripes = ((torch.floor(12.0 * xx) + torch.floor(9.0 * yy)) % 2.0) * 0.25
+    img = torch.stack([(base.roll(7 * v, dims=2) * (0.7 + 0.1 * v) + stripes).clamp(0, 1) for v in range(3)], 0) * fg   # fg-masked like the dataset's
+    scene["img"] = img
+    got = {}
+    cls = type(net)
+
+    def geo(im, return_val=False):
+        r = cls.attach_geo_feat(net, im, return_val)
+        got["geo"] = [x.detach().clone() for x in net.feat_geo]
+        return r
+
+    def tex(im, return_val=False):
+        r = cls.attach_tex_feat(net, im, return_val)
+        got["tex"] = net.feat_tex.detach().clone()
+        return r
+
+    net.attach_geo_feat, net.attach_tex_feat = geo, tex
+    try:
+        with torch.no_grad():
+            out = net.render_pifu_nerf(net, scene["img"], scene["cam"], scene["cam_tar"], level=1, sp_data=dict(scene["sp_data"]),
+                                       fine=True, uniform=True, sample_per_ray_c=Sc, sample_per_ray_f=Sf,
+                                       src_foreground_mask=scene["src_foreground_mask"], bounds=scene["bounds"])
+    finally:
+        del net.__dict__["attach_geo_feat"], net.__dict__["attach_tex_feat"]
+    scene["feat_geo"], scene["feat_tex"] = got["geo"], got["tex"]
+    d = scene_to_npz(scene)
+    d["cfg"] = np.array([3, 1, 0, 0, Sc, Sf], np.int64)
+    d["tar_focal_at_512"] = np.float64(800.0)
+    for k, v in out.items():
+        d["out." + k] = _np(v)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **d)
+    st = lambda t: f"|max| {float(t.abs().max()):.3f} std {float(t.std()):.3f}"
+    print(f"{name}: frame {tuple(out['tex_fg_fine'].shape)} alpha mean {float(out['alpha_fine'].mean()):.3f}; encoder maps: geo0 {tuple(got['geo'][0].shape)} "
+          f"{st(got['geo'][0])}, geo1 {tuple(got['geo'][1].shape)} {st(got['geo'][1])}, tex {tuple(got['tex'].shape)} {st(got['tex'])} -> {path} "
+          f"({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def run_train_case(net, name, n_views, src_hw, tar_hw, mask, Sc, Sf, seed, patch=12, noise_std=0.01):
     """TRAIN branch of batch_render_pifu_nerf (reference src/model.py:1008-1017,1049-1053,993-994,742-748,1129)
     with every random draw recorded: torch.rand_like / randn_like / rand are wrapped for the duration of the call,
@@ -527,6 +576,9 @@ def main():
     if "--only-headline" in sys.argv:
         run_headline_cases(net)
         return
+    if "--only-real-encoders" in sys.argv:
+        run_real_encoder_case(net)
+        return
     sd = {k: _np(v) for k, v in net.state_dict().items() if k.startswith(HOT_PREFIXES)}
     np.savez_compressed(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"), **sd)
     print("weights:", sum(v.size for v in sd.values()), "floats")
@@ -552,6 +604,7 @@ def main():
     run_sigma_nofine_case(net)
     run_headline_cases(net)
     run_loss_case()
+    run_real_encoder_case(net)
 
 
 def run_headline_cases(net):
