@@ -154,6 +154,50 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True, frame=None):
     return base, parity
 
 
+def clock_telemetry(run_once, torch, seconds=2.0):
+    """Shader clock and board power while the headline workload runs (AFTER the timed region, same plan): sysfs pp_dpm_sclk
+    (the level marked '*') and hwmon power sampled every 20 ms from a thread while `run_once` is repeated for about `seconds`.
+    The chip clocks to its power budget (MI355X_MICROARCH.md, DVFS): a roofline fraction quoted against the 2.4 GHz peak
+    understates what the kernel does per cycle.  Best effort: None when the files are not there."""
+    import glob
+    import threading
+    sclk_files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    pow_files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or \
+        sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+    if not sclk_files:
+        return None
+    sclk, power, stop = [], [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            try:
+                for line in open(sclk_files[0]).read().splitlines():
+                    if "*" in line:
+                        sclk.append(float(line.split(":")[1].replace("Mhz", "").replace("MHz", "").replace("*", "").strip()))
+                if pow_files:
+                    power.append(float(open(pow_files[0]).read().strip()) * 1e-6)
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(0.02)
+
+    th = threading.Thread(target=sample, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        run_once()
+        torch.cuda.synchronize()
+        n += 1
+    stop.set()
+    th.join(timeout=1.0)
+    if not sclk:
+        return None
+    sclk.sort()
+    return {"sclk_mhz_median": sclk[len(sclk) // 2], "sclk_mhz_min": sclk[0], "sclk_mhz_max": sclk[-1], "samples": len(sclk),
+            "power_w_mean": (sum(power) / len(power)) if power else None, "frames": n,
+            "source": "sysfs pp_dpm_sclk / hwmon power, 20 ms period, while the headline frame is rendered repeatedly after the timed region"}
+
+
 def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1, with_kernel=False):
     """ms per frame + valid (point, view) rows per frame of one more workload (secondary results)."""
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
@@ -240,20 +284,21 @@ def time_configs4(L, ops, torch, dev, sd, mode, with_parity=True):
     return r
 
 
-def time_training(ops, torch, dev, sd, steps=10):
-    """BASELINE configs[3], field part: train-branch forward + backward in HIP for 1024 rays x (64 + 128) samples, V=3
+def time_training(ops, torch, dev, sd, steps=10, patch=32):
+    """BASELINE configs[3], field part: train-branch forward + backward in HIP for patch x patch rays x (64 + 128) samples, V=3
     (kpn_render_rays_train + kpn_render_rays_train_backward), inputs resident, random draws prepared outside the timed
-    region.  Returns ms per forward and per backward."""
+    region.  patch = 32: 1024 rays (BASELINE configs[3]); 64: the reference's shipped patch (configs/zju.json:36-37).
+    Returns ms per forward and per backward."""
     from keypointnerf_amd.synthetic import make_scene, to_device
     scene = to_device(make_scene(n_views=3, src_hw=(512, 512), tar_hw=(512, 512), mask="ellipsoid", seed=1,
                                  tar_focal_at_512=800.0), dev)
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
                            scene["src_foreground_mask"])
     w = ops.PackedWeights(sd, device=dev)
-    R, Sc, Sf = 1024, 64, 64
+    R, Sc, Sf = patch * patch, 64, 64
     g = torch.Generator(device=dev).manual_seed(0)
-    yy, xx = torch.meshgrid(torch.arange(32, device=dev), torch.arange(32, device=dev), indexing="ij")
-    pix = torch.stack([xx.reshape(-1) + 240, yy.reshape(-1) + 240], -1).to(torch.int32)
+    yy, xx = torch.meshgrid(torch.arange(patch, device=dev), torch.arange(patch, device=dev), indexing="ij")
+    pix = torch.stack([xx.reshape(-1) + 256 - patch // 2, yy.reshape(-1) + 256 - patch // 2], -1).to(torch.int32)
     u_c, u_f = torch.rand(R, Sc, device=dev, generator=g), torch.rand(R, Sf, device=dev, generator=g)
     n_c, n_f = torch.randn(R * Sc, device=dev, generator=g), torch.randn(R * (Sc + Sf), device=dev, generator=g)
     grads = {"tex_fg": torch.randn(1, 3, R, device=dev, generator=g) / R, "tex_fg_fine": torch.randn(1, 3, R, device=dev, generator=g) / R}
@@ -275,7 +320,8 @@ def time_training(ops, torch, dev, sd, steps=10):
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / steps * 1e3
     out["iterations_per_sec"] = 1e3 / (out["forward_ms"] + out["backward_ms"])
-    out["workload"] = ("configs[3] field part: 1024 rays x (64 coarse + 128 fine-pass) evaluations, V=3, view dropout + density noise, "
+    out["rays_per_sec"] = R * out["iterations_per_sec"]
+    out["workload"] = (f"configs[3] field part: {R} rays x (64 coarse + 128 fine-pass) evaluations, V=3, view dropout + density noise, "
                        "fwd (kpn_render_rays_train_keep) + bwd (kpn_render_rays_train_backward_kept) in HIP")
     return out
 
@@ -383,6 +429,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    telemetry = clock_telemetry(lambda: step(args.warmup), torch) if (world == 1 and not args.no_secondary) else None
     # the frame of the last timed step, for the comparison with the oracle further down (world 1: rank 0's own camera)
     frame_np = {k: v[0].cpu().numpy() for k, v in out.items() if k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")} if (world == 1 and rank == 0) else None
     gather_ms = None
@@ -479,6 +526,10 @@ def main():
                                  "`launches` / `avg_launch_ms` cover the launches that processed rows, a rocprofv3 average "
                                  "over ALL k_geo_rows launches is lower by the factor launches / (launches + surplus_launches)",
                          "algorithmic_flop_per_row": flops_row,
+                         # what the chip clocked at under this load, and the fraction against the roof at THAT clock (the peaks of
+                         # MI355X_MICROARCH.md are quoted at 2.4 GHz)
+                         "clock": telemetry,
+                         "frac_at_sustained_clock": (achieved / (peak * telemetry["sclk_mhz_median"] / 2400.0)) if telemetry else None,
                          "kernel_time_share": (ms.value * 1e-3) / dt},
         }
         if world == 1 and not args.no_secondary:
@@ -516,6 +567,7 @@ def main():
                                          "unit": "TFLOP/s", "frac": ktf / rows_peak_tflops(m), "avg_launch_ms": kms}}
             if args.views == 3:
                 sec["training_step_configs3"] = time_training(ops, torch, dev, sd)
+                sec["training_step_4096"] = time_training(ops, torch, dev, sd, steps=5, patch=64)   # the reference's shipped 64 x 64 patch
             if not args.no_configs4 and res == 512 and fine:       # next to the headline only
                 del plan, ps, scene
                 torch.cuda.empty_cache()

@@ -479,10 +479,22 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         KPN_FUSE_STAMP(1);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
         float sdf_raw, rad;
+        kpn_u32x4 pooled_h[F16 ? 8 : 1], pooled_l[F16 ? 8 : 1];
         {
             kpn_f32x16 h0[2], h1[2], o2[1];
             kpn_load_bias<2>(wl + W::boff(SEG_G2_0), h, h0);
-            kpn_fuse_layer_regs<F16, SEG_G2_0, 64, 2>(wl, lane, pooled, h0);
+            if constexpr (F16) {   // the pooled vector is split once for layers2.0 and the compress layer below
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float x8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x8[i] = pooled[8 * c + i];
+                    kpn_split_f16x8(x8, pooled_h[c], pooled_l[c]);
+                }
+                kpn_hlayer_presplit<8, 2>(wl + W::woff(SEG_G2_0), lane, pooled_h, pooled_l, h0);
+            } else {
+                kpn_fuse_layer_regs<F16, SEG_G2_0, 64, 2>(wl, lane, pooled, h0);
+            }
             kpn_load_bias<2>(wl + W::boff(SEG_G2_1), h, h1);
             kpn_fuse_layer<F16, SEG_G2_1, 32, 2>(wl, lane, [&](auto gi, float (&x)[4]) {
                 constexpr int g = decltype(gi)::value;
@@ -521,7 +533,8 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         {
             kpn_f32x16 acc[1];
             kpn_load_bias<1>(wl + W::boff(SEG_CMP), h, acc);
-            kpn_fuse_layer_regs<F16, SEG_CMP, 64, 1>(wl, lane, pooled, acc);
+            if constexpr (F16) kpn_hlayer_presplit<8, 1>(wl + W::woff(SEG_CMP), lane, pooled_h, pooled_l, acc);
+            else kpn_fuse_layer_regs<F16, SEG_CMP, 64, 1>(wl, lane, pooled, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }

@@ -694,50 +694,45 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             }
         } else {
             // Weighted Welford update of the pooled statistics with this view's rows x (weight w = the view's boundary-smooth
-            // weight, un-normalised): W += w, d = x - mean, mean += (w / W) d, M2 += w d (x - mean).  The last kept view
-            // finishes: the reference normalises the weights by (sum + 1e-6) (model.py:759), so with S = sum w, s = S / (S + 1e-6):
-            //     mean_ref = s mu,   var_ref = sum_v pw_v (x_v - mean_ref)^2 = (M2 + S (mu (1 - s))^2) / (S + 1e-6)
+            // weight, un-normalised; X = 2^10 x in the fp16 scheme, unscaled at the end):
+            //     W' = W + w,  r = w / W',  d = X - mean,  mean' = mean + r d,  M2' = M2 + w (1 - r) d^2      (4 instructions per value)
+            // The last kept view finishes: the reference normalises the weights by (sum + 1e-6) (model.py:759), so with S = sum w,
+            //     mean_ref = mu S / (S + 1e-6),   var_ref = sum_v pw_v (x_v - mean_ref)^2 = M2 / (S + 1e-6)  [+ S (mu 1e-6 / (S + 1e-6))^2 / (S + 1e-6):
+            //     twelve orders below mu^2, dropped]
             const bool last_view = (keep_bits >> (v + 1)) == 0u;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float w = wview[t];
                 const float wn = wsum[t] + w;
                 const float r = wn > 0.0f ? w / wn : 0.0f;
-                const float inv = 1.0f / (wn + 1e-6f), s_ = wn * inv, om = 1e-6f * inv;
+                const float c = w * (1.0f - r);
+                const float inv = 1.0f / (wn + 1e-6f);
+                const float ms = wn * inv * SC::out_down, vs = inv * (SC::out_down * SC::out_down);   // exact powers of two folded in
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         const int slab = 8 * t + 4 * b + qd;
-                        float x[4], mu[4], m2[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] = acc[t][b][4 * qd + e] * SC::out_down;
+                        float mu[4], m2[4];
                         if (first_view) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { mu[e] = x[e]; m2[e] = 0.0f; }
+                            for (int e = 0; e < 4; ++e) { mu[e] = acc[t][b][4 * qd + e]; m2[e] = 0.0f; }
                         } else {
-                            const float4 a = pst[slab * 64], c = pst[(16 + slab) * 64];
-                            const float am[4] = {a.x, a.y, a.z, a.w}, cm[4] = {c.x, c.y, c.z, c.w};
+                            const float4 a = pst[slab * 64], cc = pst[(16 + slab) * 64];
+                            const float am[4] = {a.x, a.y, a.z, a.w}, cm[4] = {cc.x, cc.y, cc.z, cc.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float d = x[e] - am[e];
+                                const float d = acc[t][b][4 * qd + e] - am[e];
                                 mu[e] = fmaf(r, d, am[e]);
-                                m2[e] = fmaf(w * d, x[e] - mu[e], cm[e]);
+                                m2[e] = fmaf(c * d, d, cm[e]);
                             }
                         }
                         if (!last_view) {
                             pst[slab * 64] = make_float4(mu[0], mu[1], mu[2], mu[3]);
                             pst[(16 + slab) * 64] = make_float4(m2[0], m2[1], m2[2], m2[3]);
                         } else if (t == 0 || has1) {
-                            float mr[4], vr[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                mr[e] = mu[e] * s_;
-                                const float dm = mu[e] * om;
-                                vr[e] = fmaxf(fmaf(wn * dm, dm, m2[e]) * inv, 0.0f);
-                            }
-                            dst[t][(4 * b + qd) * 64] = make_float4(mr[0], mr[1], mr[2], mr[3]);
-                            dst[t][(8 + 4 * b + qd) * 64] = make_float4(vr[0], vr[1], vr[2], vr[3]);
+                            dst[t][(4 * b + qd) * 64] = make_float4(mu[0] * ms, mu[1] * ms, mu[2] * ms, mu[3] * ms);
+                            dst[t][(8 + 4 * b + qd) * 64] = make_float4(m2[0] * vs, m2[1] * vs, m2[2] * vs, m2[3] * vs);
                         }
                     }
                 wsum[t] = wn;

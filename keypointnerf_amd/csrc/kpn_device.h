@@ -340,6 +340,24 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
         }
     });
 }
+// the same layer with B operands that are ALREADY split (one kpn_split_f16x8 per chunk, shared by several layers that consume the
+// same vector: layers2.0 and ibr_compress_gfeat both take the pooled 128-vector)
+template <int NC, int NOB>
+__device__ __forceinline__ void kpn_hlayer_presplit(const float* __restrict__ wseg, int lane, const kpn_u32x4 (&bh)[NC], const kpn_u32x4 (&bl)[NC],
+                                                    kpn_f32x16 (&acc)[NOB]) {
+    const kpn_lptr4 base = KPN_LDS4(wseg) + lane;
+    kpn_static_for<0, NC>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
+            acc[ob] = kpn_mfma_f16(ah, bh[c], acc[ob]);
+            acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]);
+            acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]);
+            acc[ob] = kpn_mfma_f16(al, bl[c], acc[ob]);
+        }
+    });
+}
 template <int KS, int NOB, int NSRC>
 __device__ __forceinline__ void kpn_hlayer_regs(const float* __restrict__ wseg, int lane, const float (&src)[NSRC], kpn_f32x16 (&acc)[NOB]) {
     static_assert(NSRC >= KS, "operand array too short");

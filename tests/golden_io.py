@@ -7,6 +7,9 @@ import torch
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["case_a_v3_ellipsoid", "case_b_v4_dense_tile", "case_c_v3_offaxis"]
 TILED_CASE = "case_d_v3_tiled_frame"
+# render_pifu_nerf of the reference WITH its own image encoders (reference init) on structured source images: the feature maps in
+# this fixture are what HGFilterV2 / ResBlkEncoder produced (oracle/make_golden.py::run_real_encoder_case)
+REAL_ENCODER_CASE = "case_s_v3_real_encoder_maps"
 
 
 def load_weights():

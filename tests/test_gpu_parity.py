@@ -216,6 +216,28 @@ def test_full_frame_equals_reference_tiles(ops, golden_weights):
         assert np.abs(out[k][0].cpu().numpy().reshape(g["out." + k].shape) - g["out." + k]).max() <= RGBA_TOL, k
 
 
+@pytest.mark.parametrize("rows_mode,fuse_mode", [(3, 1), (2, 0), (0, 0)])
+def test_frame_from_real_encoder_maps_vs_reference(ops, golden_weights, rows_mode, fuse_mode):
+    """Golden case S: the reference's render_pifu_nerf with its OWN image encoders (HGFilterV2 / ResBlkEncoder, reference init) on
+    structured source images.  Until round 4 no HIP kernel had seen a feature map an encoder produced (every GPU input was randn):
+    these maps are smooth, channel-correlated and O(0.1 - 1) — the default two-fp16-piece kernels and both fp32-range kernel sets
+    against the reference's frame, and the range guard must not have had to take over."""
+    from tests.golden_io import REAL_ENCODER_CASE
+    scene, cfg, g = load_case(REAL_ENCODER_CASE)
+    s, ps = _prep(ops, scene)
+    H, W = s["cam_tar"]["height"], s["cam_tar"]["width"]
+    rm, fm = ops.get_geo_rows_mode(), ops.get_fuse_mode()
+    ops.set_geo_rows_mode(rows_mode); ops.set_fuse_mode(fuse_mode)
+    try:
+        c0 = ops.range_guard_count()
+        out = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=(0, 0, 1, W, H), n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+        for k in ("tex_fg", "tex_fg_fine", "alpha", "alpha_fine"):
+            assert np.abs(out[k][0].cpu().numpy().reshape(g["out." + k].shape) - g["out." + k]).max() <= RGBA_TOL, k
+        assert ops.range_guard_count() == c0
+    finally:
+        ops.set_geo_rows_mode(rm); ops.set_fuse_mode(fm)
+
+
 @pytest.mark.parametrize("n_views,mask,src_hw,tar_hw,Sc,Sf", [(3, "ellipsoid", (128, 128), (64, 64), 32, 32),   # C1-like
                                                             (1, "dense", (64, 96), (24, 20), 16, 16),
                                                             (10, "dense", (64, 64), (20, 24), 12, 20),   # C5's view count

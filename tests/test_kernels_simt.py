@@ -719,3 +719,15 @@ def test_range_guard_of_the_fp16_kernels(env):
         finally:
             lib.check(lib.kpn_set_range_guard(1))
         assert not all(np.isfinite(v).all() for v in raw.values()), name
+
+
+def test_frame_from_real_encoder_maps(env):
+    """Golden case S (the reference's frame from the maps its own encoders produced): the kernels on the emulator, default modes."""
+    from tests.golden_io import REAL_ENCODER_CASE
+    lib, packed, _ = env
+    scene, cfg, g = load_case(REAL_ENCODER_CASE)
+    hs = sh.HostScene(lib, scene)
+    H, W = scene["cam_tar"]["height"], scene["cam_tar"]["width"]
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, W, H), cfg["Sc"], cfg["Sf"])
+    for k in ("tex_fg", "tex_fg_fine", "alpha", "alpha_fine"):
+        assert np.abs(o[k] - g["out." + k].reshape(o[k].shape)).max() < 5e-5, k

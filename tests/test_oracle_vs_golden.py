@@ -333,3 +333,23 @@ def test_train_render_backward_composition_vs_reference_autograd(case):
                                             g["noise_c"], g["noise_f"], g["u_f"], keep_bits(g["keep_c"]), keep_bits(g["keep_f"]),
                                             float(g["noise_std"]), grads)
     assert_train_grads_vs_golden(list(got), g, sd, 5e-5)
+
+
+def test_frame_from_real_encoder_maps_vs_reference():
+    """Golden case S: the reference's render_pifu_nerf with its OWN encoders (HGFilterV2 / ResBlkEncoder at the reference's init)
+    on structured source images; the recorded maps are spatially smooth, channel-correlated, |max| 0.9 / 3.4 / 5.9 — not the
+    randn maps of the other fixtures.  The oracle on those maps reproduces the reference's frame."""
+    from tests.golden_io import REAL_ENCODER_CASE
+    scene, cfg, g = load_case(REAL_ENCODER_CASE)
+    g0 = scene["feat_geo"][0].numpy()
+    assert np.abs(np.diff(g0, axis=-1)).mean() < 0.5 * g0.std()            # smooth in space (randn: 1.13 sigma)
+    osc, wflat = oracle.OracleScene(scene), oracle.flat_weights(load_weights())
+    H, W = scene["cam_tar"]["height"], scene["cam_tar"]["width"]
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
+    out = oracle.render_rays(osc, wflat, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"])
+    assert 0.1 < float(out["alpha_fine"].mean()) < 0.9
+    for k in ("tex_fg", "tex_fg_fine"):
+        assert np.abs(out[k] - g["out." + k].reshape(3, -1).T).max() < 2e-5, k
+    for k in ("alpha", "alpha_fine", "depth_fine"):
+        assert np.abs(out[k] - g["out." + k].reshape(-1)).max() < 2e-5, k
