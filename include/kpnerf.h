@@ -228,7 +228,12 @@ typedef struct kpn_render_args {
     int32_t step_y;             /* 0: rows advance by `step` like the columns (the reference's grids); > 0: py = y0 + iy*step_y —
                                  * one frame's rows dealt round-robin to the ranks of a render job (rank r of W: y0 = r,
                                  * step_y = W), SURVEY 8(e) */
+    int32_t rows_kernel;        /* KPN_ROWS_*: the rows kernel of THIS call; 0 = the process-wide selection (kpn_set_geo_rows_mode) */
+    int32_t fuse_kernel;        /* KPN_FUSE_*: the per-point kernel of THIS call; 0 = the process-wide selection (kpn_set_fuse_mode) */
 } kpn_render_args;
+/* per-call kernel selection (kpn_render_args): the same kernels as kpn_set_geo_rows_mode(0 / 2 / 3) and kpn_set_fuse_mode(0 / 1) */
+enum { KPN_ROWS_DEFAULT = 0, KPN_ROWS_F32 = 1, KPN_ROWS_BF16X3 = 2, KPN_ROWS_F16X2 = 3 };
+enum { KPN_FUSE_DEFAULT = 0, KPN_FUSE_F32 = 1, KPN_FUSE_F16X2 = 2 };
 
 /* Note on the fine pass: z_fine = sort(cat(z_coarse, z_new)) (src/model.py:1076) repeats the coarse samples; their field
  * values are taken from the coarse pass and the field is evaluated at the new samples only — identical points, identical

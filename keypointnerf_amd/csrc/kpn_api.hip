@@ -916,12 +916,16 @@ void launch_fuse(int fmode, const kpn_scene_dev& sc, const kpn_points& ps, const
         KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
 }
 
+// rows_sel / fuse_sel: KPN_ROWS_* / KPN_FUSE_* of kpn_render_args (0 = the process-wide selection)
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
-              uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0, int allow_pool = 0) {
+              uint8_t* valid, void* ws, void* stream, int lean = 0, int keep_rows = 0, int allow_pool = 0, int rows_sel = 0, int fuse_sel = 0) {
     // POOL layout of the scratch (kpn_field_shared.h): the pair-tile rows kernels pool over the views themselves — the eval render
     // passes and kpn_query; never when a backward pass reads the per-view rows again, never in the train branch (whose kept and
     // not-kept forward must stay bit-identical)
-    const int pool = (allow_pool && !keep_rows && out && pool_layout_selected()) ? 1 : 0;
+    const int rmode = rows_sel == KPN_ROWS_F32 ? 0 : (rows_sel == KPN_ROWS_BF16X3 ? 2 : (rows_sel == KPN_ROWS_F16X2 ? 3 : geo_rows_mode()));
+    const int fmode = !out ? 0 : (fuse_sel == KPN_FUSE_F32 ? 0 : (fuse_sel == KPN_FUSE_F16X2 ? 1 : fuse_mode()));
+    // (the workspace is laid out for the process-wide selection: a per-call rows kernel without the POOL layout uses the ROWS one)
+    const int pool = (allow_pool && !keep_rows && out && pool_layout_selected() && rmode >= 2) ? 1 : 0;
     const QueryLayout L = query_layout(N, sc.V, pool != 0);
     char* base = static_cast<char*>(ws);
     int* count = reinterpret_cast<int*>(base + L.count);
@@ -931,7 +935,6 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     const int ppt = mask_points_per_thread(N);
     KPN_LAUNCH(k_mask_compact, grid1d(N, 256 * ppt), dim3(256), stream, sc, ps, N, mode, lean, ppt, wp + kpn_scalar_off(), out, valid, list, count);
     if (keep_rows && L.nbatch > 1) return fail(KPN_EWORKSPACE, "a pass whose rows a backward call reads again must fit the row scratch");
-    const int rmode = geo_rows_mode(), fmode = out ? fuse_mode() : 0;
     // which launches stand under the range guard: the two-fp16-piece ones; `redo`: the fp32-range pair behind them
     const bool guard = range_guard() && out && (rmode == 3 || fmode == 1);
     int* redone = guard ? redone_counter() : nullptr;
@@ -1386,6 +1389,7 @@ int check_render(const kpn_render_args* a) {
     KPN_REQUIRE(a != nullptr, "render args null");
     KPN_REQUIRE(a->K && a->RT && a->bounds, "null camera/bounds");
     KPN_REQUIRE(a->nx > 0 && a->ny > 0 && a->step > 0 && a->step_y >= 0, "bad pixel grid");
+    KPN_REQUIRE(a->rows_kernel >= 0 && a->rows_kernel <= KPN_ROWS_F16X2 && a->fuse_kernel >= 0 && a->fuse_kernel <= KPN_FUSE_F16X2, "bad kernel selection");
     KPN_REQUIRE(a->n_coarse >= 3 && a->n_coarse <= 128, "sample_per_ray_c must be in [3,128]");
     KPN_REQUIRE(!a->fine || (a->n_fine >= 1 && a->n_fine <= 128), "sample_per_ray_f must be in [1,128]");
     KPN_REQUIRE((int64_t)a->nx * a->ny < (1ll << 31), "too many rays");
@@ -1457,7 +1461,7 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
         const bool reuse = (t == nullptr) && a->fine && !no_reuse;
         float* rgba_coarse = reuse ? F(L.rgba_c) : F(L.rgba);
         const int allow_pool = t == nullptr;   // eval: pooled inside the rows kernel; the train branch keeps the per-view rows
-        if (int e = run_field(sc, ps, wp, n * Sc, 1, rgba_coarse, nullptr, base + L.query, stream, 1, 0, allow_pool)) return e;   // model.py:1062
+        if (int e = run_field(sc, ps, wp, n * Sc, 1, rgba_coarse, nullptr, base + L.query, stream, 1, 0, allow_pool, a->rows_kernel, a->fuse_kernel)) return e;   // model.py:1062
         if (int e = kpn_rgba2out(rgba_coarse, F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
@@ -1470,12 +1474,12 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
             sc.keep = t ? t->keep_fine : 0xFFFFFFFFu;
             if (reuse) {
                 kpn_points pn{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zn), Sf, nullptr, 0.0f};
-                if (int e = run_field(sc, pn, wp, n * Sf, 1, F(L.rgba_n), nullptr, base + L.query, stream, 1, 0, allow_pool)) return e;  // :1082, new samples
+                if (int e = run_field(sc, pn, wp, n * Sf, 1, F(L.rgba_n), nullptr, base + L.query, stream, 1, 0, allow_pool, a->rows_kernel, a->fuse_kernel)) return e;  // :1082, new samples
                 if (int e = rgba2out_merged(F(L.rgba_c), F(L.rgba_n), src, F(L.zf), n, Sc, Sf, F(L.color), F(L.depth), F(L.alpha), F(L.sdf), stream)) return e;
             } else {
                 kpn_points pf{nullptr, nullptr, F(L.cam_pos), dirs, F(L.zf), Sfull,
                               (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
-                if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1, 0, allow_pool)) return e;  // :1082
+                if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1, 0, allow_pool, a->rows_kernel, a->fuse_kernel)) return e;  // :1082
                 if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
             }
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);

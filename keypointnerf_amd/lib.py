@@ -38,7 +38,7 @@ class RenderArgs(ctypes.Structure):
     """struct kpn_render_args"""
     _fields_ = [(n, c_p) for n in ("K", "RT", "bounds")] + [("znear", c_f), ("zfar", c_f)] + \
                [(n, c_i32) for n in ("x0", "y0", "step", "nx", "ny", "n_coarse", "n_fine", "fine", "chunk_rays")] + \
-               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")] + [("step_y", c_i32)]
+               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")] + [("step_y", c_i32), ("rows_kernel", c_i32), ("fuse_kernel", c_i32)]
 
 
 class TrainArgs(ctypes.Structure):

@@ -324,7 +324,9 @@ def query_backward(scene, weights, pts, view, d_out, mode=1, keep_mask=0xFFFFFFF
 class RenderPlan:
     """Pre-allocated outputs + workspace for repeated renders of one pixel grid (no per-call allocation)."""
 
-    def __init__(self, scene, grid, n_coarse, n_fine, fine=True, chunk_rays=0, device=None):
+    def __init__(self, scene, grid, n_coarse, n_fine, fine=True, chunk_rays=0, device=None, rows_kernel=None, fuse_kernel=None):
+        """rows_kernel / fuse_kernel: the kernels of the calls made with THIS plan ("f32" / "bf16x3" / "f16x2", "f32" / "f16x2";
+        None = the process-wide selection of set_geo_rows_mode / set_fuse_mode) — include/kpnerf.h kpn_render_args."""
         L = kl.get_library()
         # grid = (x0, y0, step, nx, ny) as the reference's strided grids, or (x0, y0, step, nx, ny, step_y): rows advance by step_y
         # (a frame's rows dealt round-robin to the ranks of a render job: parallel.rows_of_rank)
@@ -342,6 +344,8 @@ class RenderPlan:
         a = kl.RenderArgs()
         a.x0, a.y0, a.step, a.nx, a.ny, a.step_y = x0, y0, step, nx, ny, step_y
         a.n_coarse, a.n_fine, a.fine, a.chunk_rays = int(n_coarse), int(n_fine), int(bool(fine)), int(chunk_rays)
+        a.rows_kernel = {None: 0, "f32": 1, "bf16x3": 2, "f16x2": 3}[rows_kernel]
+        a.fuse_kernel = {None: 0, "f32": 1, "f16x2": 2}[fuse_kernel]
         for k, v in self.out.items():
             setattr(a, k, v.data_ptr())
         self.args = a

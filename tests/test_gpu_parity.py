@@ -753,6 +753,28 @@ def test_fuse_kernel_modes(ops, golden_weights):
         ops.set_fuse_mode(default_fuse)
 
 
+def test_per_call_kernel_selection(ops, golden_weights):
+    """kpn_render_args.rows_kernel / fuse_kernel select the kernels of ONE call (ops.RenderPlan(rows_kernel=, fuse_kernel=)): the
+    frame is bit-identical to the one rendered with the same kernels selected process-wide, and the process-wide selection is
+    left alone."""
+    scene, cfg, g = load_case(CASES[0])
+    s, ps = _prep(ops, scene)
+    H, W = s["cam_tar"]["height"], s["cam_tar"]["width"]
+    rm, fm = ops.get_geo_rows_mode(), ops.get_fuse_mode()
+    grid = (0, 0, 1, W, H)
+    for rk, fk, rmode, fmode in (("f32", "f32", 0, 0), ("bf16x3", "f32", 2, 0), ("f16x2", "f16x2", 3, 1), ("bf16x3", "f16x2", 2, 1)):
+        plan = ops.RenderPlan(ps, grid, cfg["Sc"], cfg["Sf"], rows_kernel=rk, fuse_kernel=fk)
+        a = {k: v.clone() for k, v in ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], plan=plan).items()}
+        assert (ops.get_geo_rows_mode(), ops.get_fuse_mode()) == (rm, fm)
+        ops.set_geo_rows_mode(rmode); ops.set_fuse_mode(fmode)
+        try:
+            b = ops.render_rays(ps, golden_weights[1], s["cam_tar"], s["bounds"], grid=grid, n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+            for k in a:
+                assert torch.equal(a[k], b[k]), (rk, fk, k)
+        finally:
+            ops.set_geo_rows_mode(rm); ops.set_fuse_mode(fm)
+
+
 def test_default_rows_kernel_soak(ops, golden_weights):
     """A short version of scripts/soak_mode2.py inside the suite: 2,000,000 random points x 3 views evaluated 41 times with the
     default rows kernel (2.5e8 row evaluations, about a second) — every repeat bit-identical to the first, and the first within
