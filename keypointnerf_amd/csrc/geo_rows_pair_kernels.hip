@@ -408,8 +408,11 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
     __shared__ __attribute__((aligned(16))) float bias_s[4][128];
     // POOL: the Welford state of this wave's tile pair, [32 slabs][64 lanes] float4: slabs 0..15 running mean (tile t, block b,
     // quad q -> slab 8 t + 4 b + q), 16..31 the weighted squared deviations.  Lane-private: no synchronisation.
-    __shared__ __attribute__((aligned(16))) float4 pool_s[POOL ? 4 * 32 * 64 : 1];
-    float4* const pst = pool_s + (POOL ? ((threadIdx.x >> 6) * 32 * 64 + lane) : 0);
+    // Slabs 32, 33: the two points (x, y, z) + their weight sums so far; slab 34: this view's weights — values that live across the
+    // whole view would otherwise sit in VGPRs through the four layers (the kernel is at the 256-register limit: held in registers
+    // they came back as scratch reloads in the epilogue, 7 k cycles per view).
+    __shared__ __attribute__((aligned(16))) float4 pool_s[POOL ? 4 * 35 * 64 : 1];
+    float4* const pst = pool_s + (POOL ? ((threadIdx.x >> 6) * 35 * 64 + lane) : 0);
     {
         const int segs[4] = {SEG_G1_0A, SEG_G1_1, SEG_G1_2, SEG_G1_3};
         for (int i = threadIdx.x; i < 4 * 128; i += blockDim.x) {
@@ -459,17 +462,24 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
 #pragma unroll
         for (int t = 0; t < 2; ++t) kpn_point_finish(ps, nx_raw[t], P[t], D[t]);
         bool prefetched = false;                           // the next item's ticket / list / points: under the first computed view
-        float wsum[2] = {0.0f, 0.0f};                      // POOL: the views' weights so far
         bool first_view = true;
+        if constexpr (POOL) {                              // the points and the (zero) weight sums wait in LDS between the views
+            pst[32 * 64] = make_float4(P[0][0], P[0][1], P[0][2], 0.0f);
+            pst[33 * 64] = make_float4(P[1][0], P[1][1], P[1][2], 0.0f);
+        }
       for (int v = v_begin; v < v_end; ++v) {
         const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+        if constexpr (POOL) {
+            const float4 p0 = pst[32 * 64], p1 = pst[33 * 64];
+            P[0][0] = p0.x; P[0][1] = p0.y; P[0][2] = p0.z; P[1][0] = p1.x; P[1][1] = p1.y; P[1][2] = p1.z;
+        }
         kpn_proj q[2];
         float4* dst[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tr = 2 * pair + t;
             q[t] = kpn_project(tb, P[t][0], P[t][1], P[t][2], sc);
-            dst[t] = reinterpret_cast<float4*>(xscr) + (POOL ? lay.tile(tr) : lay.row(tr, v)) * 64 + lane;
+            if constexpr (!POOL) dst[t] = reinterpret_cast<float4*>(xscr) + lay.row(tr, v) * 64 + lane;
         }
         if (!((sc.keep >> v) & 1u)) {                      // a dropped view: zero rows (its gather records: k_row_records)
             if constexpr (!POOL) {
@@ -482,9 +492,11 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             }
             continue;                                      // (POOL: weight 0 in the pooling, nothing to do)
         }
-        float wview[2] = {0.0f, 0.0f};                     // POOL: this view's boundary-smooth weight of the two points (model.py:752-758)
-        if constexpr (POOL) { wview[0] = kpn_pix_weight(q[0]); wview[1] = kpn_pix_weight(q[1]); }
-        const bool pf = SC::PREFETCH && !prefetched;
+        // POOL: this view's boundary-smooth weight of the two points (model.py:752-758), parked in LDS until the epilogue
+        if constexpr (POOL) pst[34 * 64] = make_float4(kpn_pix_weight(q[0]), kpn_pix_weight(q[1]), 0.0f, 0.0f);
+        // the next item's ticket / list / points ride under the LAST view of this item (POOL: fetched under the first view they
+        // would sit in 18 registers through all the other views)
+        const bool pf = SC::PREFETCH && !prefetched && (!POOL || (keep_bits >> (v + 1)) == 0u);
         if (pf) draw_ticket();
         KPN_H2_STAMP(0);
         // ---- layers1.0 as ONE 16-step chain (HSEG_G1_0A and HSEG_G1_0B are adjacent, same step size): steps 0-11 one
@@ -655,7 +667,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             [&](auto ti, auto ei) -> float { return a1[decltype(ti)::value][0][decltype(ei)::value]; },
             a1, xb, xa);
         KPN_H2_STAMP(2);
-        if (pf) fetch_points();
+        if constexpr (!POOL) { if (pf) fetch_points(); }   // POOL: after the views (the raw points would occupy 14 registers through layers1.2 / 1.3)
         kpn_f32x16 acc[2][2];
         kpn_mfma16_layer2<SC, 9, 4, 8, KPN_H2_LOOKAHEAD, KPN_H2_LOOKAHEAD>(wp + kpn_xseg_off(HSEG_G1_2, NP), lane,
             [&](auto si, auto ti, auto ei) -> float {
@@ -697,17 +709,23 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             // weight, un-normalised; X = 2^10 x in the fp16 scheme, unscaled at the end):
             //     W' = W + w,  r = w / W',  d = X - mean,  mean' = mean + r d,  M2' = M2 + w (1 - r) d^2      (4 instructions per value)
             // The last kept view finishes: the reference normalises the weights by (sum + 1e-6) (model.py:759), so with S = sum w,
-            //     mean_ref = mu S / (S + 1e-6),   var_ref = sum_v pw_v (x_v - mean_ref)^2 = M2 / (S + 1e-6)  [+ S (mu 1e-6 / (S + 1e-6))^2 / (S + 1e-6):
-            //     twelve orders below mu^2, dropped]
+            //     mean_ref = mu S / (S + 1e-6),   var_ref = sum_v pw_v (x_v - mean_ref)^2 = (M2 + S (mu 1e-6 / (S + 1e-6))^2) / (S + 1e-6)
+            // (the second term is NOT negligible: near a frustum corner the weights are a product of three sigmoids, 3e-7, the same
+            // size as the 1e-6 — the reference's mean is then far from mu and its variance is mostly this term)
             const bool last_view = (keep_bits >> (v + 1)) == 0u;
+            const float4 wv4 = pst[34 * 64];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dst[t] = reinterpret_cast<float4*>(xscr) + lay.tile(2 * pair + t) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const float w = wview[t];
-                const float wn = wsum[t] + w;
+                const float4 pw4 = pst[(32 + t) * 64];
+                const float w = t == 0 ? wv4.x : wv4.y;
+                const float wn = pw4.w + w;
                 const float r = wn > 0.0f ? w / wn : 0.0f;
                 const float c = w * (1.0f - r);
                 const float inv = 1.0f / (wn + 1e-6f);
                 const float ms = wn * inv * SC::out_down, vs = inv * (SC::out_down * SC::out_down);   // exact powers of two folded in
+                const float om2 = wn * (1e-6f * inv) * (1e-6f * inv);                                   // S (1 - s)^2
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -732,15 +750,17 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                             pst[(16 + slab) * 64] = make_float4(m2[0], m2[1], m2[2], m2[3]);
                         } else if (t == 0 || has1) {
                             dst[t][(4 * b + qd) * 64] = make_float4(mu[0] * ms, mu[1] * ms, mu[2] * ms, mu[3] * ms);
-                            dst[t][(8 + 4 * b + qd) * 64] = make_float4(m2[0] * vs, m2[1] * vs, m2[2] * vs, m2[3] * vs);
+                            dst[t][(8 + 4 * b + qd) * 64] = make_float4(fmaf(om2 * mu[0], mu[0], m2[0]) * vs, fmaf(om2 * mu[1], mu[1], m2[1]) * vs,
+                                                                        fmaf(om2 * mu[2], mu[2], m2[2]) * vs, fmaf(om2 * mu[3], mu[3], m2[3]) * vs);
                         }
                     }
-                wsum[t] = wn;
+                pst[(32 + t) * 64] = make_float4(pw4.x, pw4.y, pw4.z, wn);
             }
             first_view = false;
         }
       }   // views of the work item
         if (!prefetched) { draw_ticket(); fetch_list(); fetch_points(); }
+        else if constexpr (POOL) fetch_points();
     }
 }
 

@@ -731,3 +731,24 @@ def test_frame_from_real_encoder_maps(env):
     o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, W, H), cfg["Sc"], cfg["Sf"])
     for k in ("tex_fg", "tex_fg_fine", "alpha", "alpha_fine"):
         assert np.abs(o[k] - g["out." + k].reshape(o[k].shape)).max() < 5e-5, k
+
+
+def test_pooling_inside_the_rows_kernel_with_tiny_view_weights(env, monkeypatch):
+    """The POOL layout (rows kernel pools over the views with a weighted Welford update) on a scene whose single source view sees
+    points near a frustum corner: their boundary-smooth weight is a product of three sigmoids, ~3e-7 — the size of the 1e-6 the
+    reference adds to the weight sum (src/model.py:759), so the reference's pooled mean is far from the row itself and its
+    variance is (S / (S + 1e-6)) x^2 (1 - s)^2-like, not 0.  (A GPU fuzz scene of round 4 caught a finish that had dropped that
+    term: 8.7e-3 in one ray.)  Against the oracle and against the ROWS layout (KPN_NO_POOL=1)."""
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    lib = env[0]
+    sd = random_hotpath_state_dict(seed=938341)
+    scene = make_scene(n_views=1, src_hw=(48, 48), tar_hw=(29, 10), mask="ellipsoid", seed=938342, tar_focal_at_512=800.0)
+    hs, packed = sh.HostScene(lib, scene), sh.pack_weights(lib, sd)
+    yy, xx = np.meshgrid(np.arange(29), np.arange(10), indexing="ij")
+    pix = np.stack([xx.reshape(-1), yy.reshape(-1)], -1).astype(np.int32)
+    ref = oracle.render_rays(oracle.OracleScene(scene), oracle.flat_weights(sd), scene["cam_tar"], scene["bounds"], pix, 8, 16, fine=False)
+    for no_pool in ("0", "1"):
+        monkeypatch.setenv("KPN_NO_POOL", no_pool)
+        o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (0, 0, 1, 10, 29), 8, 16, fine=False, chunk_rays=100)
+        assert np.abs(o["alpha"].reshape(-1) - ref["alpha"]).max() < 1e-5, no_pool
+        assert np.abs(o["tex_fg"].transpose(1, 2, 0).reshape(-1, 3) - ref["tex_fg"]).max() < 1e-5, no_pool
