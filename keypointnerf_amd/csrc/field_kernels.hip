@@ -554,22 +554,31 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
                 if (pass == 0) emin = fminf(emin, e);  // min over ALL views (:1288)
                 else if ((keep >> v) & 1u) esum = RADD(esum, RSUB(e, emin));
             }
-        // fused mean/var over views of x' (utils.py:91-95): K-steps mean' (16 + 3 + pad), var' (16 + 3 + pad)
+        // fused mean/var over views of x' (utils.py:91-95): K-steps mean' (16 + 3 + pad), var' (16 + 3 + pad).
+        // ONE pass over the views: a weighted Welford update per view (W += w, d = x - mu, mu += (w / W) d, M2 += w (1 - w / W) d^2)
+        // with the normalised blend weights w_v = (e_v - min e) / (sum + 1e-8) (model.py:1287-1289), finished as
+        //     mean' = sum w x = W mu,   var' = sum w (x - mean')^2 = M2 + W (mu (1 - W))^2      (W = sum w is 1 only up to the 1e-8).
+        // Round 3 ran two passes and read every parked x' back for the second (an L2 round trip per view in a latency-bound phase).
         float mv[40];
 #pragma unroll
         for (int i = 0; i < 40; ++i) mv[i] = 0.0f;
-        auto stats = [&](int pass, float dot, const kpn_ibr_view& iv) {
+        float wtot = 0.0f;
+        auto stats = [&](float dot, const kpn_ibr_view& iv) {
             const float wv = RSUB(kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f))), emin) / RADD(esum, 1e-8f);
+            wtot = RADD(wtot, wv);
+            const float r = wtot > 0.0f ? wv / wtot : 0.0f;
+            const float c = wv * (1.0f - r);
 #pragma unroll
             for (int i = 0; i < 19; ++i) {
                 const float x = i < 16 ? iv.xb0[i] : iv.xb1[i - 16];
-                if (pass == 0) mv[i] = RADD(mv[i], RMUL(x, wv));
-                else { const float d = RSUB(x, mv[i]); mv[20 + i] = RADD(mv[20 + i], RMUL(wv, RMUL(d, d))); }
+                const float d = RSUB(x, mv[i]);
+                mv[i] = fmaf(r, d, mv[i]);
+                mv[20 + i] = fmaf(RMUL(c, d), d, mv[20 + i]);
             }
         };
-        // x' of a view is needed three times (two statistics passes, the head).  With park_x the first pass parks it
-        // in slabs 0..4 of the view's row block — the 64-vector stored there is dead once it has been pooled — and the
-        // later passes read it back (5 dwordx4 per lane) instead of re-running the gather and the ray encoder.
+        // x' of a view is needed twice (the statistics, the head).  With park_x the statistics pass parks it (ROWS layout: in slabs
+        // 0..4 of the view's row block — the 64-vector stored there is dead once it has been pooled; POOL layout: over the pooled
+        // slabs) and the head reads it back (5 dwordx4 per lane) instead of re-running the gather and the ray encoder.
         float4* const park = const_cast<float4*>(scr) + lane;
         auto park_store = [&](int v, const kpn_ibr_view& x) {
             float4* d = park + lay.park(t, v) * 64;
@@ -587,19 +596,22 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             const float4 f = d[4 * 64];
             x.xb1[0] = f.x; x.xb1[1] = f.y; x.xb1[2] = f.z;
         };
-        for (int pass = 0; pass < 2; ++pass)
-            for (int v = 0; v < V; ++v) {
-                if (!((keep >> v) & 1u)) continue;
-                if (pass == 0 || !park_x) {
-                    kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
-                    kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
-                    if (park_x) park_store(v, iv);
-                    stats(pass, gv.rd[3], iv);
-                } else {
-                    park_load(v, iv);
-                    stats(pass, scr[(lay.rec(t, v) + 1) * 64 + p].w, iv);
-                }
+        for (int v = 0; v < V; ++v) {
+            if (!((keep >> v) & 1u)) continue;
+            kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
+            kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
+            if (park_x) park_store(v, iv);
+            stats(gv.rd[3], iv);
+        }
+        {
+            const float om = 1.0f - wtot;
+#pragma unroll
+            for (int i = 0; i < 19; ++i) {
+                const float dm = RMUL(mv[i], om);
+                mv[20 + i] = fmaf(RMUL(wtot, dm), dm, mv[20 + i]);
+                mv[i] = RMUL(mv[i], wtot);
             }
+        }
         KPN_FUSE_STAMP(4);
         // view-invariant part of base_layer.0: W[:, mean|var] * [mean, var] + b
         kpn_f32x16 base[2];

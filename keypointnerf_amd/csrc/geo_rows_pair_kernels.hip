@@ -714,8 +714,14 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             // size as the 1e-6 — the reference's mean is then far from mu and its variance is mostly this term)
             const bool last_view = (keep_bits >> (v + 1)) == 0u;
             const float4 wv4 = pst[34 * 64];
+            // (the lane offset goes through an opaque statement: formed from loop invariants only, the eight store addresses of a tile
+            // were hoisted to the top of the work item and held — spilled — through every view)
+            int lane_late = lane;
+#ifndef KPN_SIMT_EMU
+            asm volatile("" : "+v"(lane_late));
+#endif
 #pragma unroll
-            for (int t = 0; t < 2; ++t) dst[t] = reinterpret_cast<float4*>(xscr) + lay.tile(2 * pair + t) * 64 + lane;
+            for (int t = 0; t < 2; ++t) dst[t] = reinterpret_cast<float4*>(xscr) + lay.tile(2 * pair + t) * 64 + lane_late;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float4 pw4 = pst[(32 + t) * 64];
