@@ -33,7 +33,18 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 # split-operand rows kernels: N 16-bit MFMAs (2.5 PFLOP/s dense peak, bf16 and fp16 alike) per fp32 product term set ->
 # fp32-equivalent roof = 2500 / N: mode 2 (three bf16 pieces) N = 6, mode 3 (two fp16 pieces, the default) N = 4
 SPLIT_PRODUCTS = {2: 6, 3: 4}
-ROWS_KERNEL = {0: "k_geo_rows", 2: "k_geo_rows_h2", 3: "k_geo_rows_f2"}
+ROWS_KERNEL_BASE = {0: "k_geo_rows", 2: "k_geo_rows_h2", 3: "k_geo_rows_f2"}
+
+
+class _RowsKernel(dict):
+    """name of the rows kernel a render pass launches: the pair-tile kernels pool over the views themselves in the render passes
+    (suffix p, POOL layout of the scratch) unless KPN_NO_POOL=1"""
+    def __getitem__(self, mode):
+        pool = mode >= 2 and not (os.environ.get("KPN_NO_POOL") and int(os.environ["KPN_NO_POOL"]))
+        return ROWS_KERNEL_BASE[mode] + ("p" if pool else "")
+
+
+ROWS_KERNEL = _RowsKernel()
 ROWS_DTYPE = {0: "f32",
               2: "f32 (dominant kernel: every fp32 operand as three bf16 pieces, six bf16-MFMA products per term set, fp32 accumulation: "
                  "all terms above 2^-24 relative kept; everything else fp32)",
@@ -516,7 +527,9 @@ def main():
             "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "algorithmic_bytes_per_launch": (320.0 if args.geo_rows_mode == 0 else 256.0) * rows.value / max(1, launches.value),
+                         # written per row: mode 0 the 64-vector + the gather record (320 B); pair kernels without pooling the 64-vector
+                         # (256 B); with pooling inside the kernel (POOL) 128 floats per POINT = 512 / V bytes per row
+                         "algorithmic_bytes_per_launch": (320.0 if args.geo_rows_mode == 0 else (512.0 / args.views if ROWS_KERNEL[args.geo_rows_mode].endswith("p") else 256.0)) * rows.value / max(1, launches.value),
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "surplus_launches": surplus.value,
                          "traffic_source": "profiles/geo_rows_traffic.json: PMC (FETCH_SIZE, WRITE_SIZE) bytes per row from separate rocprofv3 --pmc passes of this kernel, times this run's rows per launch" if traffic is not None else None,

@@ -493,7 +493,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             continue;                                      // (POOL: weight 0 in the pooling, nothing to do)
         }
         // POOL: this view's boundary-smooth weight of the two points (model.py:752-758), parked in LDS until the epilogue
-        if constexpr (POOL) pst[34 * 64] = make_float4(kpn_pix_weight(q[0]), kpn_pix_weight(q[1]), 0.0f, 0.0f);
+        if constexpr (POOL) pst[34 * 64] = make_float4(kpn_pix_weight_fast(q[0]), kpn_pix_weight_fast(q[1]), 0.0f, 0.0f);
         // the next item's ticket / list / points ride under the LAST view of this item (POOL: fetched under the first view they
         // would sit in 18 registers through all the other views)
         const bool pf = SC::PREFETCH && !prefetched && (!POOL || (keep_bits >> (v + 1)) == 0u);

@@ -118,6 +118,23 @@ __device__ __forceinline__ float kpn_pix_weight(const kpn_proj& q) {
     return RMUL(RMUL(w3[0], w3[1]), w3[2]);
 }
 
+// the same weight for the pooling inside the rows kernels (POOL layout): reciprocals by v_rcp_f32 (1 ulp) instead of IEEE divisions
+// (ten instructions each, twelve of them per point pair and view in a VALU-only stretch); the weights enter a weighted mean
+__device__ __forceinline__ float kpn_pix_weight_fast(const kpn_proj& q) {
+#ifndef KPN_SIMT_EMU
+    const float c3[3] = {RADD(RMUL(0.5f, q.xn), 0.5f), RADD(RMUL(0.5f, q.yn), 0.5f), RADD(RMUL(0.5f, q.zn), 0.5f)};
+    float w = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float d = fminf(c3[i], RSUB(1.0f, c3[i]));
+        w *= __builtin_amdgcn_rcpf(1.0f + kpn_fast_exp(-RMUL(5.0f, RSUB(d * 10.0f, 1.0f))));
+    }
+    return w;
+#else
+    return kpn_pix_weight(q);
+#endif
+}
+
 // the colour head's per-(point,view) gather record (query_color, model.py:806-832) in its two parts: A = [r,g,b, pooling
 // weight | ray_diff direction(3), dot] (held by the h=0 lanes of a row), B = the 8 texture channels (model.py:818; h=1 lanes)
 __device__ __forceinline__ void kpn_row_record_a(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, const kpn_proj& q,

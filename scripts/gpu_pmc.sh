@@ -10,5 +10,6 @@ run sq4 SQ_INSTS_VALU_TRANS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_INSTS_VMEM_W
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
+(cd $R; python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary $BENCH_ARGS 2>/dev/null | tail -1 > gpurun_out/bench_r4_pmc_rows.json)   # the rows of one frame (x 2 frames per pass)
 ls $R/gpurun_out/pmc_$TAG | head
 cd $R; python scripts/pmc_summary.py gpurun_out/pmc_$TAG > gpurun_out/pmc_${TAG}_summary.txt 2>&1; rm -rf gpurun_out/pmc_$TAG
