@@ -605,11 +605,11 @@ def main():
                                         "reference_pytorch": ref, "port": port}
             else:
                 line["cpu_baseline"] = port
-            ej = os.path.join(ROOT, "profiles", "r02_eager_pytorch_on_mi355x.json")
+            ej = os.path.join(ROOT, "profiles", "r04_eager_pytorch_on_mi355x.json")
             if os.path.exists(ej):   # eager PyTorch restatement of the path on an MI355X (scripts/bench_torch_eager.py), recorded
                 e = json.load(open(ej))
                 line["eager_pytorch_same_gpu"] = {"rays_per_sec": max(v["rays_per_sec"] for k, v in e.items() if "ray" in k and isinstance(v, dict)),
-                                                  "recorded_by": "scripts/bench_torch_eager.py (profiles/r02_eager_pytorch_on_mi355x.json)",
+                                                  "recorded_by": "scripts/bench_torch_eager.py (profiles/r04_eager_pytorch_on_mi355x.json)",
                                                   "what": e["what"]}
         print(json.dumps(line), flush=True)
     if world > 1:
