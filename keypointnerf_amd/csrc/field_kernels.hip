@@ -416,7 +416,7 @@ template <bool F16>
 __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
                                                     const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                     int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                    int park_x, float* __restrict__ out, const kpn_batch& batch, int zero_skip) {
+                                                    int /*unused*/, float* __restrict__ out, const kpn_batch& batch, int zero_skip) {
     using W = kpn_fuse_w<F16>;
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -514,7 +514,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             sdf_raw = F16 ? o2[0][0] * (1.0f / KPN_F16_G22_SCALE) : o2[0][0];
             rad = F16 ? o2[0][1] * (1.0f / KPN_F16_G22_SCALE) : o2[0][1];
         }
-        // Exact zero-density short path (render passes only: park_x doubles as "nobody reads these rows or colours again").
+        // Exact zero-density short path (render passes only).
         // A point with relu(rad) == 0 composites with weight 1 - exp(-0 * delta) = 0 exactly, like a masked point, so its
         // colour never reaches the image (0 * rgb, rgb finite): when EVERY point of the tile is such a point — free space
         // inside the visual hull of a trained density comes in runs along the rays, i.e. in whole tiles of the ray-ordered
@@ -576,31 +576,14 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
                 mv[20 + i] = fmaf(RMUL(c, d), d, mv[20 + i]);
             }
         };
-        // x' of a view is needed twice (the statistics, the head).  With park_x the statistics pass parks it (ROWS layout: in slabs
-        // 0..4 of the view's row block — the 64-vector stored there is dead once it has been pooled; POOL layout: over the pooled
-        // slabs) and the head reads it back (5 dwordx4 per lane) instead of re-running the gather and the ray encoder.
-        float4* const park = const_cast<float4*>(scr) + lane;
-        auto park_store = [&](int v, const kpn_ibr_view& x) {
-            float4* d = park + lay.park(t, v) * 64;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[k * 64] = make_float4(x.xb0[4 * k], x.xb0[4 * k + 1], x.xb0[4 * k + 2], x.xb0[4 * k + 3]);
-            d[4 * 64] = make_float4(x.xb1[0], x.xb1[1], x.xb1[2], 0.0f);
-        };
-        auto park_load = [&](int v, kpn_ibr_view& x) {
-            const float4* d = park + lay.park(t, v) * 64;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 f = d[k * 64];
-                x.xb0[4 * k] = f.x; x.xb0[4 * k + 1] = f.y; x.xb0[4 * k + 2] = f.z; x.xb0[4 * k + 3] = f.w;
-            }
-            const float4 f = d[4 * 64];
-            x.xb1[0] = f.x; x.xb1[1] = f.y; x.xb1[2] = f.z;
-        };
+        // x' of a view is needed twice (the statistics here, the head below): the head re-runs the gather and the 624-MAC ray
+        // encoder.  Rounds 2-3 parked x' in the row scratch between the passes (three passes then); with ONE statistics pass the
+        // store + read-back (5.5 GB written and as much read back per 512 x 512 frame, most of it missing L2) measured 1.2 % of the
+        // frame SLOWER than recomputing.
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
             kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
-            if (park_x) park_store(v, iv);
             stats(gv.rd[3], iv);
         }
         {
@@ -678,11 +661,11 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             c0 = c0 * sc_old + g.rgb[0] * pn; c1 = c1 * sc_old + g.rgb[1] * pn; c2 = c2 * sc_old + g.rgb[2] * pn;
             lmax = nmax;
         };
+        // (fetching the next view's gather record ahead of the current view's head measured no gain: 23.50 vs 23.43 ms per frame)
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
             kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
-            if (park_x) park_load(v, iv);
-            else kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
+            kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }
         KPN_FUSE_STAMP(5);

@@ -939,11 +939,10 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     const bool guard = range_guard() && out && (rmode == 3 || fmode == 1);
     int* redone = guard ? redone_counter() : nullptr;
     const int safe_rmode = rmode == 3 ? 2 : rmode;
-    // park_x: k_fuse_color may recycle the pooled 64-vectors' slots of the row scratch, unless a backward pass is going to read
-    // them again (keep_rows).  zero-density short path: render passes only (lean), never when a backward pass reads the rows again
+    // zero-density short path: render passes only (lean), never when a backward pass reads the rows again
     const char* zs = getenv("KPN_NO_ZERO_SKIP");   // A/B knob, read per call
     const int zero_skip = (lean && !keep_rows && !(zs && atoi(zs))) ? 1 : 0;
-    const int park_x = keep_rows ? 0 : 1;
+    const int park_x = 0;   // (rounds 2-3: x' parked in the row scratch between the per-point kernel's passes; gone with the one-pass statistics)
     for (int b = 0; b < L.nbatch; ++b) {
         int* slots = count + 8 + 8 * b;
         int* bad = guard ? slots + 6 : nullptr;
@@ -975,7 +974,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         launch_fuse(fmode, sc, ps, wp, list, count, slots, xscr, mode, park_x, out, b_fuse, zero_skip, stream);
         if (guard) {
             // The same batch again in fp32's exponent range, IF the kernels above stood aside or flagged it: the rows first (the
-            // per-point kernel has parked its x' vectors over them; the gather records are intact), then the per-point kernel.
+            // non-finite value may have come from either kernel; the gather records are intact), then the per-point kernel.
             const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr, pool};
             const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone, pool};
             launch_rows(safe_rmode, sc, ps, wp, list, count, slots + 4, xscr, r_rows, stream);

@@ -39,20 +39,16 @@ struct kpn_batch { int index, tiles_cap; int cond; int* bad; int* redone; int po
 //   POOL (pool = 1, the render / query passes with the pair-tile rows kernels): the rows kernel walks a tile pair through ALL its views
 //         and pools on the fly (PoolModule's weighted mean / variance over views, reference src/utils.py:612-647,722-748, as a
 //         weighted Welford update per view in LDS), so only the pooled 128-vector reaches memory: per TILE
-//         16 + 2 V + 5 max(0, V - 3) slabs: 0..7 mean, 8..15 variance (same register order), then 2 slabs of gather record per
-//         view, then room for the per-point kernel to park the x' vectors of views 3.. (views 0..2 are parked over the pooled
-//         slabs, dead once they are in registers).  V = 3: 22 KB per tile instead of 30.
+//         16 + 2 V slabs: 0..7 mean, 8..15 variance (same register order), then 2 slabs of gather record per view.
+//         V = 3: 22 KB per tile instead of 30; V = 10: 36 instead of 100.
 struct kpn_tile_layout {
     int pool, V, ts;
-    __device__ __forceinline__ kpn_tile_layout(int pool_, int V_) : pool(pool_), V(V_), ts(pool_ ? 16 + 2 * V_ + 5 * (V_ > 3 ? V_ - 3 : 0) : V_ * KPN_ROW_SLABS) {}
+    __device__ __forceinline__ kpn_tile_layout(int pool_, int V_) : pool(pool_), V(V_), ts(pool_ ? 16 + 2 * V_ : V_ * KPN_ROW_SLABS) {}
     __device__ __forceinline__ size_t tile(int t) const { return (size_t)t * ts; }                                    // first slab of tile t
     __device__ __forceinline__ size_t row(int t, int v) const { return (size_t)t * ts + (size_t)v * KPN_ROW_SLABS; }   // ROWS only
     __device__ __forceinline__ size_t rec(int t, int v) const { return (size_t)t * ts + (pool ? 16 + 2 * v : v * KPN_ROW_SLABS + 8); }
-    __device__ __forceinline__ size_t park(int t, int v) const {
-        return (size_t)t * ts + (pool ? (v < 3 ? 5 * v : 16 + 2 * V + 5 * (v - 3)) : v * KPN_ROW_SLABS);
-    }
 };
-__host__ __device__ inline int kpn_tile_slabs(int pool, int V) { return pool ? 16 + 2 * V + 5 * (V > 3 ? V - 3 : 0) : V * KPN_ROW_SLABS; }
+__host__ __device__ inline int kpn_tile_slabs(int pool, int V) { return pool ? 16 + 2 * V : V * KPN_ROW_SLABS; }
 __device__ __forceinline__ bool kpn_batch_gate(const kpn_batch& b, const kpn_scene_dev& sc, const float* __restrict__ wp) {
     if (b.cond == KPN_RUN_ALWAYS) return true;
     const bool unsafe = kpn_f16_inputs_unsafe(sc, wp);
