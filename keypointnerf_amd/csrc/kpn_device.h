@@ -318,6 +318,9 @@ template <int KS, int NOB, class InFn>
 __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
     constexpr int NC = (KS + 7) / 8, NG = (KS + 3) / 4;
     const kpn_lptr4 base = KPN_LDS4(wseg) + lane;
+    // (a second accumulator for the lo-piece weight products of the one-block layers — two dependent chains of half the length —
+    // measured 0.6 % SLOWER on the frame: the matrix pipe forwards an accumulator to the next MFMA, the chains are not what the
+    // per-view heads wait for)
     kpn_static_for<0, NC>([&](auto ci) {
         constexpr int c = decltype(ci)::value;
         float x[8];
