@@ -165,50 +165,6 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True, frame=None):
     return base, parity
 
 
-def clock_telemetry(run_once, torch, seconds=2.0):
-    """Shader clock and board power while the headline workload runs (AFTER the timed region, same plan): sysfs pp_dpm_sclk
-    (the level marked '*') and hwmon power sampled every 20 ms from a thread while `run_once` is repeated for about `seconds`.
-    The chip clocks to its power budget (MI355X_MICROARCH.md, DVFS): a roofline fraction quoted against the 2.4 GHz peak
-    understates what the kernel does per cycle.  Best effort: None when the files are not there."""
-    import glob
-    import threading
-    sclk_files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-    pow_files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or \
-        sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
-    if not sclk_files:
-        return None
-    sclk, power, stop = [], [], threading.Event()
-
-    def sample():
-        while not stop.is_set():
-            try:
-                for line in open(sclk_files[0]).read().splitlines():
-                    if "*" in line:
-                        sclk.append(float(line.split(":")[1].replace("Mhz", "").replace("MHz", "").replace("*", "").strip()))
-                if pow_files:
-                    power.append(float(open(pow_files[0]).read().strip()) * 1e-6)
-            except Exception:  # noqa: BLE001
-                pass
-            time.sleep(0.02)
-
-    th = threading.Thread(target=sample, daemon=True)
-    t0 = time.perf_counter()
-    th.start()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
-        run_once()
-        torch.cuda.synchronize()
-        n += 1
-    stop.set()
-    th.join(timeout=1.0)
-    if not sclk:
-        return None
-    sclk.sort()
-    return {"sclk_mhz_median": sclk[len(sclk) // 2], "sclk_mhz_min": sclk[0], "sclk_mhz_max": sclk[-1], "samples": len(sclk),
-            "power_w_mean": (sum(power) / len(power)) if power else None, "frames": n,
-            "source": "sysfs pp_dpm_sclk / hwmon power, 20 ms period, while the headline frame is rendered repeatedly after the timed region"}
-
-
 def time_frames(L, ops, torch, scene, w, res, samples, fine, steps, warmup=1, with_kernel=False):
     """ms per frame + valid (point, view) rows per frame of one more workload (secondary results)."""
     ps = ops.PreparedScene(scene["img"], scene["cam"], scene["feat_geo"], scene["feat_tex"], scene["sp_data"],
@@ -440,7 +396,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    telemetry = clock_telemetry(lambda: step(args.warmup), torch) if (world == 1 and not args.no_secondary) else None
     # the frame of the last timed step, for the comparison with the oracle further down (world 1: rank 0's own camera)
     frame_np = {k: v[0].cpu().numpy() for k, v in out.items() if k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")} if (world == 1 and rank == 0) else None
     gather_ms = None
@@ -456,8 +411,10 @@ def main():
         dist.barrier()
         gather_ms = (time.perf_counter() - tg) / 5 * 1e3
         gatherer.finish()
-    ms, launches, rows, surplus = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
-    L.check(L.kpn_profile_collect2(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus)))
+    ms, launches, rows, surplus, clock_ghz = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_double(0)
+    # launch times (HIP events) and the shader clock the chip sustained under the rows kernel (s_memtime stamps of its first
+    # workgroup against the same launches' event time: include/kpnerf.h kpn_profile_collect3)
+    L.check(L.kpn_profile_collect3(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus), ctypes.byref(clock_ghz)))
     L.check(L.kpn_profile_enable(0))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
@@ -541,8 +498,9 @@ def main():
                          "algorithmic_flop_per_row": flops_row,
                          # what the chip clocked at under this load, and the fraction against the roof at THAT clock (the peaks of
                          # MI355X_MICROARCH.md are quoted at 2.4 GHz)
-                         "clock": telemetry,
-                         "frac_at_sustained_clock": (achieved / (peak * telemetry["sclk_mhz_median"] / 2400.0)) if telemetry else None,
+                         "effective_clock_ghz": clock_ghz.value or None,
+                         "frac_at_sustained_clock": (achieved / (peak * clock_ghz.value / 2.4)) if clock_ghz.value > 0 else None,
+                         "clock_note": "shader cycles (s_memtime) of the rows kernel's first workgroup / the launches' HIP-event time; the peaks are quoted at 2.4 GHz, the chip clocks to its power budget",
                          "kernel_time_share": (ms.value * 1e-3) / dt},
         }
         if world == 1 and not args.no_secondary:

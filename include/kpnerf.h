@@ -287,6 +287,12 @@ int kpn_profile_collect(double* geo_rows_ms_host, int64_t* launches_host, int64_
  * launches return at once: kpn_profile_collect2 reports them separately (ms / launches / rows cover the launches that
  * processed rows). */
 int kpn_profile_collect2(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host, int64_t* surplus_launches_host);
+/* The same plus *clock_ghz_host = the shader clock the chip sustained under the recorded pair-tile rows-kernel launches: shader
+ * cycles (s_memtime) between the first workgroup's entry and its last work item, divided by the launches' HIP-event time (a lower
+ * bound: the workgroup finishes a little before its launch).  The MI355X clocks to its power budget (≈ 1.9 GHz under this load,
+ * 2.4 GHz peak): a roofline fraction against the 2.4 GHz peak understates what the kernel does per cycle.  0 if not measured. */
+int kpn_profile_collect3(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host, int64_t* surplus_launches_host,
+                         double* clock_ghz_host);
 size_t kpn_row_scratch_cap_bytes(void);
 /* Process-wide; workspace sizes queried before a change are stale (query kpn_*_workspace_bytes again). */
 int kpn_set_row_scratch_cap_bytes(size_t bytes);

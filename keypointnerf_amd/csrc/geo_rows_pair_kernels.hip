@@ -451,10 +451,19 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
         for (int t = 0; t < 2; ++t) kpn_point_fetch(ps, nx_n[t], nx_raw[t]);
     };
     draw_ticket(); fetch_list(); fetch_points();           // the first item: nothing to hide behind
+#ifndef KPN_SIMT_EMU
+    const bool stamp_clk = batch.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp_clk) batch.clk[0] = clock64();
+#endif
     for (;;) {
         KPN_H2_STAMP(6);
         const int wi = nx_wi;
-        if (wi >= nwork) return;
+        if (wi >= nwork) {
+#ifndef KPN_SIMT_EMU
+            if (stamp_clk) batch.clk[1] = clock64();
+#endif
+            return;
+        }
         const int pair = POOL ? wi : wi / sc.V;
         const int v_begin = POOL ? 0 : wi - pair * sc.V, v_end = POOL ? sc.V : v_begin + 1;
         const bool has1 = 2 * pair + 1 < nbt;              // an odd batch ends in half a pair: tile 1 is computed, not stored

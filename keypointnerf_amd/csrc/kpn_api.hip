@@ -792,6 +792,8 @@ struct ProfState {
     bool on = false;
     std::vector<hipEvent_t> ev;   // pairs
     int* counts_host = nullptr;   // pinned: the pass's valid count, one copy per recorded launch
+    unsigned long long* clk_dev = nullptr;    // two shader-clock stamps per recorded launch (kpn_batch::clk), and their pinned copy
+    unsigned long long* clk_host = nullptr;
     std::vector<kpn_batch> batch; // which batch of the pass the launch was
     size_t used = 0, cap = 0;
     int V = 0;
@@ -946,12 +948,15 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     for (int b = 0; b < L.nbatch; ++b) {
         int* slots = count + 8 + 8 * b;
         int* bad = guard ? slots + 6 : nullptr;
-        const kpn_batch b_rows{b, L.tiles_cap, (guard && rmode == 3) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr, pool};
-        const kpn_batch b_rec{b, L.tiles_cap, KPN_RUN_ALWAYS, nullptr, nullptr, pool};
-        const kpn_batch b_fuse{b, L.tiles_cap, (guard && fmode == 1) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr, pool};
+        kpn_batch b_rows{b, L.tiles_cap, (guard && rmode == 3) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr, pool, nullptr};
+        const kpn_batch b_rec{b, L.tiles_cap, KPN_RUN_ALWAYS, nullptr, nullptr, pool, nullptr};
+        const kpn_batch b_fuse{b, L.tiles_cap, (guard && fmode == 1) ? KPN_RUN_IF_SAFE : KPN_RUN_ALWAYS, bad, nullptr, pool, nullptr};
 #ifndef KPN_SIMT_EMU
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
-        if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
+        if (prof) {
+            if (rmode >= 2) b_rows.clk = g_prof.clk_dev + 2 * g_prof.used;
+            (void)hipEventRecord(g_prof.ev[2 * g_prof.used], (hipStream_t)stream);
+        }
 #endif
         launch_rows(rmode, sc, ps, wp, list, count, slots + 0, xscr, b_rows, stream);
 #ifndef KPN_SIMT_EMU
@@ -975,8 +980,8 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
         if (guard) {
             // The same batch again in fp32's exponent range, IF the kernels above stood aside or flagged it: the rows first (the
             // non-finite value may have come from either kernel; the gather records are intact), then the per-point kernel.
-            const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr, pool};
-            const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone, pool};
+            const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr, pool, nullptr};
+            const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone, pool, nullptr};
             launch_rows(safe_rmode, sc, ps, wp, list, count, slots + 4, xscr, r_rows, stream);
             launch_fuse(0, sc, ps, wp, list, count, slots + 4, xscr, mode, park_x, out, r_fuse, zero_skip, stream);
         }
@@ -1764,16 +1769,27 @@ extern "C" int kpn_profile_enable(int32_t on) {
         for (auto& e : g_prof.ev) if (hipEventCreate(&e) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventCreate failed");
         if (hipHostMalloc((void**)&g_prof.counts_host, g_prof.cap * sizeof(int), 0) != hipSuccess)
             return fail(KPN_ELAUNCH, "hipHostMalloc failed");
+        if (hipMalloc((void**)&g_prof.clk_dev, g_prof.cap * 2 * sizeof(unsigned long long)) != hipSuccess ||
+            hipHostMalloc((void**)&g_prof.clk_host, g_prof.cap * 2 * sizeof(unsigned long long), 0) != hipSuccess)
+            return fail(KPN_ELAUNCH, "hipMalloc failed");
     }
+    if (on && hipMemset(g_prof.clk_dev, 0, g_prof.cap * 2 * sizeof(unsigned long long)) != hipSuccess) return fail(KPN_ELAUNCH, "hipMemset failed");
     g_prof.on = on != 0;
     g_prof.used = 0;
 #endif
     return KPN_OK;
 }
-extern "C" int kpn_profile_collect2(double* ms_out, int64_t* launches_out, int64_t* rows_out, int64_t* surplus_out) {
+extern "C" int kpn_profile_collect3(double* ms_out, int64_t* launches_out, int64_t* rows_out, int64_t* surplus_out, double* clock_ghz_out) {
     KPN_REQUIRE(ms_out && launches_out && rows_out && surplus_out, "null pointer");
     *ms_out = 0.0; *launches_out = 0; *rows_out = 0; *surplus_out = 0;
+    if (clock_ghz_out) *clock_ghz_out = 0.0;
 #ifndef KPN_SIMT_EMU
+    double cyc = 0.0, cyc_ms = 0.0;
+    if (g_prof.used && g_prof.clk_dev) {
+        if (hipEventSynchronize(g_prof.ev[2 * (g_prof.used - 1) + 1]) != hipSuccess ||
+            hipMemcpy(g_prof.clk_host, g_prof.clk_dev, g_prof.used * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(KPN_ELAUNCH, "could not read the clock stamps");
+    }
     for (size_t i = 0; i < g_prof.used; ++i) {
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventSynchronize failed");
         float ms = 0.0f;
@@ -1788,10 +1804,20 @@ extern "C" int kpn_profile_collect2(double* ms_out, int64_t* launches_out, int64
         *rows_out += ((p1 < count ? p1 : count) - p0) * g_prof.V;
         *ms_out += ms;
         ++*launches_out;
+        if (g_prof.clk_host && g_prof.clk_host[2 * i + 1] > g_prof.clk_host[2 * i]) {   // pair-tile kernels only
+            cyc += (double)(g_prof.clk_host[2 * i + 1] - g_prof.clk_host[2 * i]);
+            cyc_ms += ms;
+        }
     }
+    // shader cycles the first workgroup spent in the launches / the launches' event time: a lower bound of the sustained clock
+    // (the workgroup ends a little before its launch does)
+    if (clock_ghz_out && cyc_ms > 0.0) *clock_ghz_out = cyc / (cyc_ms * 1e6);
     g_prof.used = 0;
 #endif
     return KPN_OK;
+}
+extern "C" int kpn_profile_collect2(double* ms_out, int64_t* launches_out, int64_t* rows_out, int64_t* surplus_out) {
+    return kpn_profile_collect3(ms_out, launches_out, rows_out, surplus_out, nullptr);
 }
 extern "C" int kpn_profile_collect(double* ms_out, int64_t* launches_out, int64_t* rows_out) {
     int64_t surplus = 0;

@@ -31,7 +31,10 @@ struct kpn_points {
 //                      NaN into a number, so it reaches the per-point outputs).  Otherwise they return at once (3-4 us).
 // Never a NaN where the reference is finite, and no host synchronisation to get there.
 enum { KPN_RUN_ALWAYS = 0, KPN_RUN_IF_SAFE = 1, KPN_RUN_IF_UNSAFE = 2 };
-struct kpn_batch { int index, tiles_cap; int cond; int* bad; int* redone; int pool; };   // redone: counter of batches evaluated again (diagnostic); pool: layout below
+// redone: counter of batches evaluated again (diagnostic); pool: layout below; clk (measurement hook, may be NULL): two shader-clock
+// stamps (s_memtime) of the launch's first workgroup, entry and last work item done — with the launch's HIP-event time they give
+// the clock the chip actually sustained under this kernel (kpn_profile_collect3)
+struct kpn_batch { int index, tiles_cap; int cond; int* bad; int* redone; int pool; unsigned long long* clk; };
 
 // Two layouts of the scratch between the rows kernel, k_row_records and the per-point kernel, in slabs of [64 lanes] float4:
 //   ROWS (pool = 0): per (tile, view) KPN_ROW_SLABS = 10 slabs: 0..7 the view's 64-vector (a lane's 32 registers, block b = slab / 4),

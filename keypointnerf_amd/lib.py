@@ -111,6 +111,7 @@ _SIGNATURES = {
     "kpn_pix_l1_loss": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, ctypes.c_float, c_p, c_p, c_p, c_p]),
     "kpn_profile_collect": (ctypes.c_int, [c_p, c_p, c_p]),
     "kpn_profile_collect2": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
+    "kpn_profile_collect3": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "kpn_row_scratch_cap_bytes": (ctypes.c_size_t, []),
     "kpn_set_row_scratch_cap_bytes": (ctypes.c_int, [ctypes.c_size_t]),
     "kpn_selftest_mfma": (ctypes.c_int, [c_p, c_p, c_p]),
