@@ -116,7 +116,7 @@ def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, 
         idx = np.nonzero(above)[0]
         sub = {k: got[k][idx] for k in keys}
         subref = {k: ref[k][idx] for k in keys}
-        env = lambda: oracle.render_envelope(osc, wflat, cam_tar, bounds, pix[idx], Sc, Sf, fine=fine)
+        env = lambda: oracle.render_envelope(osc, wflat, cam_tar, bounds, pix[idx], Sc, Sf, fine=fine, trials=parity_gate.ENVELOPE_TRIALS)
         try:
             rep = parity_gate.check_rays(sub, subref, env, keys=keys, max_widened_fraction=1.0, what="bench frame")
             res["widened"] = len(rep["widened"])
@@ -230,7 +230,7 @@ def time_configs4(L, ops, torch, dev, sd, mode, with_parity=True):
             got = {"tex_fg": frame["tex_fg"].T, "alpha": frame["alpha"]}
             from tests import parity_gate
             try:
-                rep = parity_gate.check_rays(got, ref, lambda: oracle.render_envelope(osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, samples, samples, fine=False, ref=ref),
+                rep = parity_gate.check_rays(got, ref, parity_gate.oracle_envelope(oracle, osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, samples, samples, fine=False),
                                              keys=keys, max_widened_fraction=0.01, what="configs[4] subset")
                 parity = {"rays": int(pix.shape[0]), "max_abs_rgb": rep["max_err"]["tex_fg"], "max_abs_alpha": rep["max_err"]["alpha"],
                           "rays_above_1e-4": rep["above_bar"], "widened": len(rep["widened"]), "unexplained": 0, "ok": True}

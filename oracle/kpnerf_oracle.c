@@ -159,8 +159,10 @@ static void inverse3(const float* A /*row stride 4*/, double* inv) {
 /* ------------------------------------------------------------------------------------------
  * IBRRenderingHead.forward for ONE (ray, sample): model.py:1267-1302.
  * rgb_feat (V,35), ray_diff (V,4), mask (V) -> rgb[3] */
+static float g_pert_eps_z, g_pert_eps_f;                       /* conditioning probe: kpo_set_perturbation, below */
+static inline float pert_sign(uint64_t a, uint64_t b, uint64_t c);
 static void ibr_head(const kpo_weights* wt, int V, const float (*rgb_feat)[35], const float (*ray_diff)[4],
-                     const float* mask, float* rgb_out) {
+                     const float* mask, float* rgb_out, uint64_t point_id) {
     float x35[KPO_MAXV][35], weight[KPO_MAXV], e[KPO_MAXV];
     float h16[16], dirf[35];
     for (int v = 0; v < V; ++v) {
@@ -170,6 +172,10 @@ static void ibr_head(const kpo_weights* wt, int V, const float (*rgb_feat)[35], 
         linear(wt->w[L_RE_1], wt->b[L_RE_1], 35, 16, h16, dirf);
         for (int i = 0; i < 35; ++i) x35[v][i] = rgb_feat[v][i] + eluf(dirf[i]); /* :1281-1284 */
         e[v] = expf(fabsf(wt->ani_al) * (ray_diff[v][3] - 1.0f));                 /* :1287 */
+        /* conditioning probe: the blend weights below are DIFFERENCES of these exponentials against 1e-8 (:1288-1289) — two views with
+         * nearly the same angle to the query ray leave a difference of a few ulps, and the weight of the larger one anywhere between 0
+         * and 1: any two exp implementations differ there.  Disturbed at rounding level like the sample depths. */
+        if (g_pert_eps_z != 0.0f) e[v] *= 1.0f + g_pert_eps_z * pert_sign(point_id, (uint64_t)(40 + v), 3);
     }
     float emin = e[0];
     for (int v = 1; v < V; ++v) emin = fminf(emin, e[v]);
@@ -421,7 +427,7 @@ void kpo_query_ex(const kpo_scene* sc, const float* wflat, int64_t N, const floa
                 ray_diff[v][0] = rd[0] / rc; ray_diff[v][1] = rd[1] / rc; ray_diff[v][2] = rd[2] / rc;
                 ray_diff[v][3] = dot;
             }
-            ibr_head(&wt, V, (const float(*)[35])rgb_feat, (const float(*)[4])ray_diff, a, rgb);
+            ibr_head(&wt, V, (const float(*)[35])rgb_feat, (const float(*)[4])ray_diff, a, rgb, (uint64_t)n);
         }
         if (apply_eval_func) { /* model.py:981-997 */
             float mask = (float)is_valid;

@@ -45,7 +45,7 @@ def run_scene(ops, cfg):
     keys = ("tex_fg", "alpha") + (("tex_fg_fine", "alpha_fine") if cfg["fine"] else ())
     got = {k: (out[k][0].permute(1, 2, 0).reshape(-1, 3) if k.startswith("tex") else out[k].reshape(-1)).cpu().numpy() for k in keys}
     return parity_gate.check_rays(
-        got, ref, lambda: oracle.render_envelope(osc, wf, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=cfg["fine"], ref=ref),
+        got, ref, parity_gate.oracle_envelope(oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=cfg["fine"]),
         keys=keys, max_widened_fraction=0.01, what=str(cfg))
 
 

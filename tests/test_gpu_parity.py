@@ -264,7 +264,7 @@ def test_render_vs_oracle(ops, n_views, mask, src_hw, tar_hw, Sc, Sf):
     got.update({k: out[k].reshape(-1).cpu().numpy() for k in ("alpha", "alpha_fine")})
     # every ray within 1e-4, except rays the oracle's own conditioning probe singles out (tests/parity_gate.py); the V = 16 scene has
     # one (ray 24: a density of 1e-11 in front of the 1e10 last interval, envelope 1.3e-4)
-    rep = parity_gate.check_rays(got, ref, lambda: oracle.render_envelope(osc, wf, scene["cam_tar"], scene["bounds"], pix, Sc, Sf, ref=ref),
+    rep = parity_gate.check_rays(got, ref, parity_gate.oracle_envelope(oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, Sc, Sf),
                                  max_widened_fraction=0.01, what=f"V={n_views} {mask} {Sc}+{Sf}")
     assert len(rep["widened"]) <= 1
 

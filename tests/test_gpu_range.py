@@ -99,12 +99,7 @@ def run_case(ops, scene, sd):
     ref = oracle.render_rays(osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF)
     keys = ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")
     oracle_finite = all(np.isfinite(ref[k]).all() for k in keys)
-    env = {}
-
-    def envelope():
-        if not env:
-            env.update(oracle.render_envelope(osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF, ref=ref))
-        return env
+    envelope = parity_gate.oracle_envelope(oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF)
 
     def render():
         ps = ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"])
