@@ -464,7 +464,12 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         KPN_FUSE_STAMP(0);
         // ---- pooled mean / var over views of the 64-vector ----
         const float4* const scr = reinterpret_cast<const float4*>(xscr);
-        const float4* rows = scr + lay.tile(t) * 64;
+#ifdef KPN_DBG_FUSE_SAMETILE   // timing experiment (wrong results): every tile reads tile 0's block of the scratch -> cache hits
+        const int t_scr = 0;
+#else
+        const int t_scr = t;
+#endif
+        const float4* rows = scr + lay.tile(t_scr) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
         float pwsum;
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
@@ -549,7 +554,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         float emin = 3.0e38f, esum = 0.0f;
         for (int pass = 0; pass < 2; ++pass)
             for (int v = 0; v < V; ++v) {
-                const float dot = scr[(lay.rec(t, v) + 1) * 64 + p].w;
+                const float dot = scr[(lay.rec(t_scr, v) + 1) * 64 + p].w;
                 const float e = kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f)));
                 if (pass == 0) emin = fminf(emin, e);  // min over ALL views (:1288)
                 else if ((keep >> v) & 1u) esum = RADD(esum, RSUB(e, emin));
@@ -582,7 +587,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // frame SLOWER than recomputing.
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
-            kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
+            kpn_gather_view(scr + lay.rec(t_scr, v) * 64, lane, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             stats(gv.rd[3], iv);
         }
@@ -662,9 +667,12 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             lmax = nmax;
         };
         // (fetching the next view's gather record ahead of the current view's head measured no gain: 23.50 vs 23.43 ms per frame)
+        // (touching the NEXT tile's block of the scratch — one dword per 128-B line — under the last view's head, so that its
+        // lines are in L2 when the next tile starts: 23.93-23.97 vs 23.94-24.02 ms per frame, no gain; with EVERY tile reading tile 0's
+        // block, i.e. no HBM misses at all, the frame is 0.9 ms faster: profiles/r04_z_ab_experiments.txt)
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
-            kpn_gather_view(scr + lay.rec(t, v) * 64, lane, h, gv);
+            kpn_gather_view(scr + lay.rec(t_scr, v) * 64, lane, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }

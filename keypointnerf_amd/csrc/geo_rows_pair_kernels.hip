@@ -156,8 +156,13 @@ __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC
     } else if constexpr (F16 && Q == 3) {
 #ifndef KPN_SIMT_EMU
         uint32_t lo;
+#if KPN_F16_LO_MIXLO   // x - h rounded once to fp16 into the two halves of lo: the same values in two instructions (kpn_split_f16x8)
+        asm volatile("v_fma_mixlo_f16 %0, %3, -1.0, %1 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %3, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(lo) : "v"(p.x0), "v"(p.x1), "v"(p.pk));
+#else
         asm volatile("v_fma_mix_f32 %1, %3, -1.0, %1 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
                      "v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(lo), "+v"(p.x0), "+v"(p.x1) : "v"(p.pk));
+#endif
         dst[1][J] = lo;
 #else
         p.x0 = p.x0 - kpn_emu_h_lo(p.pk); p.x1 = p.x1 - kpn_emu_h_hi(p.pk);
@@ -354,6 +359,9 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
 // densities) from below to 1.3e-4, above the 1e-4 bar.  Not worth it: off by default (-DKPN_H2_L0_INTERLEAVE=1 switches it on).
 #ifndef KPN_H2_L0_INTERLEAVE
 #define KPN_H2_L0_INTERLEAVE 0
+#endif
+#ifndef KPN_H2_L0_AHEAD
+#define KPN_H2_L0_AHEAD 2   // interleaved order: positions between a geometry step's gathers and its first use (2 or 3)
 #endif
 struct kpn_h2_l0_order {
     static constexpr int at(int p) { return KPN_H2_L0_INTERLEAVE ? ((p % 4 == 3) ? 12 + p / 4 : p - p / 4) : p; }
@@ -619,8 +627,8 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                     // Interleaved order: two positions ahead (the previous geometry step ended three positions ago).
                     if constexpr (qq == 2 && (j == 1 || j == 3)) {
                         if constexpr (KPN_H2_L0_INTERLEAVE) {
-                            if constexpr (p0 + 2 < 16) {
-                                constexpr int nx2 = kpn_h2_l0_order::at(p0 + 2);
+                            if constexpr (p0 + KPN_H2_L0_AHEAD < 16) {
+                                constexpr int nx2 = kpn_h2_l0_order::at(p0 + KPN_H2_L0_AHEAD);
                                 if constexpr (nx2 >= 12) geo_loads(kpn_ic<nx2>{}, ti, kpn_ic<j / 2>{});
                             }
                         } else {

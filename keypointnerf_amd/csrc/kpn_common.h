@@ -92,6 +92,11 @@ __device__ __forceinline__ kpn_f32x16 kpn_mfma_f16(kpn_f32x4 a, kpn_u32x4 b, kpn
 // while the emulator and the compiler-selected form of the same arithmetic were right (bisected on the device: idle states
 // IN FRONT of the statements do not help, idle states BEHIND the two conversions whose results are MFMA operands do).  Hence
 // the "s_nop 1" inside those two statements.  (The pair-tile rows kernels produce their operands a whole step ahead.)
+// (measured on the MI355X: the two-instruction form is SLOWER — +0.17 ms per frame in k_fuse_color_h, +0.5 % in k_geo_rows_f2p;
+// v_fma_mixhi_f16 waits for v_fma_mixlo_f16's partial write of the same register.  Kept as an A/B switch, off.)
+#ifndef KPN_F16_LO_MIXLO
+#define KPN_F16_LO_MIXLO 0
+#endif
 __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& h, kpn_u32x4& l) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -99,11 +104,27 @@ __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& 
         float r0, r1;
         // one statement per pair (hipcc puts an s_nop behind every asm result it sees consumed); the idle states behind the last
         // conversion cover pl, ph is three instructions older
+#ifdef KPN_ABLATE_SPLIT   // timing experiment only (wrong results): the hi piece alone, one instruction per pair instead of four
+        asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=&v"(ph) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+        h[j] = ph; l[j] = 0u;
+        continue;
+#endif
+#if KPN_F16_LO_MIXLO
+        // lo pieces: the fused x - h rounded ONCE to fp16 into the low / high half of the destination (v_fma_mixlo_f16 /
+        // v_fma_mixhi_f16).  x - h is exact in fp32, so this is the same value as fp16(fp32(x - h)) — three instructions per pair
+        // instead of four; bit-identical over 1.7e7 values incl. 3.2e6 fp16 subnormals, infinities, NaNs (scripts/mixlo_probe.hip).
+        asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+            "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1"
+            : "=&v"(ph), "=&v"(pl) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+        (void)r0; (void)r1;
+#else
         asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
             "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
             "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
             "v_cvt_pk_f16_f32 %1, %2, %3\n\ts_nop 1"
             : "=&v"(ph), "=&v"(pl), "=&v"(r0), "=&v"(r1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
+#endif
         h[j] = ph; l[j] = pl;
     }
 }
