@@ -31,8 +31,9 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 # split-operand rows kernels: N 16-bit MFMAs (2.5 PFLOP/s dense peak, bf16 and fp16 alike) per fp32 product term set ->
-# fp32-equivalent roof = 2500 / N: mode 2 (three bf16 pieces) N = 6, mode 3 (two fp16 pieces, the default) N = 4
-SPLIT_PRODUCTS = {2: 6, 3: 4}
+# fp32-equivalent roof = 2500 / N: mode 2 (three bf16 pieces) N = 6, mode 3 (two fp16 pieces, the default) N = 3 (hh hl lh; round 4
+# until its last build: 4, roof 625 — the products' count went down, the algorithmic FLOP did not)
+SPLIT_PRODUCTS = {2: 6, 3: 3}
 ROWS_KERNEL_BASE = {0: "k_geo_rows", 2: "k_geo_rows_h2", 3: "k_geo_rows_f2"}
 
 
@@ -48,8 +49,8 @@ ROWS_KERNEL = _RowsKernel()
 ROWS_DTYPE = {0: "f32",
               2: "f32 (dominant kernel: every fp32 operand as three bf16 pieces, six bf16-MFMA products per term set, fp32 accumulation: "
                  "all terms above 2^-24 relative kept; everything else fp32)",
-              3: "f32 (dominant kernel: every fp32 operand as two fp16 pieces (22 bits, the residual formed exactly), four fp16-MFMA "
-                 "products per term set, fp32 accumulation: measured as close to fp64 as an fp32 fma chain; everything else fp32)"}
+              3: "f32 (dominant kernel: every fp32 operand as two fp16 pieces (22 bits, the residual formed exactly), three fp16-MFMA "
+                 "products per term set (hh hl lh: all terms above 2^-24 relative), fp32 accumulation; everything else fp32)"}
 
 
 def rows_peak_tflops(mode):
@@ -75,7 +76,7 @@ def parse():
     ap.add_argument("--chunk-rays", type=int, default=0)
     ap.add_argument("--no-fine", action="store_true", help="flat sampling: coarse pass only (BASELINE configs[4] style)")
     ap.add_argument("--geo-rows-mode", type=int, default=3, choices=[0, 2, 3],
-                    help="rows kernel of the field's first MLP: 3 = two fp16 pieces per operand, four products on the fp16 MFMA, two "
+                    help="rows kernel of the field's first MLP: 3 = two fp16 pieces per operand, three products on the fp16 MFMA, two "
                          "tiles per wave, one wave per SIMD (the library's default: fp32-class results); 2 = three bf16 pieces, six "
                          "products (fp32's exponent range); 0 = fp32 MFMA")
     ap.add_argument("--no-coarse-reuse", action="store_true",
@@ -490,7 +491,7 @@ def main():
                          "launches": launches.value, "avg_launch_ms": ms.value / max(1, launches.value),
                          "surplus_launches": surplus.value,
                          "traffic_source": "profiles/geo_rows_traffic.json: PMC (FETCH_SIZE, WRITE_SIZE) bytes per row from separate rocprofv3 --pmc passes of this kernel, times this run's rows per launch" if traffic is not None else None,
-                         "note": "achieved = algorithmic fp32 FLOP (140,160 per row) / kernel time; in the split-operand modes the matrix pipe executes N 16-bit products per fp32 product term set (mode 3: N = 4, mode 2: N = 6), so the roof is the dense 16-bit peak / N; the row scratch between the rows kernel and k_fuse_color is capped ("
+                         "note": "achieved = algorithmic fp32 FLOP (140,160 per row) / kernel time; in the split-operand modes the matrix pipe executes N 16-bit products per fp32 product term set (mode 3: N = 3, mode 2: N = 6), so the roof is the dense 16-bit peak / N; the row scratch between the rows kernel and k_fuse_color is capped ("
                                  + f"{L.kpn_row_scratch_cap_bytes() / 2**30:.1f} GiB) and reused by batches of a pass; the worst-case "
                                  "number of batches is launched and the surplus ones return at once (a few us each): "
                                  "`launches` / `avg_launch_ms` cover the launches that processed rows, a rocprofv3 average "

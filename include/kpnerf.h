@@ -163,7 +163,8 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
 /* Rows kernel of the dominant stage (MLPUNet.layers1 per (point, view) row, reference src/utils.py:691-720), all with
  * fp32 accumulation and the same parity bar against the reference goldens:
  *   3 = v_mfma_f32_32x32x16_f16 with every fp32 operand carried as two fp16 pieces (x - fp16(x) is formed exactly by one
- *       v_fma_mix_f32) and four products per term set; two 32-point tiles per wavefront, one wavefront per SIMD
+ *       v_fma_mix_f32) and three products per term set (hh hl lh: every term above 2^-24 relative); two 32-point tiles per
+ *       wavefront, one wavefront per SIMD
  *       (k_geo_rows_f2).  The default.  Operands must stay within fp16's range (a pre-activation beyond 454 in natural units,
  *       a packed weight or a feature-map value beyond 65504 is not representable): the RANGE GUARD below sees to that.
  *   2 = v_mfma_f32_32x32x16_bf16, three bf16 pieces, six products (k_geo_rows_h2): the same structure in fp32's exponent range.

@@ -39,7 +39,7 @@
 //   kpn_sc_bf16x3 (rows mode 2): x = h + m + l in bf16 (8 + 8 + 8 significant bits), six products per term set
 //                 hh hm mh mm hl lh (everything above 2^-24 relative), v_mfma_f32_32x32x16_bf16.  fp32's exponent range.
 //   kpn_sc_f16x2  (rows mode 3, the default): x = h + l in fp16 (11 + 11 bits; the residual x - h is formed exactly by ONE
-//                 v_fma_mix_f32 per value, which reads the fp16 half in place), four products hh hl lh ll,
+//                 v_fma_mix_f32 per value, which reads the fp16 half in place), three products hh hl lh (four with ll until round 4's last build),
 //                 v_mfma_f32_32x32x16_f16: 1.5x fewer MFMAs and 2 instead of 5.5 split instructions per value.  Measured
 //                 (scripts/f16_split_probe.hip, MI355X): the residual is always exact, |x - (h + l)| <= 2^-23 |x| with an
 //                 absolute floor of 2^-24 (fp16's subnormal quantum; the f16 MFMA honours subnormal inputs), a K = 256 dot
@@ -59,9 +59,12 @@ struct kpn_sc_bf16x3 {
     static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
 };
 struct kpn_sc_f16x2 {
-    static constexpr int NP = 2, NPROD = 4, NSLICE = 4;
-    static constexpr int pa(int pr) { return pr >> 1; }                                        // h h l l
-    static constexpr int pb(int pr) { return pr & 1; }                                         // h l h l
+    // KPN_F16_PRODUCTS (kpn_common.h) = 3: the products hh hl lh.  |l| <= 2^-12 |x| for both operands, so the fourth product ll is
+    // at most 2^-24 of the term — half an fp32 ulp, what ONE rounding of the reference's fp32 fma chain costs — and the bf16 scheme
+    // above drops its terms of that size (ml, lm) as well.  25 % fewer MFMAs; three slices of 5-6 instructions, one per gap.
+    static constexpr int NP = 2, NPROD = KPN_F16_PRODUCTS, NSLICE = KPN_F16_PRODUCTS == 3 ? 3 : 4;
+    static constexpr int pa(int pr) { return NPROD == 3 ? (pr == 2 ? 1 : 0) : pr >> 1; }       // h h l (l)
+    static constexpr int pb(int pr) { return NPROD == 3 ? (pr == 1 ? 1 : 0) : pr & 1; }        // h l h (l)
     static constexpr int hseg_base() { return kpn_fseg_off(0); }
     static constexpr float out_up = KPN_F16_ROW_SCALE, out_down = 1.0f / KPN_F16_ROW_SCALE;    // layers1.3 is packed times 2^10
     static constexpr bool PREFETCH = true;    // the next work item's ticket / list entries / points fetched under this one's layers
@@ -134,7 +137,56 @@ struct kpn_h2_pair { float x0, x1, e0, e1; uint32_t pk; };
 template <class SC, bool ACT, int Q, int J, class V0, class V1>
 __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC::NP], V0&& v0, V1&& v1) {
     constexpr bool F16 = SC::NP == 2;
-    if constexpr (F16 && Q == 2) {
+    if constexpr (F16 && SC::NSLICE == 3) {
+        // three products: THREE slices, one per MFMA gap (NOB = 4; two for NOB = 2), issue slots 7 7 6 (a transcendental = 2).
+        // One asm statement per gap: hipcc puts an s_nop between two adjacent asm statements.  Concatenated in order the sixteen
+        // instructions never read a transcendental's result in the next slot.
+        //   0: read u0 u1, exp 0, exp 1, max 0     1: 1 + e0, 1 + e1, log 0, log 1, max 1     2: add 0, add 1, hi pieces, x0 - h0, x1 - h1, lo pieces
+        //   without ACT: 0: x0 = v0()   1: x1 = v1()   2: hi pieces, x0 - h0, x1 - h1, lo pieces
+        if constexpr (Q == 0) {
+            if constexpr (ACT) {
+                const float a0 = v0(), a1 = v1();
+#ifndef KPN_SIMT_EMU
+                asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_exp_f32 %2, -|%0|\n\tv_exp_f32 %3, -|%1|\n\tv_max_f32 %0, 0, %0"
+                             : "=&v"(p.x0), "=&v"(p.x1), "=&v"(p.e0), "=&v"(p.e1) : "a"(a0), "a"(a1));
+#else
+                p.x0 = a0; p.x1 = a1;
+                p.e0 = kpn_exp2(-fabsf(p.x0)); p.e1 = kpn_exp2(-fabsf(p.x1));
+                p.x0 = fmaxf(p.x0, 0.0f);
+#endif
+            } else { p.x0 = v0(); KPN_H2_USE(p.x0); }
+        } else if constexpr (Q == 1) {
+            if constexpr (ACT) {
+#ifndef KPN_SIMT_EMU
+                asm volatile("v_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_log_f32 %0, %0\n\tv_log_f32 %1, %1\n\tv_max_f32 %2, 0, %2"
+                             : "+v"(p.e0), "+v"(p.e1), "+v"(p.x1));
+#else
+                p.e0 = 1.0f + p.e0; p.e1 = 1.0f + p.e1; p.e0 = kpn_log2(p.e0); p.e1 = kpn_log2(p.e1); p.x1 = fmaxf(p.x1, 0.0f);
+#endif
+            } else { p.x1 = v1(); KPN_H2_USE(p.x1); }
+        } else {
+#ifndef KPN_SIMT_EMU
+            uint32_t lo;
+            if constexpr (ACT)
+                asm volatile("v_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %5\n\tv_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                             "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                             "v_cvt_pk_f16_f32 %1, %2, %3"
+                             : "=&v"(p.pk), "=&v"(lo), "+v"(p.x0), "+v"(p.x1) : "v"(p.e0), "v"(p.e1));
+            else
+                asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                             "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                             "v_cvt_pk_f16_f32 %1, %2, %3"
+                             : "=&v"(p.pk), "=&v"(lo), "+v"(p.x0), "+v"(p.x1));
+            dst[0][J] = p.pk; dst[1][J] = lo;
+#else
+            if constexpr (ACT) { p.x0 = p.x0 + p.e0; p.x1 = p.x1 + p.e1; }
+            p.pk = kpn_emu_cvt_pk_f16(p.x0, p.x1);
+            dst[0][J] = p.pk;
+            p.x0 = p.x0 - kpn_emu_h_lo(p.pk); p.x1 = p.x1 - kpn_emu_h_hi(p.pk);
+            dst[1][J] = kpn_emu_cvt_pk_f16(p.x0, p.x1);
+#endif
+        }
+    } else if constexpr (F16 && Q == 2) {
         if constexpr (ACT) {
 #ifndef KPN_SIMT_EMU
             asm volatile("v_log_f32 %3, %3\n\tv_max_f32 %1, 0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_cvt_pk_f16_f32 %4, %0, %1"
@@ -256,9 +308,9 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     static_assert(!NEXT || NOB == 4, "the look-ahead needs blocks 0/1 in the first half of a step");
     constexpr int NP = SC::NP, NPROD = SC::NPROD, NSLICE = SC::NSLICE;
     constexpr int H0 = NOB / 2, H1 = NOB - H0;
-    constexpr int MF = 2 * NPROD * NOB, PP = MF / 8;     // MFMAs per step; MFMA gaps per operand pair (8 pairs per step)
-    constexpr int SPG = NSLICE / PP;                     // slices per gap: 1 (NOB = 4) or 2 (NOB = 2)
-    static_assert(SPG * PP == NSLICE && (SPG == 1 || SPG == 2), "whole slices per gap");
+    constexpr int MF = 2 * NPROD * NOB;                  // MFMAs per step
+    constexpr int SPG = 8 * NSLICE / MF;                 // slices per MFMA gap (8 operand pairs of NSLICE slices per step): 1, 2 or 4
+    static_assert(SPG * MF == 8 * NSLICE, "whole slices per gap");
     kpn_u32x4 xp[2][2][NP];                              // [buffer][tile][piece]: four dwords = eight 16-bit values
     kpn_f32x4 wa[NP][H0], wb[NP][H1];                    // the A pieces of the two halves of the output blocks (raw dwords)
     kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, 0u};
@@ -327,24 +379,23 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
             constexpr int m = decltype(mi)::value;
             mfma(mi, xp[cur]);
             if constexpr (s + 1 < KS16) {
-                constexpr int pair = m / PP, t = pair % 2, j = pair / 2, q = m % PP;
-                using SN = kpn_ic<s + 1>; using TI = kpn_ic<t>; using JI = kpn_ic<j>;
-                if constexpr (SPG == 1) slice(SN{}, nxt, TI{}, JI{}, kpn_ic<q>{});
-                else { slice(SN{}, nxt, TI{}, JI{}, kpn_ic<2 * q>{}); slice(SN{}, nxt, TI{}, JI{}, kpn_ic<2 * q + 1>{}); }
+                kpn_static_for<0, SPG>([&](auto ri) {   // slice k of the step: pair k / NSLICE (tile = pair % 2), slice k % NSLICE of it
+                    constexpr int k = m * SPG + decltype(ri)::value, pair = k / NSLICE;
+                    slice(kpn_ic<s + 1>{}, nxt, kpn_ic<pair % 2>{}, kpn_ic<pair / 2>{}, kpn_ic<k % NSLICE>{});
+                });
                 // each half's weight registers are reloaded right after that half's last MFMA has been issued (an MFMA
                 // captures its operands at issue: scripts/mfma16_war_probe.hip)
                 if constexpr (m == 2 * NPROD * H0 - 1) load_half(SMAP::at(s + 1), 0, H0, wa);
                 if constexpr (m == MF - 1) load_half(SMAP::at(s + 1), H0, H1, wb);
             } else {
                 tail_fn(mi);
-                if constexpr (NEXT && m >= MF / 2) {      // two slices of the next layer's step 0 per MFMA of the second half
-                    constexpr int GPP = MF / 16;          // gaps per pair in the second half: 3 (bf16x3) or 2 (fp16x2)
-                    static_assert(2 * GPP == NSLICE, "two slices per gap");
-                    constexpr int i = m - MF / 2, pair = i / GPP, t = pair % 2, j = pair / 2, q = 2 * (i % GPP);
-                    auto v0 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j>{}); };
-                    auto v1 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j + 1>{}); };
-                    kpn_h2_slice<SC, true, q, j>(pr, xn[t], v0, v1);
-                    kpn_h2_slice<SC, true, q + 1, j>(pr, xn[t], v0, v1);
+                if constexpr (NEXT && m >= MF / 2) {      // the slices of the next layer's step 0 under the MFMAs of the second half
+                    kpn_static_for<0, 2 * SPG>([&](auto ri) {   // all 8 NSLICE slices in half a step: twice as many per gap
+                        constexpr int k = (m - MF / 2) * 2 * SPG + decltype(ri)::value, pair = k / NSLICE, t = pair % 2, j = pair / 2;
+                        auto v0 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j>{}); };
+                        auto v1 = [&]() { return next_fn(kpn_ic<t>{}, kpn_ic<2 * j + 1>{}); };
+                        kpn_h2_slice<SC, true, k % NSLICE, j>(pr, xn[t], v0, v1);
+                    });
                 }
             }
             KPN_SCHED_BARRIER();
@@ -793,7 +844,7 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_h2(kpn_scene_dev sc, kpn_points ps, con
                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {
     kpn_geo_rows_pair_body<kpn_sc_bf16x3, false>(sc, ps, wp, list, count_ptr, tickets, xscr, batch);
 }
-// rows mode 3 (the default): two fp16 pieces, four products
+// rows mode 3 (the default): two fp16 pieces, three products
 __global__ KPN_H2_BOUNDS void k_geo_rows_f2(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                             const int* __restrict__ list, const int* __restrict__ count_ptr,
                                             int* __restrict__ tickets, float* __restrict__ xscr, kpn_batch batch) {

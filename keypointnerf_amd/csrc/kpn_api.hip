@@ -805,7 +805,7 @@ static ProfState g_prof;
 // 0: fp32 MFMA (v_mfma_f32_32x32x2_f32, k_geo_rows)
 // 2: three bf16 pieces per operand, six products, two tiles per wave and ONE wave per SIMD (k_geo_rows_h2): fp32-class results
 //    (every product term above 2^-24 relative is kept) in fp32's exponent range
-// 3: two fp16 pieces per operand, four products, same kernel structure (k_geo_rows_f2): the default — the same accuracy class
+// 3: two fp16 pieces per operand, three products (hh hl lh), same kernel structure (k_geo_rows_f2): the default — the same accuracy class
 //    with 1.5x fewer MFMAs and a third of the split instructions; operands must stay within fp16's range, which the range guard
 //    below takes care of
 // (1 was the one-tile-per-wave split-bf16 kernel of round 1: not part of the library, scripts/mode1_investigation/)

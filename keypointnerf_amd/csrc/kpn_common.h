@@ -234,6 +234,14 @@ struct kpn_scene_dev {
 // max |value|) — is tested here, on the device, by the kernels themselves: no host round trip.  Activations are not known before
 // the pass: a non-finite result is caught behind the kernels (kpn_batch::bad) and the batch evaluated again by the fp32-range
 // kernels (run_field, kpn_api.hip).
+// products per term set of the two-fp16-piece kernels: 4 = hh hl lh ll, 3 = without ll (<= 2^-24 of the term).
+// Rows kernels (geo_rows_pair_kernels.hip): 3.  Per-point kernel (kpn_hlayer, kpn_device.h): 4, see there.
+#ifndef KPN_F16_PRODUCTS
+#define KPN_F16_PRODUCTS 3
+#endif
+#ifndef KPN_FUSE_F16_PRODUCTS
+#define KPN_FUSE_F16_PRODUCTS 4
+#endif
 #define KPN_F16_INPUT_LIMIT 60000.0f
 #define KPN_SCENE_FLAG_FLOATS 16
 

@@ -336,10 +336,14 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
+            // KPN_FUSE_F16_PRODUCTS = 4 (hh hl lh ll) is what ships.  The three-product form the rows kernel uses (ll dropped: <= 2^-24
+            // of a term) is 0.5 ms per frame faster here too, but in the order hh hl lh it produced WRONG colours on the MI355X
+            // (2e-2, the emulator and every static check of the instruction stream say the orders are equivalent) and in the order
+            // hh lh hl it passed the whole GPU suite — in a kernel with two waves per SIMD, the configuration in which 16-bit MFMA
+            // chains have misbehaved before.  Not shipped on one passing run; kept as a build switch.
             acc[ob] = kpn_mfma_f16(ah, bh, acc[ob]);
-            acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]);
-            acc[ob] = kpn_mfma_f16(al, bh, acc[ob]);
-            acc[ob] = kpn_mfma_f16(al, bl, acc[ob]);
+            if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); acc[ob] = kpn_mfma_f16(al, bl, acc[ob]); }
+            else { acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); }
         }
     });
 }
@@ -355,9 +359,8 @@ __device__ __forceinline__ void kpn_hlayer_presplit(const float* __restrict__ ws
         for (int ob = 0; ob < NOB; ++ob) {
             const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
             acc[ob] = kpn_mfma_f16(ah, bh[c], acc[ob]);
-            acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]);
-            acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]);
-            acc[ob] = kpn_mfma_f16(al, bl[c], acc[ob]);
+            if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bl[c], acc[ob]); }
+            else { acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); }
         }
     });
 }

@@ -237,6 +237,9 @@ def test_training_step_of_the_live_class_forward_and_gradients(emulated):
     hot = [n for n in ref_g if n.startswith(("mlp_geo.", "mlp_tex.", "ibr_compress_gfeat."))]
     enc = [n for n in ref_g if n.startswith(("geo_encoder.", "tex_encoder."))]
     assert len(hot) >= 40 and len(enc) >= 20                         # the field and both encoders receive gradients
+    # Absolute floor: a bias in front of a normalisation layer has a gradient that is zero in exact arithmetic — the reference's own
+    # value for it is rounding noise (7e-8 against gradients of 1e-3 and more in the same encoder), and so is the difference.
+    gmax = max(float(g.abs().max()) for g in ref_g.values())
     for n in ref_g:
         scale = float(ref_g[n].abs().max())
-        assert float((got_g[n] - ref_g[n]).abs().max()) <= 2e-4 * scale + 1e-7, (n, scale)
+        assert float((got_g[n] - ref_g[n]).abs().max()) <= 2e-4 * scale + max(2e-7, 1e-6 * gmax), (n, scale)

@@ -703,7 +703,7 @@ def _soak_points(ops, n=400_000):
 
 
 def test_rows_kernel_modes(ops, golden_weights):
-    """kpn_set_geo_rows_mode: 3 (default) = two fp16 pieces per operand, four products on v_mfma_f32_32x32x16_f16; 2 = three bf16
+    """kpn_set_geo_rows_mode: 3 (default) = two fp16 pieces per operand, three products on v_mfma_f32_32x32x16_f16; 2 = three bf16
     pieces, six products on v_mfma_f32_32x32x16_bf16 (both: two tiles per wave, one wave per SIMD, Softplus in log2 units); 0 = fp32
     MFMA.  All three: the reference goldens (query and rendered images) at the parity bar, bit-identical run to run, and
     fp32-class agreement with mode 0 on 400,000 random points — no tolerated outliers (the long soak over code placements is

@@ -452,7 +452,7 @@ def test_device_weight_packer(env):
 
 def test_split_operand_geo_rows(env):
     """The pair-tile rows kernels on the emulated matrix instructions vs the reference's recorded query outputs and vs the
-    fp32-MFMA kernel: k_geo_rows_f2 (mode 3, the default: two fp16 pieces per operand, four products on
+    fp32-MFMA kernel: k_geo_rows_f2 (mode 3, the default: two fp16 pieces per operand, three products on
     v_mfma_f32_32x32x16_f16) and k_geo_rows_h2 (mode 2: three bf16 pieces, six products on v_mfma_f32_32x32x16_bf16), both with
     the Softplus in log2 units folded into the packed streams; an even and an odd number of tiles (the last pair's second tile
     is computed and not stored).  Mode 1 (one tile per wave) is not part of the shipped library any more."""
