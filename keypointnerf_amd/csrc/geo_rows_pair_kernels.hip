@@ -56,6 +56,7 @@ struct kpn_sc_bf16x3 {
     static constexpr int hseg_base() { return kpn_hseg_off(0); }
     static constexpr float out_up = 1.0f, out_down = 1.0f;
     static constexpr bool PREFETCH = false;   // register-saturated (256 VGPRs): the next item's data would only add spills
+    static constexpr int WBUF = 1;
     static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
 };
 struct kpn_sc_f16x2 {
@@ -68,6 +69,10 @@ struct kpn_sc_f16x2 {
     static constexpr int hseg_base() { return kpn_fseg_off(0); }
     static constexpr float out_up = KPN_F16_ROW_SCALE, out_down = 1.0f / KPN_F16_ROW_SCALE;    // layers1.3 is packed times 2^10
     static constexpr bool PREFETCH = true;    // the next work item's ticket / list entries / points fetched under this one's layers
+#ifndef KPN_H2_WBUF
+#define KPN_H2_WBUF 2
+#endif
+    static constexpr int WBUF = KPN_H2_WBUF;   // weight registers double-buffered (kpn_mfma16_layer2)
     static __device__ __forceinline__ kpn_f32x16 mfma(kpn_f32x4 a, kpn_u32x4 b, kpn_f32x16 c);
 };
 // ---- the operand production: one volatile asm BLOCK per slice ----
@@ -312,7 +317,15 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     constexpr int SPG = 8 * NSLICE / MF;                 // slices per MFMA gap (8 operand pairs of NSLICE slices per step): 1, 2 or 4
     static_assert(SPG * MF == 8 * NSLICE, "whole slices per gap");
     kpn_u32x4 xp[2][2][NP];                              // [buffer][tile][piece]: four dwords = eight 16-bit values
-    kpn_f32x4 wa[NP][H0], wb[NP][H1];                    // the A pieces of the two halves of the output blocks (raw dwords)
+    // the A pieces of the two halves of the output blocks (raw dwords).  SC::WBUF = 2 (the fp16 scheme, which has the registers):
+    // two buffers, step s reads buffer s & 1 and a half's registers are reloaded — right after its last MFMA has been issued —
+    // with the weights of step s + 2: a step and a half of MFMAs (36 x 32 cycles) between a load and its first use instead of
+    // half a step (12 MFMAs = 384 cycles with three products, less than an L2 round trip under load): rows kernel -2.4 %.
+    // (Handing the registers on from layer to layer as well — the first two steps of layers1.1-1.3 fetched under the previous
+    // layer's last two — measured no different: 3.240 vs 3.239 ms per launch; not kept.)
+    constexpr int WBUF = SC::WBUF;
+    auto wsel = [](int s) constexpr { return SC::WBUF == 2 ? (s & 1) : 0; };
+    kpn_f32x4 wa[WBUF][NP][H0], wb[WBUF][NP][H1];
     kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, 0u};
     // A half's pieces are contiguous ([step][block][piece][lane]): one scalar base in its middle, immediate offsets of
     // -3..+2 KB (the 13-bit signed range of global_load), the lane offset in one register for the whole kernel.  The base is
@@ -337,17 +350,24 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) w[pc][k] = src[(k * NP + pc - NP) * 64];
     };
+    // half hf (0 / 1) of step vs into the buffer that step reads
+    auto load_virtual = [&](auto vsi, auto hfi) {
+        constexpr int vs = decltype(vsi)::value, hf = decltype(hfi)::value, b = wsel(vs);
+        if constexpr (vs < KS16) {
+            if constexpr (hf == 0) load_half(SMAP::at(vs), 0, H0, wa[b]); else load_half(SMAP::at(vs), H0, H1, wb[b]);
+        }
+    };
     // MFMA number m of a step: half, then product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi — the order k_geo_rows_h
     // uses per accumulator), then block, then tile: the accumulators of a half rotate, consecutive MFMAs are independent
-    auto mfma = [&](auto mi, const kpn_u32x4 (&x)[2][NP]) {
-        constexpr int m = decltype(mi)::value;
+    auto mfma = [&](auto mi, auto wi, const kpn_u32x4 (&x)[2][NP]) {
+        constexpr int m = decltype(mi)::value, wsel = decltype(wi)::value;
         if constexpr (m < 2 * NPROD * H0) {
             constexpr int prd = m / (2 * H0), k = (m / 2) % H0, t = m % 2;
-            acc[t][k] = SC::mfma(wa[SC::pa(prd)][k], x[t][SC::pb(prd)], acc[t][k]);
+            acc[t][k] = SC::mfma(wa[wsel][SC::pa(prd)][k], x[t][SC::pb(prd)], acc[t][k]);
             KPN_H2_PIN_ACC(acc[t][k]);
         } else {
             constexpr int mm = m - 2 * NPROD * H0, prd = mm / (2 * H1), k = (mm / 2) % H1, t = mm % 2;
-            acc[t][H0 + k] = SC::mfma(wb[SC::pa(prd)][k], x[t][SC::pb(prd)], acc[t][H0 + k]);
+            acc[t][H0 + k] = SC::mfma(wb[wsel][SC::pa(prd)][k], x[t][SC::pb(prd)], acc[t][H0 + k]);
             KPN_H2_PIN_ACC(acc[t][H0 + k]);
         }
     };
@@ -358,8 +378,8 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
         if constexpr (!act && q < 3) stage_fn(sn, ti, ji, qi);
         kpn_h2_slice<SC, act, q, j>(pr, xp[b][t], [&]() { return val_fn(sn, ti, kpn_ic<2 * j>{}); }, [&]() { return val_fn(sn, ti, kpn_ic<2 * j + 1>{}); });
     };
-    load_half(SMAP::at(0), 0, H0, wa);
-    load_half(SMAP::at(0), H0, H1, wb);
+    load_virtual(kpn_ic<0>{}, kpn_ic<0>{}); load_virtual(kpn_ic<0>{}, kpn_ic<1>{});
+    if constexpr (WBUF == 2) { load_virtual(kpn_ic<1>{}, kpn_ic<0>{}); load_virtual(kpn_ic<1>{}, kpn_ic<1>{}); }
     if constexpr (HAVE0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -377,7 +397,7 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
         constexpr int cur = s & 1, nxt = cur ^ 1;
         kpn_static_for<0, MF>([&](auto mi) {
             constexpr int m = decltype(mi)::value;
-            mfma(mi, xp[cur]);
+            mfma(mi, kpn_ic<wsel(s)>{}, xp[cur]);
             if constexpr (s + 1 < KS16) {
                 kpn_static_for<0, SPG>([&](auto ri) {   // slice k of the step: pair k / NSLICE (tile = pair % 2), slice k % NSLICE of it
                     constexpr int k = m * SPG + decltype(ri)::value, pair = k / NSLICE;
@@ -385,8 +405,8 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
                 });
                 // each half's weight registers are reloaded right after that half's last MFMA has been issued (an MFMA
                 // captures its operands at issue: scripts/mfma16_war_probe.hip)
-                if constexpr (m == 2 * NPROD * H0 - 1) load_half(SMAP::at(s + 1), 0, H0, wa);
-                if constexpr (m == MF - 1) load_half(SMAP::at(s + 1), H0, H1, wb);
+                if constexpr (m == 2 * NPROD * H0 - 1) load_virtual(kpn_ic<s + WBUF>{}, kpn_ic<0>{});
+                if constexpr (m == MF - 1) load_virtual(kpn_ic<s + WBUF>{}, kpn_ic<1>{});
             } else {
                 tail_fn(mi);
                 if constexpr (NEXT && m >= MF / 2) {      // the slices of the next layer's step 0 under the MFMAs of the second half
@@ -781,55 +801,65 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             // (the second term is NOT negligible: near a frustum corner the weights are a product of three sigmoids, 3e-7, the same
             // size as the 1e-6 — the reference's mean is then far from mu and its variance is mostly this term)
             const bool last_view = (keep_bits >> (v + 1)) == 0u;
-            const float4 wv4 = pst[34 * 64];
-            // (the lane offset goes through an opaque statement: formed from loop invariants only, the eight store addresses of a tile
-            // were hoisted to the top of the work item and held — spilled — through every view)
-            int lane_late = lane;
+            // ONE branch selects among four straight-line bodies (first / last view known at compile time inside each): written as
+            // run-time tests inside the slab loop, hipcc kept them there — twelve branches per slab, 64 accumulator moves between
+            // the arms, 4-5 k cycles per view for 330 instructions' worth of work at one wave per SIMD.
+            auto welford = [&](auto first_c, auto last_c) {
+                constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+                const float4 wv4 = pst[34 * 64];
+                // (the lane offset goes through an opaque statement: formed from loop invariants only, the eight store addresses of a
+                // tile were hoisted to the top of the work item and held — spilled — through every view)
+                int lane_late = lane;
 #ifndef KPN_SIMT_EMU
-            asm volatile("" : "+v"(lane_late));
+                asm volatile("" : "+v"(lane_late));
 #endif
 #pragma unroll
-            for (int t = 0; t < 2; ++t) dst[t] = reinterpret_cast<float4*>(xscr) + lay.tile(2 * pair + t) * 64 + lane_late;
+                for (int t = 0; t < 2; ++t) dst[t] = reinterpret_cast<float4*>(xscr) + lay.tile(2 * pair + t) * 64 + lane_late;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float4 pw4 = pst[(32 + t) * 64];
-                const float w = t == 0 ? wv4.x : wv4.y;
-                const float wn = pw4.w + w;
-                const float r = wn > 0.0f ? w / wn : 0.0f;
-                const float c = w * (1.0f - r);
-                const float inv = 1.0f / (wn + 1e-6f);
-                const float ms = wn * inv * SC::out_down, vs = inv * (SC::out_down * SC::out_down);   // exact powers of two folded in
-                const float om2 = wn * (1e-6f * inv) * (1e-6f * inv);                                   // S (1 - s)^2
+                for (int t = 0; t < 2; ++t) {
+                    const float4 pw4 = pst[(32 + t) * 64];
+                    const float w = t == 0 ? wv4.x : wv4.y;
+                    const float wn = pw4.w + w;
+                    const float r = wn > 0.0f ? w / wn : 0.0f;
+                    const float c = w * (1.0f - r);
+                    const float inv = 1.0f / (wn + 1e-6f);
+                    const float ms = wn * inv * SC::out_down, vs = inv * (SC::out_down * SC::out_down);   // exact powers of two folded in
+                    const float om2 = wn * (1e-6f * inv) * (1e-6f * inv);                                   // S (1 - s)^2
+                    const bool store = t == 0 || has1;
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const int slab = 8 * t + 4 * b + qd;
-                        float mu[4], m2[4];
-                        if (first_view) {
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const int slab = 8 * t + 4 * b + qd;
+                            float mu[4], m2[4];
+                            if constexpr (FIRST) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { mu[e] = acc[t][b][4 * qd + e]; m2[e] = 0.0f; }
-                        } else {
-                            const float4 a = pst[slab * 64], cc = pst[(16 + slab) * 64];
-                            const float am[4] = {a.x, a.y, a.z, a.w}, cm[4] = {cc.x, cc.y, cc.z, cc.w};
+                                for (int e = 0; e < 4; ++e) { mu[e] = acc[t][b][4 * qd + e]; m2[e] = 0.0f; }
+                            } else {
+                                const float4 a = pst[slab * 64], cc = pst[(16 + slab) * 64];
+                                const float am[4] = {a.x, a.y, a.z, a.w}, cm[4] = {cc.x, cc.y, cc.z, cc.w};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float d = acc[t][b][4 * qd + e] - am[e];
-                                mu[e] = fmaf(r, d, am[e]);
-                                m2[e] = fmaf(c * d, d, cm[e]);
+                                for (int e = 0; e < 4; ++e) {
+                                    const float d = acc[t][b][4 * qd + e] - am[e];
+                                    mu[e] = fmaf(r, d, am[e]);
+                                    m2[e] = fmaf(c * d, d, cm[e]);
+                                }
+                            }
+                            if constexpr (!LAST) {
+                                pst[slab * 64] = make_float4(mu[0], mu[1], mu[2], mu[3]);
+                                if constexpr (!FIRST) pst[(16 + slab) * 64] = make_float4(m2[0], m2[1], m2[2], m2[3]);
+                                else pst[(16 + slab) * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            } else if (store) {
+                                dst[t][(4 * b + qd) * 64] = make_float4(mu[0] * ms, mu[1] * ms, mu[2] * ms, mu[3] * ms);
+                                dst[t][(8 + 4 * b + qd) * 64] = make_float4(fmaf(om2 * mu[0], mu[0], m2[0]) * vs, fmaf(om2 * mu[1], mu[1], m2[1]) * vs,
+                                                                            fmaf(om2 * mu[2], mu[2], m2[2]) * vs, fmaf(om2 * mu[3], mu[3], m2[3]) * vs);
                             }
                         }
-                        if (!last_view) {
-                            pst[slab * 64] = make_float4(mu[0], mu[1], mu[2], mu[3]);
-                            pst[(16 + slab) * 64] = make_float4(m2[0], m2[1], m2[2], m2[3]);
-                        } else if (t == 0 || has1) {
-                            dst[t][(4 * b + qd) * 64] = make_float4(mu[0] * ms, mu[1] * ms, mu[2] * ms, mu[3] * ms);
-                            dst[t][(8 + 4 * b + qd) * 64] = make_float4(fmaf(om2 * mu[0], mu[0], m2[0]) * vs, fmaf(om2 * mu[1], mu[1], m2[1]) * vs,
-                                                                        fmaf(om2 * mu[2], mu[2], m2[2]) * vs, fmaf(om2 * mu[3], mu[3], m2[3]) * vs);
-                        }
-                    }
-                pst[(32 + t) * 64] = make_float4(pw4.x, pw4.y, pw4.z, wn);
-            }
+                    if constexpr (!LAST) pst[(32 + t) * 64] = make_float4(pw4.x, pw4.y, pw4.z, wn);
+                }
+            };
+            if (first_view) { if (last_view) welford(kpn_ic<1>{}, kpn_ic<1>{}); else welford(kpn_ic<1>{}, kpn_ic<0>{}); }
+            else { if (last_view) welford(kpn_ic<0>{}, kpn_ic<1>{}); else welford(kpn_ic<0>{}, kpn_ic<0>{}); }
             first_view = false;
         }
       }   // views of the work item
