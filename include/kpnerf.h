@@ -174,8 +174,8 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
 int kpn_set_geo_rows_mode(int32_t mode);
 int kpn_get_geo_rows_mode(void);
 /* The per-point kernel (MLPUNet.layers2 + ibr_compress_gfeat + IBRRenderingHead, reference src/utils.py:577-587,
- * src/model.py:819,1267-1302): 1 = weights as two fp16 pieces per value, four products on v_mfma_f32_32x32x16_f16
- * (k_fuse_color_h, the default: fp32-class results at a quarter of the matrix time); 0 = fp32 weights on
+ * src/model.py:819,1267-1302): 1 = weights as two fp16 pieces per value, three products (hh lh hl) on v_mfma_f32_32x32x16_f16
+ * (k_fuse_color_h, the default: fp32-class results at less than a fifth of the matrix time); 0 = fp32 weights on
  * v_mfma_f32_32x32x2_f32 (k_fuse_color).  Process-wide; initial value from the environment variable KPN_FUSE_MODE. */
 int kpn_set_fuse_mode(int32_t mode);
 int kpn_get_fuse_mode(void);

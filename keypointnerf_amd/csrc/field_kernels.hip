@@ -260,7 +260,7 @@ __device__ __forceinline__ void kpn_gather_view(const float4* __restrict__ rec, 
 
 // The per-point kernel exists with two weight formats (template parameter F16 of its body):
 //   false: fp32 streams on v_mfma_f32_32x32x2_f32 (k_fuse_color; the region [kpn_k2_base(), + kpn_k2_floats()) of the packed buffer)
-//   true : two fp16 pieces per value, four products on v_mfma_f32_32x32x16_f16 (k_fuse_color_h; the kpn_cseg_* region) — the
+//   true : two fp16 pieces per value, three products on v_mfma_f32_32x32x16_f16 (k_fuse_color_h; the kpn_cseg_* region) — the
 //          k_geo_rows_f2 arithmetic: a quarter of the matrix time for the same fp32-class results
 // kpn_fuse_w<F16> maps a segment / scalar / row vector to its offset in the packed buffer (the LDS pointer is biased by -base).
 template <bool F16> struct kpn_fuse_w;

@@ -235,12 +235,13 @@ struct kpn_scene_dev {
 // the pass: a non-finite result is caught behind the kernels (kpn_batch::bad) and the batch evaluated again by the fp32-range
 // kernels (run_field, kpn_api.hip).
 // products per term set of the two-fp16-piece kernels: 4 = hh hl lh ll, 3 = without ll (<= 2^-24 of the term).
-// Rows kernels (geo_rows_pair_kernels.hip): 3.  Per-point kernel (kpn_hlayer, kpn_device.h): 4, see there.
+// Rows kernels (geo_rows_pair_kernels.hip): KPN_F16_PRODUCTS.  Per-point kernel (kpn_hlayer, kpn_device.h): KPN_FUSE_F16_PRODUCTS,
+// three as well — in the product order given there.
 #ifndef KPN_F16_PRODUCTS
 #define KPN_F16_PRODUCTS 3
 #endif
 #ifndef KPN_FUSE_F16_PRODUCTS
-#define KPN_FUSE_F16_PRODUCTS 4
+#define KPN_FUSE_F16_PRODUCTS 3
 #endif
 #define KPN_F16_INPUT_LIMIT 60000.0f
 #define KPN_SCENE_FLAG_FLOATS 16

@@ -309,11 +309,11 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
     }, acc);
 }
 
-// The same Linear layer on v_mfma_f32_32x32x16_f16 with two fp16 pieces per operand and four products per term set (the
+// The same Linear layer on v_mfma_f32_32x32x16_f16 with two fp16 pieces per operand and three products per term set (the
 // k_geo_rows_f2 arithmetic, geo_rows_pair_kernels.hip) for the per-point kernel: the stream is the LDS copy of a kpn_cseg_*
 // segment (kpn_common.h), KS fp32 K-steps taken eight at a time.  in_fn has kpn_mfma_layer's signature with G = 4
 // (in_fn(kpn_ic<g>, float (&x)[4]) = K-steps 4g .. 4g+3); a chunk is two such groups.  Compiler-scheduled: two waves share a
-// SIMD in this kernel.  4 MFMAs of 32 cycles per (chunk, block) against 8 of 64 on the fp32 pipe.
+// SIMD in this kernel.  3 MFMAs of 32 cycles per (chunk, block) against 8 of 64 on the fp32 pipe.
 template <int KS, int NOB, class InFn>
 __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
     constexpr int NC = (KS + 7) / 8, NG = (KS + 3) / 4;
@@ -336,14 +336,21 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
-            // KPN_FUSE_F16_PRODUCTS = 4 (hh hl lh ll) is what ships.  The three-product form the rows kernel uses (ll dropped: <= 2^-24
-            // of a term) is 0.5 ms per frame faster here too, but in the order hh hl lh it produced WRONG colours on the MI355X
-            // (2e-2, the emulator and every static check of the instruction stream say the orders are equivalent) and in the order
-            // hh lh hl it passed the whole GPU suite — in a kernel with two waves per SIMD, the configuration in which 16-bit MFMA
-            // chains have misbehaved before.  Not shipped on one passing run; kept as a build switch.
+            // Three products (ll dropped: <= 2^-24 of a term, as in the rows kernel), in the order hh LH HL.  In the order hh hl lh this
+            // kernel — two waves per SIMD, compiler-scheduled — came out WRONG and NON-DETERMINISTIC on the MI355X (62 % of the points
+            // off, different points from run to run; right on the emulator; -DKPN_FUSE_F16_ORDER_HLFIRST rebuilds it).  The cause is
+            // not established: the order only changes hipcc's schedule and register assignment, and nothing the static checks of
+            // the two instruction streams look for (a source register rewritten behind an MFMA, a result read too early) tells
+            // them apart.  What is established is the behaviour of THIS order: 1.4e10 row evaluations bit-identical run to run and
+            // within fp32 class of the fp32 kernels (scripts/soak_mode2.py, both masks), the GPU suite and the 200-scene sweep pass.
+            // Any change to this kernel's instruction stream has to pass the same soak before it ships.
             acc[ob] = kpn_mfma_f16(ah, bh, acc[ob]);
             if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); acc[ob] = kpn_mfma_f16(al, bl, acc[ob]); }
+#ifdef KPN_FUSE_F16_ORDER_HLFIRST   // the order that came out wrong on the device (see above); experiments only
+            else { acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); }
+#else
             else { acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); }
+#endif
         }
     });
 }
@@ -360,7 +367,11 @@ __device__ __forceinline__ void kpn_hlayer_presplit(const float* __restrict__ ws
             const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
             acc[ob] = kpn_mfma_f16(ah, bh[c], acc[ob]);
             if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bl[c], acc[ob]); }
+#ifdef KPN_FUSE_F16_ORDER_HLFIRST
+            else { acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); }
+#else
             else { acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); }
+#endif
         }
     });
 }

@@ -20,6 +20,7 @@ R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o ${TAG}_bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary) > $R/gpurun_out/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 cd $R; DB=$(find gpurun_out/prof -name "${TAG}_bench*.db" | head -1); python scripts/rocprof_summary.py $DB gpurun_out/${TAG}_kernel_stats.md > /dev/null 2>&1; head -8 gpurun_out/${TAG}_kernel_stats.md; rm -rf gpurun_out/prof
 (timeout 600 python scripts/soak_mode2.py --mode 3 --repeats 8000) 2>/dev/null | tail -1 | tee gpurun_out/soak_mode3_$TAG.jsonl | cut -c1-400
+(timeout 600 python scripts/soak_mode2.py --mode 3 --repeats 4000 --mask ellipsoid) 2>/dev/null | tail -1 | tee -a gpurun_out/soak_mode3_$TAG.jsonl | cut -c1-300
 (timeout 600 python scripts/soak_mode2.py --mode 2 --repeats 600) 2>/dev/null | tail -1 | tee -a gpurun_out/soak_mode3_$TAG.jsonl | cut -c1-200
 (timeout 900 python scripts/fuzz_parity.py 200) > gpurun_out/fuzz_$TAG.log 2>&1; echo "fuzz rc=$?"; tail -1 gpurun_out/fuzz_$TAG.log | cut -c1-400; cp gpurun_out/fuzz_parity.json gpurun_out/fuzz_parity_200_scenes_default_$TAG.json
 bash scripts/gpu_pmc.sh $TAG 2>&1 | tail -3
