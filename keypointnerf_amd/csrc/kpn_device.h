@@ -341,7 +341,8 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
             // off, different points from run to run; right on the emulator; -DKPN_FUSE_F16_ORDER_HLFIRST rebuilds it).  The cause is
             // not established: the order only changes hipcc's schedule and register assignment, and nothing the static checks of
             // the two instruction streams look for (a source register rewritten behind an MFMA, a result read too early) tells
-            // them apart.  What is established is the behaviour of THIS order: 1.4e10 row evaluations bit-identical run to run and
+            // them apart (the obvious suspect, a weight register reloaded from LDS behind the last of a chain of dependent MFMAs with
+            // another wave's MFMAs in the pipe, is harmless: scripts/mfma_src_reload_probe.hip).  What is established is the behaviour of THIS order: 1.4e10 row evaluations bit-identical run to run and
             // within fp32 class of the fp32 kernels (scripts/soak_mode2.py, both masks), the GPU suite and the 200-scene sweep pass.
             // Any change to this kernel's instruction stream has to pass the same soak before it ships.
             acc[ob] = kpn_mfma_f16(ah, bh, acc[ob]);
