@@ -11,12 +11,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_lib", "libkpnerf_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-# two translation units: the library, and the pair-tile rows kernel with its own flag (see csrc/geo_rows_pair_tu.hip)
-UNITS = [("kpn_api.hip", []), ("geo_rows_pair_tu.hip", ["-fno-slp-vectorize"])]
+# two translation units, compiled in parallel: the library, and the pair-tile rows kernels (csrc/geo_rows_pair_tu.hip).
+# -fno-slp-vectorize on both: the fp16 / bf16 operand splits (kpn_common.h) rely on hipcc selecting v_fma_mix_f32 per value
+# (the SLP vectoriser turns a pair of them into v_cvt_f32_f16 x2 + v_pk_fma_f32), and packed fp32 beside MFMAs is slower here.
+UNITS = [("kpn_api.hip", ["-fno-slp-vectorize"]), ("geo_rows_pair_tu.hip", ["-fno-slp-vectorize"])]
+
+
+def assembly_files():
+    """device assembly kept by the last build, one file per translation unit"""
+    return [os.path.join(os.path.dirname(OUT), src.replace(".hip", ".gfx950.s")) for src, _ in UNITS]
 
 
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not all(os.path.exists(f) for f in assembly_files()):
         return True
     # every file under csrc/ is part of the one translation unit kpn_api.hip (it #includes the other .hip files)
     deps = [os.path.join(CSRC, s) for s in sorted(os.listdir(CSRC)) if s.endswith((".hip", ".h"))]
@@ -32,13 +39,24 @@ def build(force=False, verbose=True):
     objs = []
     for src, extra in UNITS:
         obj = os.path.join(os.path.dirname(OUT), src.replace(".hip", ".o"))
-        cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        # -save-temps=obj: the device assembly of the very compile that makes the object is kept beside it (<unit>.gfx950.s) for the
+        # ISA audit of the CPU suite (tests/test_isa_audit.py, scripts/isa_asm_hazards.py); the other intermediates are removed
+        cmd = [hipcc] + HIPCC_FLAGS + extra + ["-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        objs.append((obj, subprocess.Popen(cmd)))
+        objs.append((obj, subprocess.Popen(cmd, stderr=subprocess.DEVNULL if not verbose else None)))
     for obj, proc in objs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, obj)
+        stem = obj[:-2]
+        for f in os.listdir(os.path.dirname(OUT)):
+            full = os.path.join(os.path.dirname(OUT), f)
+            if not f.startswith(os.path.basename(stem) + "-") and not f.startswith(os.path.basename(stem) + ".hip-"):
+                continue
+            if f.endswith("-gfx950.s"):
+                os.replace(full, stem + ".gfx950.s")
+            else:
+                os.remove(full)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in objs] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -213,13 +213,8 @@ __device__ __forceinline__ void kpn_h2_slice(kpn_h2_pair& p, kpn_u32x4 (&dst)[SC
     } else if constexpr (F16 && Q == 3) {
 #ifndef KPN_SIMT_EMU
         uint32_t lo;
-#if KPN_F16_LO_MIXLO   // x - h rounded once to fp16 into the two halves of lo: the same values in two instructions (kpn_split_f16x8)
-        asm volatile("v_fma_mixlo_f16 %0, %3, -1.0, %1 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %3, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                     : "=&v"(lo) : "v"(p.x0), "v"(p.x1), "v"(p.pk));
-#else
         asm volatile("v_fma_mix_f32 %1, %3, -1.0, %1 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
                      "v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(lo), "+v"(p.x0), "+v"(p.x1) : "v"(p.pk));
-#endif
         dst[1][J] = lo;
 #else
         p.x0 = p.x0 - kpn_emu_h_lo(p.pk); p.x1 = p.x1 - kpn_emu_h_hi(p.pk);

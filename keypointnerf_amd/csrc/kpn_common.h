@@ -85,76 +85,60 @@ __device__ __forceinline__ kpn_f32x16 kpn_mfma_f16(kpn_f32x4 a, kpn_u32x4 b, kpn
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(kpn_f16x8, a), __builtin_bit_cast(kpn_f16x8, b), c, 0, 0, 0);
 }
 // eight fp32 values -> two fp16 pieces each, x = h + l to 2^-23 relative (absolute floor 2^-24: fp16's subnormal quantum):
-// h = RNE(x) by v_cvt_pk_f16_f32, x - h formed exactly by ONE v_fma_mix_f32 that reads the fp16 half in place, l = RNE(x - h)
-// (scripts/f16_split_probe.hip).  Plain (movable) asm statements: hipcc has no builtin that selects these forms.
-// A VGPR written by a VALU instruction needs idle states before a v_mfma may read it as a source operand, and hipcc's hazard
-// recogniser only guards producers it can see: with these statements bare, k_fuse_color_h returned NaN colours on the MI355X
-// while the emulator and the compiler-selected form of the same arithmetic were right (bisected on the device: idle states
-// IN FRONT of the statements do not help, idle states BEHIND the two conversions whose results are MFMA operands do).  Hence
-// the "s_nop 1" inside those two statements.  (The pair-tile rows kernels produce their operands a whole step ahead.)
-// (measured on the MI355X: the two-instruction form is SLOWER — +0.17 ms per frame in k_fuse_color_h, +0.5 % in k_geo_rows_f2p;
-// v_fma_mixhi_f16 waits for v_fma_mixlo_f16's partial write of the same register.  Kept as an A/B switch, off.)
-#ifndef KPN_F16_LO_MIXLO
-#define KPN_F16_LO_MIXLO 0
-#endif
+// h = RNE(x) (v_cvt_pk_f16_f32), x - h formed exactly by ONE v_fma_mix_f32 that reads the fp16 half in place, l = RNE(x - h)
+// (scripts/f16_split_probe.hip): four instructions per pair of values.
+//
+// COMPILER-SELECTED instructions, not inline asm (round 5).  Rounds 3-4 wrote the four instructions as (movable) asm statements,
+// and k_fuse_color_h came out WRONG AND NON-DETERMINISTIC on the MI355X in one of two equivalent product orders.  The cause
+// (scripts/isa_asm_hazards.py on the two builds, scripts/repro_asm_waw_hazard.hip): hipcc's hazard recogniser treats an INLINEASM
+// as one opaque instruction and applies none of its MFMA <-> VALU wait-state rules to the instructions inside the string.  The
+// register allocator had put the statement's outputs ("=&v") into DEAD registers of the destination tuple of an MFMA issued three
+// states earlier (a layer whose output block is only partly used: ray_encoder.2's rows 32..34 use 3 of 16 registers), and the
+// MFMA's write-back, eight passes later, overwrote the freshly converted pieces — XDL write -> VALU write (WAW), a pair hipcc pads
+// with wait states only when it can see the VALU instruction.  Which registers the allocator picks changes with every edit; the
+// shipped order was right by luck of allocation, not by construction.  With the conversions, the fused subtract and the packing
+// visible to the compiler every such pair is padded by hipcc itself.
+//   * v_cvt_pk_f16_f32 is what gfx950 selects for fptrunc <2 x float> -> <2 x half>;
+//   * v_fma_mix_f32 is selected for fma(fpext(half), b, c); b = -1.0 must be OPAQUE (an SGPR written by an asm s_mov: an SALU
+//     instruction, no VALU hazard class applies) or the DAG combiner rewrites fma(h, -1, x) into a subtract of a separately
+//     converted half (two more instructions per pair);
+//   * the translation unit is compiled with -fno-slp-vectorize (build.py), or the two fused subtracts of a pair become one
+//     v_pk_fma_f32 behind two v_cvt_f32_f16 (and packed fp32 beside MFMAs is an anti-lever on this chip).
+typedef _Float16 kpn_h2 __attribute__((ext_vector_type(2)));
+typedef float kpn_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float kpn_opaque_minus_one() {
+    float m;
+    asm("s_mov_b32 %0, -1.0" : "=s"(m));   // pure: hoisted out of loops and merged by CSE
+    return m;
+}
 __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& h, kpn_u32x4& l) {
+    const float m1 = kpn_opaque_minus_one();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        uint32_t ph, pl;
-        float r0, r1;
-        // one statement per pair (hipcc puts an s_nop behind every asm result it sees consumed); the idle states behind the last
-        // conversion cover pl, ph is three instructions older
-#ifdef KPN_ABLATE_SPLIT   // timing experiment only (wrong results): the hi piece alone, one instruction per pair instead of four
-        asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=&v"(ph) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-        h[j] = ph; l[j] = 0u;
-        continue;
-#endif
-#if KPN_F16_LO_MIXLO
-        // lo pieces: the fused x - h rounded ONCE to fp16 into the low / high half of the destination (v_fma_mixlo_f16 /
-        // v_fma_mixhi_f16).  x - h is exact in fp32, so this is the same value as fp16(fp32(x - h)) — three instructions per pair
-        // instead of four; bit-identical over 1.7e7 values incl. 3.2e6 fp16 subnormals, infinities, NaNs (scripts/mixlo_probe.hip).
-        asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
-            "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1"
-            : "=&v"(ph), "=&v"(pl) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-        (void)r0; (void)r1;
-#else
-        asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-            "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
-            "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-            "v_cvt_pk_f16_f32 %1, %2, %3\n\ts_nop 1"
-            : "=&v"(ph), "=&v"(pl), "=&v"(r0), "=&v"(r1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-#endif
-        h[j] = ph; l[j] = pl;
+        const kpn_f2 v = {x[2 * j], x[2 * j + 1]};
+        const kpn_h2 hh = __builtin_convertvector(v, kpn_h2);
+        const kpn_f2 r = {__builtin_fmaf((float)hh[0], m1, v[0]), __builtin_fmaf((float)hh[1], m1, v[1])};   // exact
+        const kpn_h2 ll = __builtin_convertvector(r, kpn_h2);
+        h[j] = __builtin_bit_cast(uint32_t, hh);
+        l[j] = __builtin_bit_cast(uint32_t, ll);
     }
 }
 // eight fp32 values -> three bf16 pieces each (x = h + m + l to 2^-24 relative, fp32's exponent range): the packed form of
 // kpn_split3 — v_cvt_pk_bf16_f32 converts two values at once, 5.5 instead of 7.5 instructions per value — for kernels whose
-// operands have a gradient's dynamic range (k_weight_grad).  The conversions' results are MFMA operands: idle states behind them
-// (see kpn_split_f16x8).
-// One asm statement per pair of values (11 instructions): hipcc's hazard recogniser puts an s_nop behind every asm result it sees
-// consumed (it assumes a partial write), i.e. one per instruction when each is its own statement.  TO_MFMA: the last conversion's
-// result may be an MFMA operand in the very next slot -> two idle states behind it (the h and m pieces are older by 5+ slots);
-// false where the pieces go to LDS or sit behind a barrier first (k_weight_grad).
+// operands have a gradient's dynamic range (k_geo_rows_bwd, k_weight_grad).  Compiler-selected for the same reason as above
+// (gfx950 selects v_cvt_pk_bf16_f32 for fptrunc <2 x float> -> <2 x bfloat>; a bf16's fp32 value is its bit pattern shifted).
+typedef __bf16 kpn_b2 __attribute__((ext_vector_type(2)));
 template <bool TO_MFMA = true>
 __device__ __forceinline__ void kpn_split_bf16x8(const float (&x)[8], kpn_bf16x8& h, kpn_bf16x8& m, kpn_bf16x8& l) {
     kpn_u32x4 ph, pm, pl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        uint32_t a, b, c;
-        float r0, r1, t0, t1;
-#define KPN_SPLIT3_BODY                                                                                               \
-        "v_cvt_pk_bf16_f32 %0, %7, %8\n\tv_lshlrev_b32 %5, 16, %0\n\tv_and_b32 %6, 0xffff0000, %0\n\t"               \
-        "v_sub_f32 %3, %7, %5\n\tv_sub_f32 %4, %8, %6\n\t"                                                          \
-        "v_cvt_pk_bf16_f32 %1, %3, %4\n\tv_lshlrev_b32 %5, 16, %1\n\tv_and_b32 %6, 0xffff0000, %1\n\t"               \
-        "v_sub_f32 %3, %3, %5\n\tv_sub_f32 %4, %4, %6\n\t"                                                          \
-        "v_cvt_pk_bf16_f32 %2, %3, %4"
-        if constexpr (TO_MFMA)
-            asm(KPN_SPLIT3_BODY "\n\ts_nop 1" : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-        else
-            asm(KPN_SPLIT3_BODY : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1) : "v"(x[2 * j]), "v"(x[2 * j + 1]));
-#undef KPN_SPLIT3_BODY
-        ph[j] = a; pm[j] = b; pl[j] = c;
+        const kpn_f2 v = {x[2 * j], x[2 * j + 1]};
+        const uint32_t a = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, kpn_b2));
+        const kpn_f2 r = {v[0] - __builtin_bit_cast(float, a << 16), v[1] - __builtin_bit_cast(float, a & 0xffff0000u)};
+        const uint32_t b = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, kpn_b2));
+        const kpn_f2 s = {r[0] - __builtin_bit_cast(float, b << 16), r[1] - __builtin_bit_cast(float, b & 0xffff0000u)};
+        ph[j] = a; pm[j] = b; pl[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, kpn_b2));
     }
     h = __builtin_bit_cast(kpn_bf16x8, ph); m = __builtin_bit_cast(kpn_bf16x8, pm); l = __builtin_bit_cast(kpn_bf16x8, pl);
 }
