@@ -117,7 +117,7 @@ def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, 
         idx = np.nonzero(above)[0]
         sub = {k: got[k][idx] for k in keys}
         subref = {k: ref[k][idx] for k in keys}
-        env = lambda: oracle.render_envelope(osc, wflat, cam_tar, bounds, pix[idx], Sc, Sf, fine=fine, trials=parity_gate.ENVELOPE_TRIALS)
+        env = parity_gate.oracle_envelope(oracle, osc, wflat, cam_tar, bounds, pix[idx], Sc, Sf, fine=fine)
         try:
             rep = parity_gate.check_rays(sub, subref, env, keys=keys, max_widened_fraction=1.0, what="bench frame")
             res["widened"] = len(rep["widened"])
@@ -216,11 +216,11 @@ def time_configs4(L, ops, torch, dev, sd, mode, with_parity=True):
     peak = rows_peak_tflops(mode)
     valid = rows.value / (views * res * res * samples)
     parity = None
-    if with_parity:   # 1,024 rays of this very frame against the oracle (a 32 x 32 lattice over the 4096^2 target)
+    if with_parity:   # 9,216 rays of this very frame against the oracle (a 96 x 96 lattice over the 4096^2 target; 1,024 until round 4)
         try:
             import numpy as np
             from oracle import oracle
-            ys, xs = np.meshgrid(np.arange(32) * 128 + 64, np.arange(32) * 128 + 64, indexing="ij")
+            ys, xs = np.meshgrid(np.arange(96) * 42 + 53, np.arange(96) * 42 + 53, indexing="ij")
             pix = np.stack([xs.reshape(-1), ys.reshape(-1)], -1).astype(np.int32)
             scene_cpu = to_device(scene, "cpu")
             osc, wflat = oracle.OracleScene(scene_cpu), oracle.flat_weights(sd)
@@ -237,7 +237,7 @@ def time_configs4(L, ops, torch, dev, sd, mode, with_parity=True):
                           "rays_above_1e-4": rep["above_bar"], "widened": len(rep["widened"]), "unexplained": 0, "ok": True}
             except AssertionError as e:
                 parity = {"rays": int(pix.shape[0]), "ok": False, "error": str(e)[:400]}
-            parity["sample"] = "1,024 rays (32 x 32 lattice, step 128) of this 4096 x 4096 frame vs the C oracle, V = 10, 128 flat samples"
+            parity["sample"] = "9,216 rays (96 x 96 lattice, step 42) of this 4096 x 4096 frame vs the C oracle, V = 10, 128 flat samples"
             del scene_cpu, osc
         except Exception as e:  # noqa: BLE001
             parity = {"ok": False, "error": f"{type(e).__name__}: {e}"}
@@ -511,9 +511,11 @@ def main():
             for name, kw in ((f"{other}_mask", dict(mask=other, tar_focal_at_512=args.tar_focal)),
                              ("round1_scene_ellipsoid_focal600", dict(mask="ellipsoid", tar_focal_at_512=600.0))):
                 sc2 = to_device(make_scene(n_views=args.views, src_hw=(res, res), tar_hw=(res, res), seed=1, **kw), dev)
-                ms2, rows2 = time_frames(L, ops, torch, sc2, w, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
+                ms2, rows2, kms, ktf = time_frames(L, ops, torch, sc2, w, res, args.samples, fine, steps=max(2, min(args.steps, 5)), with_kernel=True)
                 sec[name] = {"ms_per_frame": ms2, "rays_per_sec": rays_per_step / (ms2 * 1e-3),
-                             "valid_fraction_of_field_evaluations": rows2 / (args.views * rays_per_step * evals_per_ray)}
+                             "valid_fraction_of_field_evaluations": rows2 / (args.views * rays_per_step * evals_per_ray),
+                             "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": ktf, "peak": peak,
+                                          "unit": "TFLOP/s", "frac": ktf / peak, "avg_launch_ms": kms}}
                 del sc2
             if args.density_bias == 0.0:
                 # a density that is exactly 0 in about half of the visual hull (trained models: the free space between the
@@ -548,6 +550,19 @@ def main():
                 except Exception as e:  # noqa: BLE001  (e.g. a box with less host memory): say so, keep the line
                     sec["configs4_full"] = {"error": f"{type(e).__name__}: {e}"}
             line["secondary"] = sec
+            # the dominant kernel's fraction of its roof on the three workloads the headline is quoted beside (same kernel, same
+            # accounting: algorithmic FLOP of the rows it processed / its launch time inside the library)
+            side = {"configs[1] ellipsoid mask (headline)": {"frac": line["roofline"]["frac"], "achieved": achieved, "avg_launch_ms": line["roofline"]["avg_launch_ms"],
+                                                              "ms_per_frame": line["ms_per_step"], "rays_per_sec": value}}
+            dm = sec.get("dense_mask")
+            if dm:
+                side["configs[1] dense mask (80 % of the field evaluations valid)"] = dict(dm["roofline"], ms_per_frame=dm["ms_per_frame"], rays_per_sec=dm["rays_per_sec"])
+            c4 = sec.get("configs4_full")
+            if c4 and "roofline" in c4:
+                side["configs[4] at full size (4096^2 rays, V = 10, 128 flat samples)"] = dict(c4["roofline"], ms_per_frame=c4["ms_per_step"], rays_per_sec=c4["rays_per_sec"],
+                                                                                            parity_ok=(c4.get("parity") or {}).get("ok"))
+            line["roofline"]["workloads"] = {k: {kk: vv for kk, vv in v.items() if kk in ("frac", "achieved", "peak", "avg_launch_ms", "ms_per_frame", "rays_per_sec", "parity_ok")}
+                                             for k, v in side.items()}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             port, parity = cpu_baseline(args, scene_cpu, sd, fine=fine, frame=frame_np)
             # the timed frame itself, compared with the oracle on the rays the CPU baseline renders anyway

@@ -230,7 +230,9 @@ typedef struct kpn_render_args {
                                  * one frame's rows dealt round-robin to the ranks of a render job (rank r of W: y0 = r,
                                  * step_y = W), SURVEY 8(e) */
     int32_t rows_kernel;        /* KPN_ROWS_*: the rows kernel of THIS call; 0 = the process-wide selection (kpn_set_geo_rows_mode) */
-    int32_t fuse_kernel;        /* KPN_FUSE_*: the per-point kernel of THIS call; 0 = the process-wide selection (kpn_set_fuse_mode) */
+    int32_t fuse_kernel;        /* KPN_FUSE_*: the per-point kernel of THIS call; 0 = the process-wide selection (kpn_set_fuse_mode).
+                                 * kpn_render_rays only: the kpn_render_rays_train* entry points (forward, kept state, backward
+                                 * recompute must run the same kernels) refuse a non-zero selection with KPN_EINVAL */
 } kpn_render_args;
 /* per-call kernel selection (kpn_render_args): the same kernels as kpn_set_geo_rows_mode(0 / 2 / 3) and kpn_set_fuse_mode(0 / 1) */
 enum { KPN_ROWS_DEFAULT = 0, KPN_ROWS_F32 = 1, KPN_ROWS_BF16X3 = 2, KPN_ROWS_F16X2 = 3 };

@@ -330,7 +330,7 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     // v_readlane_b32 and the five wait states a VALU-written SGPR needs before a memory instruction may read it.
     int prev_pos = 0;
     const float* gp = hseg;
-    auto load_half = [&](int s, int ob0, int n, auto& w) {
+    auto load_half = [&](int s, int ob0, int n, auto& w, bool reload = false) {
 #ifdef KPN_DBG_H2_SAMEW   // timing experiment (wrong results): every step reads the weights of step 0 -> the stream stays in L1
         const int pos = (ob0 * NP + NP) * (64 * 4);
 #else
@@ -340,6 +340,15 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
         prev_pos = pos;
         KPN_PIN_POINTER(gp);
         const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
+#ifdef KPN_DBG_H2_NOW     // timing experiment (wrong results): a layer's weight registers are loaded once (steps 0 and 1) and never reloaded
+        if (reload) {
+#pragma unroll
+            for (int k = 0; k < n; ++k)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) asm volatile("" : "+v"(w[pc][k]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < n; ++k)
 #pragma unroll
@@ -349,7 +358,7 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     auto load_virtual = [&](auto vsi, auto hfi) {
         constexpr int vs = decltype(vsi)::value, hf = decltype(hfi)::value, b = wsel(vs);
         if constexpr (vs < KS16) {
-            if constexpr (hf == 0) load_half(SMAP::at(vs), 0, H0, wa[b]); else load_half(SMAP::at(vs), H0, H1, wb[b]);
+            if constexpr (hf == 0) load_half(SMAP::at(vs), 0, H0, wa[b], vs >= WBUF); else load_half(SMAP::at(vs), H0, H1, wb[b], vs >= WBUF);
         }
     };
     // MFMA number m of a step: half, then product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi — the order k_geo_rows_h

@@ -871,25 +871,23 @@ int range_guard() {
     if (g_range_guard < 0) { const char* e = getenv("KPN_NO_RANGE_GUARD"); g_range_guard = (e && atoi(e) != 0) ? 0 : 1; }
     return g_range_guard;
 }
-// batches evaluated again by the fp32-range kernels since the library was loaded, per device (a device int the per-point kernel
-// of such a launch increments; read by kpn_range_guard_count)
-int* g_redone_dev[64] = {nullptr};
-int* redone_counter() {
-    int dev = 0;
+// batches evaluated again by the fp32-range kernels since the library was loaded, per device: a device GLOBAL of this module (one
+// instance per device, zero-initialised when the module is loaded) that the per-point kernel of such a launch increments and
+// kpn_range_guard_count reads.  No allocation, no synchronisation on the render path (round 4 hipMalloc'ed the counter inside the
+// first guarded render: an advisor finding — a first frame captured into a HIP graph would have been invalidated).
 #ifndef KPN_SIMT_EMU
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-#endif
-    if (!g_redone_dev[dev]) {
-        void* p = nullptr;
-        if (hipMalloc(&p, 64) != hipSuccess) return nullptr;
-#ifndef KPN_SIMT_EMU
-        if (hipMemset(p, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+__device__ int kpn_redone_batches;
 #else
-        memset(p, 0, 64);
+static int kpn_redone_batches;
 #endif
-        g_redone_dev[dev] = static_cast<int*>(p);
-    }
-    return g_redone_dev[dev];
+int* redone_counter() {
+#ifndef KPN_SIMT_EMU
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(kpn_redone_batches)) != hipSuccess) return nullptr;
+    return static_cast<int*>(p);
+#else
+    return &kpn_redone_batches;
+#endif
 }
 
 void launch_rows(int rows_mode, const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, const int* list, const int* count,
@@ -1581,6 +1579,10 @@ int train_impl(const kpn_scene_desc* d, const void* scene_ws, const float* wp, c
     if (int e = check_desc(d)) return e;
     if (int e = check_render(a)) return e;
     KPN_REQUIRE(t != nullptr, "train args null");
+    // the forward, its kept state and the backward's recompute must run the SAME kernels: the train branch follows the process-wide
+    // selection only (kpn_set_geo_rows_mode / kpn_set_fuse_mode); a per-call selection is refused rather than silently replaced
+    KPN_REQUIRE(a->rows_kernel == KPN_ROWS_DEFAULT && a->fuse_kernel == KPN_FUSE_DEFAULT,
+                "the train branch takes the process-wide kernel selection: rows_kernel / fuse_kernel must be 0");
     KPN_REQUIRE(a->fine, "the train branch renders coarse + fine (dr_kwargs.fine)");
     KPN_REQUIRE(scene_ws && wp, "null pointer");
     KPN_REQUIRE(t->pix && t->u_coarse && t->u_fine, "train args: pix, u_coarse, u_fine are required");

@@ -168,11 +168,19 @@ def _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
 # are kept for the backward call instead of being built twice.  Autograd hands the backward op NEW tensor objects over the same
 # storage, so the key is (storage address, version counter, shape, device) per tensor — and the entry HOLDS the forward call's
 # input tensors: while it lives their storage cannot be freed, so an equal address means the same storage, and an in-place change
-# in between moves the version counter: a miss, never a stale hit.  The backward op drops the entry when it is done (nothing of an
-# iteration stays resident after it); one entry per thread.
+# in between moves the version counter: a miss, never a stale hit.  The backward op drops the entry when it is done: nothing of
+# an iteration stays resident after it.
+# ONE entry for the process, behind a lock (round 5; an advisor finding): for CUDA tensors autograd runs the backward op on its
+# device worker thread, not on the thread that ran the forward — a thread-local entry was never found by the backward (which then
+# built the scene and the packed weights a second time, the very work the cache exists to avoid) and never cleared on the forward's
+# thread.  Two threads training different models in one process take turns at the single entry: a miss, never a wrong hit.
 import threading
 
-_iter_cache = threading.local()
+
+class _IterCache:
+    lock = threading.Lock()
+    key = scene = w = pinned = None
+    hits = misses = 0      # observable by the tests
 
 
 def _tensor_key(t):
@@ -182,18 +190,23 @@ def _tensor_key(t):
 
 
 def _iter_cache_clear():
-    _iter_cache.key = _iter_cache.scene = _iter_cache.w = _iter_cache.pinned = None
+    with _IterCache.lock:
+        _IterCache.key = _IterCache.scene = _IterCache.w = _IterCache.pinned = None
 
 
 def _scene_and_weights(plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal):
     tensors = (plain, geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask)
     key = tuple(_tensor_key(t) for t in tensors) + (tuple(scal),)
-    if any(t is not None and t.is_inference() for t in tensors) or key != getattr(_iter_cache, "key", None):
-        _iter_cache.scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal)
-        _iter_cache.w = ops.PackedWeights.from_plain(plain, device=geo0.device)
-        _iter_cache.key = key
-        _iter_cache.pinned = tensors
-    return _iter_cache.scene, _iter_cache.w
+    with _IterCache.lock:
+        if not any(t is not None and t.is_inference() for t in tensors) and key == _IterCache.key:
+            _IterCache.hits += 1
+            return _IterCache.scene, _IterCache.w
+    scene = _raw_scene(geo0, geo1, tex, img, KRT, extrin, kpt3d, fg_mask, scal)
+    w = ops.PackedWeights.from_plain(plain, device=geo0.device)
+    with _IterCache.lock:
+        _IterCache.misses += 1
+        _IterCache.key, _IterCache.scene, _IterCache.w, _IterCache.pinned = key, scene, w, tensors
+    return scene, w
 
 
 @_lib.custom_op("kpnerf::render_rays_train", mutates_args=(), device_types="cuda")

@@ -8,5 +8,5 @@ for lib in "$@"; do
   echo "$line" | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
-print(f\"$lib rep $rep: {d['ms_per_step']:.3f} ms/frame, rows kernel {d['roofline']['avg_launch_ms']:.3f} ms x {d['roofline']['launches']}, frac {d['roofline']['frac']:.3f}\")"
+print(f\"$lib rep $rep: {d['ms_per_step']:.3f} ms/frame, rows kernel {d['roofline']['avg_launch_ms']:.3f} ms x {d['roofline']['launches']}, frac {d['roofline']['frac']:.3f}, clock {d['roofline'].get('effective_clock_ghz')}, per-point kernel {d.get('secondary', {}).get('fuse_kernel_ms', '')}\")"
 done; done

@@ -42,8 +42,9 @@ def oracle_envelope(oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine=True,
 
 def check_rays(out, ref, envelope_fn, keys=("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"), tol=RGBA_TOL, cap=0.1, cap_envelopes=20.0,
                max_widened_fraction=2e-3, what=""):
-    """out / ref: {key: (R,) or (R,3) arrays}; envelope_fn(idx) (or envelope_fn()) -> {key: (R,)} is only called when some ray is
-    above `tol`."""
+    """out / ref: {key: (R,) or (R,3) arrays}; envelope_fn(idx) -> {key: (R,)} (oracle_envelope above) is only called when some
+    ray is above `tol`, with the indices of those rays.  (A failure INSIDE the probe propagates: round 4 retried with no arguments
+    on any TypeError, which could hide a bad dtype or shape in the probe behind a different envelope — an advisor finding.)"""
     keys = [k for k in keys if k in ref and k in out]
     err = {}
     for k in keys:
@@ -56,10 +57,7 @@ def check_rays(out, ref, envelope_fn, keys=("tex_fg", "alpha", "tex_fg_fine", "a
     report = {"rays": R, "above_bar": int(above.sum()), "max_err": {k: float(np.nanmax(err[k])) for k in keys}, "widened": [], "failed": []}
     if not above.any():
         return report
-    try:
-        env = envelope_fn(np.nonzero(above)[0])        # (oracle_envelope above: the probe on the suspicious rays only)
-    except TypeError:
-        env = envelope_fn()
+    env = envelope_fn(np.nonzero(above)[0])            # (oracle_envelope above: the probe on the suspicious rays only)
     flag = tol / 3.0
     for r in np.nonzero(above)[0]:
         ok = True

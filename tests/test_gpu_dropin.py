@@ -253,7 +253,13 @@ def test_training_step_through_the_dropin(monkeypatch, case, seed):
     for k in keys:
         assert out[k].shape == g["out." + k].shape, k
         assert np.abs(out[k].detach().cpu().numpy() - g["out." + k]).max() <= 1e-4, k
+    from keypointnerf_amd import torch_ops
+    hits0, misses0 = torch_ops._IterCache.hits, torch_ops._IterCache.misses
+    assert torch_ops._IterCache.key is not None, "the forward leaves its prepared scene / packed weights for the backward"
     sum((out[k] * torch.from_numpy(g["G." + k]).cuda()).sum() for k in keys).backward()
+    # the backward op runs on autograd's device worker thread: it must FIND the forward's entry (one hit, nothing rebuilt) and drop it
+    assert (torch_ops._IterCache.hits, torch_ops._IterCache.misses) == (hits0 + 1, misses0)
+    assert torch_ops._IterCache.key is None and torch_ops._IterCache.pinned is None
     # p.grad of the module's own parameters -> the flat layout the shared checker reads
     from keypointnerf_amd.synthetic import HOTPATH_LAYERS
     params = dict(net.named_parameters())
