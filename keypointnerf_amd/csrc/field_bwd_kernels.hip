@@ -31,13 +31,9 @@ struct kpn_bwd_bufs {
     float* dgeo0;  // V x g0h x g0w x 64, accumulated
     float* dgeo1;  // V x g1h x g1w x 8, accumulated
 };
-#ifdef KPN_ABLATE_DUMP  // timing experiment only (wrong results): no activation / gradient dumps
-#define KPN_ST4(p, v) ((void)0)
-#define KPN_ST1(p, v) ((void)0)
-#else
 // The dumps are written once and read once by a later kernel (k_weight_grad; 2.5 GB per training iteration from this kernel alone):
 // streaming stores (global_store ... nt) keep them from displacing the weight streams and the feature maps in L2.  Measured:
-// backward 4.98 -> 4.80 ms; without any dump stores (-DKPN_ABLATE_DUMP) 4.48 ms.  -DKPN_DUMP_NT=0 restores plain stores.
+// backward 4.98 -> 4.80 ms; without any dump stores (KPN_ABLATE_DUMP, scripts/experiments/ablation_switches.patch) 4.48 ms.  -DKPN_DUMP_NT=0 restores plain stores.
 #ifndef KPN_DUMP_NT
 #define KPN_DUMP_NT 1
 #endif
@@ -48,7 +44,6 @@ typedef float kpn_nt4 __attribute__((ext_vector_type(4)));
 #define KPN_ST4(p, v) (*reinterpret_cast<float4*>(p) = (v))
 #endif
 #define KPN_ST1(p, v) (*(p) = (v))
-#endif
 #define KPN_STAGE_LD 132  // 128 floats + pad: rows start on different banks, float4-aligned
 #define KPN_SCAT_LD KPN_STAGE_LD
 #ifndef KPN_BWD_OCC

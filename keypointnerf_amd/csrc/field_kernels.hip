@@ -464,11 +464,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         KPN_FUSE_STAMP(0);
         // ---- pooled mean / var over views of the 64-vector ----
         const float4* const scr = reinterpret_cast<const float4*>(xscr);
-#ifdef KPN_DBG_FUSE_SAMETILE   // timing experiment (wrong results): every tile reads tile 0's block of the scratch -> cache hits
-        const int t_scr = 0;
-#else
         const int t_scr = t;
-#endif
         const float4* rows = scr + lay.tile(t_scr) * 64;
         const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
         float pwsum;
@@ -657,9 +653,12 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             for (int r = 0; r < 8; ++r) o8[r] = kpn_elu(va[0][r]);
             kpn_load_bias<1>(wl + W::boff(SEG_O_1), h, va);
             kpn_fuse_layer_regs<F16, SEG_O_1, 8, 1>(wl, lane, o8, va);
+            // out_layer.2 has 8 outputs: rows 0..3 in registers 0..3 of the h = 0 lanes, rows 4..7 in those of the h = 1 lanes; the other
+            // twelve registers of the block are padding (zero weights in out_layer.4's row vector): four ELUs, not sixteen
+            float o4[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tin[r] = kpn_elu(va[0][r]);
-            const float logit = kpn_row_dot(wl + W::row(ROW_O_2), h, tin);  // out_layer.4
+            for (int r = 0; r < 4; ++r) o4[r] = kpn_elu(va[0][r]);
+            const float logit = kpn_row_dot4(wl + W::row(ROW_O_2), h, o4);  // out_layer.4
             const float nmax = fmaxf(lmax, logit);
             const float sc_old = kpn_fast_exp(lmax - nmax), pn = kpn_fast_exp(logit - nmax);
             lden = lden * sc_old + pn;

@@ -31,11 +31,9 @@ __device__ __forceinline__ void kpn_ld_chain(const float* __restrict__ base, int
 }
 template <int NQ>
 __device__ __forceinline__ void kpn_st_chain(float* __restrict__ base, int h, const float (&x)[4 * NQ]) {
-#ifndef KPN_ABLATE_DUMP2   // (timing experiment only: no dumps from k_fuse_bwd / k_color_bwd, wrong results)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
         KPN_ST_ROW4(base + 8 * q + 4 * h, make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
-#endif
 }
 
 struct kpn_fuse_bwd_bufs {

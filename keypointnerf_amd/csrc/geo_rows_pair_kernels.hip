@@ -322,43 +322,39 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     auto wsel = [](int s) constexpr { return SC::WBUF == 2 ? (s & 1) : 0; };
     kpn_f32x4 wa[WBUF][NP][H0], wb[WBUF][NP][H1];
     kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, 0u};
-    // A half's pieces are contiguous ([step][block][piece][lane]): one scalar base in its middle, immediate offsets of
-    // -3..+2 KB (the 13-bit signed range of global_load), the lane offset in one register for the whole kernel.  The base is
-    // a RUNNING pointer advanced from one half to the next (s_add_u32 + s_addc_u32, then re-defined through an empty asm so
-    // that the loads cannot rise above it): computed as `segment + constant` every one of the 82 bases of a work item is
-    // loop-invariant, and hipcc hoisted them all out of the work loop into SGPRs it then had to spill — each use cost two
-    // v_readlane_b32 and the five wait states a VALU-written SGPR needs before a memory instruction may read it.
-    int prev_pos = 0;
-    const float* gp = hseg;
-    auto load_half = [&](int s, int ob0, int n, auto& w, bool reload = false) {
-#ifdef KPN_DBG_H2_SAMEW   // timing experiment (wrong results): every step reads the weights of step 0 -> the stream stays in L1
-        const int pos = (ob0 * NP + NP) * (64 * 4);
-#else
-        const int pos = s * (NP * NOB * 64 * 4) + (ob0 * NP + NP) * (64 * 4);   // s: stream step
+    // A step's pieces are contiguous ([step][block][piece][lane] x 16 B: 8 KB with four output blocks): ONE uniform base for the
+    // layer (SGPR pair), a per-lane byte offset in a VGPR that points at the MIDDLE of the current step, and immediate offsets of
+    // -4 .. +3 KB (the 13-bit signed range of global_load) for its eight 1-KB rows: the offset register is advanced once per step
+    // by one v_add_u32 (re-defined through an empty asm so that the loads cannot rise above it).  Until round 4 the base was a
+    // running SGPR pointer advanced per HALF step: s_add_u32 + s_addc_u32 = 290 scalar instructions per (tile pair, view) in a
+    // kernel that is bound by its issue slots at one wave per SIMD (profiles/r05_b_rows_kernel_ablations.txt).  (Computed as
+    // `segment + constant` the bases are loop-invariant, and hipcc hoists them out of the work loop into SGPRs it then spills.)
+    constexpr int STEP_BYTES = NP * NOB * 64 * 16;
+    int prev_step = 0;
+    uint32_t voff = (uint32_t)lane * 16u + (uint32_t)(STEP_BYTES / 2);
+#ifndef KPN_SIMT_EMU
+    asm volatile("" : "+v"(voff));
 #endif
-        gp += pos - prev_pos;
-        prev_pos = pos;
-        KPN_PIN_POINTER(gp);
-        const kpn_gptr4 src = KPN_GLOBAL4(gp) + lane;
-#ifdef KPN_DBG_H2_NOW     // timing experiment (wrong results): a layer's weight registers are loaded once (steps 0 and 1) and never reloaded
-        if (reload) {
-#pragma unroll
-            for (int k = 0; k < n; ++k)
-#pragma unroll
-                for (int pc = 0; pc < NP; ++pc) asm volatile("" : "+v"(w[pc][k]));
-            return;
+    auto load_half = [&](int s, int ob0, int n, auto& w) {
+        if (ob0 == 0 && s != prev_step) {           // (compile-time: s and prev_step are constants after unrolling)
+            voff += (uint32_t)((s - prev_step) * STEP_BYTES);
+            prev_step = s;
+#ifndef KPN_SIMT_EMU
+            asm volatile("" : "+v"(voff));
+#endif
         }
-#endif
+        const char* row0 = reinterpret_cast<const char*>(hseg) + voff;
 #pragma unroll
         for (int k = 0; k < n; ++k)
 #pragma unroll
-            for (int pc = 0; pc < NP; ++pc) w[pc][k] = src[(k * NP + pc - NP) * 64];
+            for (int pc = 0; pc < NP; ++pc)
+                w[pc][k] = *KPN_GLOBAL4(row0 + ((ob0 + k) * NP + pc) * 1024 - STEP_BYTES / 2);
     };
     // half hf (0 / 1) of step vs into the buffer that step reads
     auto load_virtual = [&](auto vsi, auto hfi) {
         constexpr int vs = decltype(vsi)::value, hf = decltype(hfi)::value, b = wsel(vs);
         if constexpr (vs < KS16) {
-            if constexpr (hf == 0) load_half(SMAP::at(vs), 0, H0, wa[b], vs >= WBUF); else load_half(SMAP::at(vs), H0, H1, wb[b], vs >= WBUF);
+            if constexpr (hf == 0) load_half(SMAP::at(vs), 0, H0, wa[b]); else load_half(SMAP::at(vs), H0, H1, wb[b]);
         }
     };
     // MFMA number m of a step: half, then product (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi — the order k_geo_rows_h
@@ -607,9 +603,6 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
                 cz[t] = RADD(kpn_dot3(P[t][0], P[t][1], P[t][2], E[8], E[9], E[10]), E[11]);
                 kpn_load_bias<4>(bias_s[0], h, a0[t]);
                 tp[t] = kpn_make_taps(q[t].xn, q[t].yn, sc.g0h, sc.g0w);
-#ifdef KPN_DBG_H2_SAMETAP   // timing experiment (wrong results): every lane gathers the same texels -> two cache lines per load
-                tp[t].o00 = 0; tp[t].o01 = 1; tp[t].o10 = 2; tp[t].o11 = 3;
-#endif
             }
             const float* kc = tb + KPN_TBL_KCAM + (12 * h) * 3;
             const float* g0 = sc.geo0 + (size_t)v * sc.g0h * sc.g0w * 64 + 8 * h;
@@ -621,7 +614,7 @@ __device__ __forceinline__ void kpn_geo_rows_pair_body(const kpn_scene_dev& sc, 
             // Tried and dropped for the geometry steps: the taps fetched COALESCED, four whole texels per
             // instruction landing in LDS (global_load_lds_dwordx4, the texel index of a point by ds_bpermute, a rotated chunk order
             // for conflict-free reads): correct, 5 % SLOWER — 510 more instructions per work item in a kernel that is issue-bound,
-            // although with every lane gathering the same texels (-DKPN_DBG_H2_SAMETAP) the kernel runs 12 % faster.
+            // although with every lane gathering the same texels (scripts/experiments/ablation_switches.patch: KPN_DBG_H2_SAMETAP) the kernel runs 12 % faster.
             float fdz[2][2], fw[2][2], fs1[2][2], fc1[2][2];
             float kcv[2][3] = {{kc[0], kc[1], kc[2]}, {kc[3], kc[4], kc[5]}};   // keypoints of steps 0 and 1 (this half's 12)
             float tdx[2], tdy[2], ty[2], targ[2], ts2[2], tc2[2];

@@ -41,10 +41,6 @@ typedef const kpn_f32x4* kpn_lptr4;
 #ifndef KPN_SIMT_EMU
 // hardware global_atomic_add_f32 (no CAS loop); the sum order is not deterministic
 __device__ __forceinline__ void kpn_atomic_add(float* p, float v) {
-#ifdef KPN_ABLATE_ATOMIC  // timing experiment only (wrong results)
-    if (v == 1234.5f) *p = v;
-    return;
-#endif
     unsafeAtomicAdd(p, v);
 }
 #else

@@ -46,9 +46,6 @@ __device__ __forceinline__ float kpn_sigmoid(float x) { return 1.0f / (1.0f + kp
 // Softplus(beta=100, threshold=20), reference src/utils.py:523-524.  log(1+e^t)/100: the /100 makes
 // the fast exp/log's ~1e-6 relative error an absolute error < 1e-8.
 __device__ __forceinline__ float kpn_softplus100(float x) {
-#ifdef KPN_ABLATE_ACT  // timing experiment only: wrong results
-    return x;
-#endif
     const float sp = kpn_log2(1.0f + kpn_exp2(x * 144.269504088896341f)) * 6.93147180559945309e-3f;  // ln2/100
     return (x * 100.0f > 20.0f) ? x : sp;
 }
@@ -90,9 +87,6 @@ __device__ __forceinline__ void kpn_sincos_pi(float z, float& s, float& c) {
 #endif
 }
 __device__ __forceinline__ float kpn_elu(float x) {
-#ifdef KPN_ABLATE_ELU  // timing experiment only: wrong results
-    return x;
-#endif
     // ELU(x) = x if x >= 0 else e^x - 1 (torch.nn.ELU) as compare + select.  Round 3 used one v_med3_f32 (median(x, e^x - 1, 0));
     // a median drops NaNs (v_med3_f32 returns min3 when an input is a NaN, and min3 returns the numeric operand), so an overflowed
     // fp16 operand of k_fuse_color_h — NaN in every accumulator it touches — came out of the next ELU as 0 and the point as a
@@ -221,15 +215,9 @@ __device__ __forceinline__ void kpn_load_bias(const float* __restrict__ bseg, in
 template <int NQ, int MEM>
 __device__ __forceinline__ void kpn_load_group(const float* __restrict__ gbase, int lane, kpn_f32x4 (&w)[NQ]) {
     if constexpr (MEM == 0) {
-#ifdef KPN_ABLATE_WLOAD  // timing experiment only (wrong results): no weight traffic at all
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { const float f = 1e-3f * (float)(lane + q); w[q] = kpn_f32x4{f, -f, f, -f}; }
-        (void)gbase;
-#else
         const kpn_gptr4 src = KPN_GLOBAL4(gbase) + lane * NQ;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) w[q] = src[q];
-#endif
     } else {
         // LDS copy of a stream: [group][q][64 lanes] float4 (re-laid by kpn_stage_lds_streams).  ds_read_b128 is served in
         // four 16-lane groups over a 256-B bank row: consecutive lanes 16 B apart fill it exactly, whereas the global
@@ -312,8 +300,8 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
 // The same Linear layer on v_mfma_f32_32x32x16_f16 with two fp16 pieces per operand and three products per term set (the
 // k_geo_rows_f2 arithmetic, geo_rows_pair_kernels.hip) for the per-point kernel: the stream is the LDS copy of a kpn_cseg_*
 // segment (kpn_common.h), KS fp32 K-steps taken eight at a time.  in_fn has kpn_mfma_layer's signature with G = 4
-// (in_fn(kpn_ic<g>, float (&x)[4]) = K-steps 4g .. 4g+3); a chunk is two such groups.  Compiler-scheduled: two waves share a
-// SIMD in this kernel.  3 MFMAs of 32 cycles per (chunk, block) against 8 of 64 on the fp32 pipe.
+// (in_fn(kpn_ic<g>, float (&x)[4]) = K-steps 4g .. 4g+3); a chunk is two such groups.  Compiler-scheduled, every instruction
+// compiler-selected (no asm statement: hipcc pads every MFMA <-> VALU pair itself); two waves share a SIMD in this kernel.  3 MFMAs of 32 cycles per (chunk, block) against 8 of 64 on the fp32 pipe.
 template <int KS, int NOB, class InFn>
 __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
     constexpr int NC = (KS + 7) / 8, NG = (KS + 3) / 4;
@@ -336,22 +324,15 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
-            // Three products (ll dropped: <= 2^-24 of a term, as in the rows kernel), in the order hh LH HL.  In the order hh hl lh this
-            // kernel — two waves per SIMD, compiler-scheduled — came out WRONG and NON-DETERMINISTIC on the MI355X (62 % of the points
-            // off, different points from run to run; right on the emulator; -DKPN_FUSE_F16_ORDER_HLFIRST rebuilds it).  The cause is
-            // not established: the order only changes hipcc's schedule and register assignment, and nothing the static checks of
-            // the two instruction streams look for (a source register rewritten behind an MFMA, a result read too early) tells
-            // them apart (the obvious suspect, a weight register reloaded from LDS behind the last of a chain of dependent MFMAs with
-            // another wave's MFMAs in the pipe, is harmless: scripts/mfma_src_reload_probe.hip).  What is established is the behaviour of THIS order: 1.4e10 row evaluations bit-identical run to run and
-            // within fp32 class of the fp32 kernels (scripts/soak_mode2.py, both masks), the GPU suite and the 200-scene sweep pass.
-            // Any change to this kernel's instruction stream has to pass the same soak before it ships.
+            // Three products (ll dropped: <= 2^-24 of a term, as in the rows kernel), in the order hh lh hl.  (Round 4: with the order
+            // hh hl lh this kernel came out wrong and non-deterministic on the MI355X.  Not the order: the operand splits were asm
+            // statements then, and in that build the register allocator had put their outputs into dead registers of an MFMA's
+            // destination tuple still in flight — a write-after-write pair hipcc only pads when it sees the VALU instruction
+            // (kpn_common.h kpn_split_f16x8, scripts/repro_asm_waw_hazard.hip).  With compiler-selected splits both orders pass the
+            // soak and the GPU suite: profiles/r05_a_waw_hazard.txt.)
             acc[ob] = kpn_mfma_f16(ah, bh, acc[ob]);
             if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); acc[ob] = kpn_mfma_f16(al, bl, acc[ob]); }
-#ifdef KPN_FUSE_F16_ORDER_HLFIRST   // the order that came out wrong on the device (see above); experiments only
-            else { acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); }
-#else
             else { acc[ob] = kpn_mfma_f16(al, bh, acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl, acc[ob]); }
-#endif
         }
     });
 }
@@ -368,11 +349,7 @@ __device__ __forceinline__ void kpn_hlayer_presplit(const float* __restrict__ ws
             const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
             acc[ob] = kpn_mfma_f16(ah, bh[c], acc[ob]);
             if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bl[c], acc[ob]); }
-#ifdef KPN_FUSE_F16_ORDER_HLFIRST
-            else { acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); }
-#else
             else { acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); }
-#endif
         }
     });
 }
@@ -553,5 +530,11 @@ __device__ __forceinline__ float kpn_row_dot(const float* __restrict__ rowvec, i
         acc = fmaf(w.x, x[4 * q + 0], acc); acc = fmaf(w.y, x[4 * q + 1], acc);
         acc = fmaf(w.z, x[4 * q + 2], acc); acc = fmaf(w.w, x[4 * q + 3], acc);
     }
+    return acc + __shfl_xor(acc, 32) + rowvec[32];
+}
+// the same for a layer whose input has 8 rows (registers 0..3 of either half; the row vector's other entries are zero padding)
+__device__ __forceinline__ float kpn_row_dot4(const float* __restrict__ rowvec, int h, const float (&x)[4]) {
+    const float4 w = *reinterpret_cast<const float4*>(rowvec + h * 16);
+    const float acc = fmaf(w.w, x[3], fmaf(w.z, x[2], fmaf(w.y, x[1], w.x * x[0])));
     return acc + __shfl_xor(acc, 32) + rowvec[32];
 }

@@ -139,12 +139,7 @@ __device__ __forceinline__ float kpn_pix_weight_fast(const kpn_proj& q) {
 __device__ __forceinline__ void kpn_row_record_a(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, const kpn_proj& q,
                                                  const float (&P)[3], const float (&D)[3], float4& rec0, float4& rec1) {
     const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
-#ifdef KPN_DBG_REC_NOLOAD
-    const float4 c = make_float4(0.3f, 0.4f, 0.5f, 1.0f);
-    (void)ti;
-#else
     const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
-#endif
     rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
     const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
     float cr[3] = {RSUB(P[0], cp[0]), RSUB(P[1], cp[1]), RSUB(P[2], cp[2])};
@@ -157,26 +152,13 @@ __device__ __forceinline__ void kpn_row_record_a(const kpn_scene_dev& sc, const 
 __device__ __forceinline__ void kpn_row_record_b(const kpn_scene_dev& sc, int v, const kpn_proj& q, float4& rec0, float4& rec1) {
     const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
     const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
-#ifdef KPN_DBG_REC_NOLOAD
-    rec0 = make_float4(0.1f, 0.2f, -0.1f, 0.3f); rec1 = make_float4(-0.2f, 0.1f, 0.0f, 0.2f);
-    (void)tt; (void)tx;
-#else
     rec0 = kpn_tap4(tx, 8, 0, tt);
     rec1 = kpn_tap4(tx, 8, 4, tt);
-#endif
 }
 // both parts by the lane layout of the row scratch: h = 0 lanes part A, h = 1 lanes part B
 __device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, int h,
                                                const kpn_proj& q, const float (&P)[3], const float (&D)[3], float4& rec0,
                                                float4& rec1) {
-#ifdef KPN_DBG_REC_NOBRANCH   // bisection: both halves compute both parts, then select
-    float4 ra0, ra1, rb0, rb1;
-    kpn_row_record_a(sc, tb, v, q, P, D, ra0, ra1);
-    kpn_row_record_b(sc, v, q, rb0, rb1);
-    rec0 = h ? rb0 : ra0;
-    rec1 = h ? rb1 : ra1;
-    return;
-#endif
     if (h == 0) kpn_row_record_a(sc, tb, v, q, P, D, rec0, rec1);
     else kpn_row_record_b(sc, v, q, rec0, rec1);
 }
