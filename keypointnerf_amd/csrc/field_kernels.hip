@@ -412,7 +412,15 @@ __device__ unsigned long long kpn_fuse_cycles[8];
 #else
 #define KPN_FUSE_STAMP(i) ((void)0)
 #endif
-template <bool F16>
+// VFIX > 0: the number of source views is known at compile time and none of them is dropped (eval passes with the shipped V = 3,
+// src/zju_dataset.py:45): the STATISTICS loops over the views (blend weights, gather -> ray_encoder -> x' -> Welford update) are
+// unrolled, so that the scheduler sees the views' independent chains in one block and starts a view's gather loads and matrix
+// chains under another view's arithmetic.  Measured on the MI355X (same box, profiles/r05_d_per_point_kernel_variants.txt): frame
+// 21.25 -> 21.04 ms with 18 VGPRs spilled to scratch; the per-view HEADS unrolled as well spill 84 VGPRs at two waves per SIMD, and
+// as ONE wave per SIMD with 512 registers (no spills) the frame is 21.8-22.0 ms: hipcc keeps every head's MFMA chain contiguous
+// (12 dependent MFMAs in a row), it does not interleave the three heads, and the accumulators move to AGPRs (518 v_accvgpr_read).
+// VFIX = 0: any V <= KPN_MAXV, any keep mask.
+template <bool F16, int VFIX = 0>
 __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
                                                     const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                     int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
@@ -428,7 +436,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;   // before the LDS staging
     if (batch.cond == KPN_RUN_IF_UNSAFE && batch.redone != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(batch.redone, 1);
     const int ntiles = t1 - t0;
-    const int V = sc.V;
+    const int V = VFIX > 0 ? VFIX : sc.V;
     const kpn_tile_layout lay(batch.pool, V);   // ROWS or POOL layout of the scratch (kpn_field_shared.h)
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
     // wl is biased so that the packed-buffer offsets (kpn_seg_woff etc.) index it directly
@@ -466,7 +474,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         const float4* const scr = reinterpret_cast<const float4*>(xscr);
         const int t_scr = t;
         const float4* rows = scr + lay.tile(t_scr) * 64;
-        const uint32_t keep = sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
+        const uint32_t keep = VFIX > 0 ? 0xFFFFFFFFu : sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
         float pwsum;
         float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
         if (lay.pool) {    // POOL layout: the rows kernel has pooled already (slabs 0..7 mean, 8..15 variance of this tile)
@@ -548,7 +556,9 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         kpn_view_gather gv;
         kpn_ibr_view iv;
         float emin = 3.0e38f, esum = 0.0f;
+#pragma unroll
         for (int pass = 0; pass < 2; ++pass)
+#pragma unroll(VFIX > 0 ? VFIX : 1)
             for (int v = 0; v < V; ++v) {
                 const float dot = scr[(lay.rec(t_scr, v) + 1) * 64 + p].w;
                 const float e = kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f)));
@@ -581,6 +591,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // encoder.  Rounds 2-3 parked x' in the row scratch between the passes (three passes then); with ONE statistics pass the
         // store + read-back (5.5 GB written and as much read back per 512 x 512 frame, most of it missing L2) measured 1.2 % of the
         // frame SLOWER than recomputing.
+#pragma unroll(VFIX > 0 ? VFIX : 1)
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
             kpn_gather_view(scr + lay.rec(t_scr, v) * 64, lane, h, gv);
@@ -669,6 +680,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // (touching the NEXT tile's block of the scratch — one dword per 128-B line — under the last view's head, so that its
         // lines are in L2 when the next tile starts: 23.93-23.97 vs 23.94-24.02 ms per frame, no gain; with EVERY tile reading tile 0's
         // block, i.e. no HBM misses at all, the frame is 0.9 ms faster: profiles/r04_z_ab_experiments.txt)
+#pragma unroll 1
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
             kpn_gather_view(scr + lay.rec(t_scr, v) * 64, lane, h, gv);
@@ -709,7 +721,13 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color_h(kpn_scene_dev sc, kpn_p
                                                          int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
     kpn_fuse_color_body<true>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
 }
-
+// ... and with the three views of the shipped configuration unrolled (launched when V == 3 and every view is kept)
+__global__ __launch_bounds__(512, 2) void k_fuse_color_h3(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                          const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                          int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
+                                                          int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+    kpn_fuse_color_body<true, 3>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
+}
 // ---------------------------------------------------------------------------------------------
 // Lane-map self test: D = A(32x2) * B(2x32) with asymmetric operands, written out row-major.
 __global__ void k_selftest_mfma(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ Dm) {

@@ -910,7 +910,9 @@ void launch_fuse(int fmode, const kpn_scene_dev& sc, const kpn_points& ps, const
                  int* tickets, const float* xscr, int mode, int park_x, float* out, const kpn_batch& batch, int zero_skip, void* stream) {
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 / 141 KB of weights sit in LDS
     static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
-    if (fmode == 1)
+    if (fmode == 1 && sc.V == 3 && (sc.keep & 7u) == 7u)   // the shipped view count, no view dropped: the unrolled variant
+        KPN_LAUNCH(k_fuse_color_h3, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
+    else if (fmode == 1)
         KPN_LAUNCH(k_fuse_color_h, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
     else
         KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
