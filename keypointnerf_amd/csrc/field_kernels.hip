@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
             // view switched off by the train-time dropout: its pooling / blend weights are 0, only the record
             // (the blend-weight minimum runs over ALL views, model.py:1288) is needed
             float4 rec0, rec1;
-            kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
+            kpn_row_record(sc, ps, n, tb, v, h, rec0, rec1);
             float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
 #pragma unroll
             for (int k = 0; k < 8; ++k) dst[k * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_geo_rows(kpn_scene_dev sc, kpn_point
                 constexpr int g = decltype(gi)::value;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[i] = kpn_softplus100(a2[g / 4][(g % 4) * 4 + i]);
-                if constexpr (g == 2) kpn_row_record(sc, tb, v, h, q, P, D, rec0, rec1);
+                if constexpr (g == 2) kpn_row_record(sc, ps, n, tb, v, h, rec0, rec1);
             }, acc);
             float4* dst = reinterpret_cast<float4*>(xscr) + ((size_t)wi * KPN_ROW_SLABS) * 64 + lane;
 #pragma unroll

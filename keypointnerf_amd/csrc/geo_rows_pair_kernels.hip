@@ -919,13 +919,13 @@ __global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_point
         if (pair + nwaves < npairs) fetch(pair + nwaves, raw_next);
         const int tr = 2 * pair + tsel;
         float P[3], D[3];
-        kpn_point_finish(ps, raw, P, D);
+        kpn_point_finish<true>(ps, raw, P, D);               // strict: the reference's pixel coordinates bit for bit (kpn_row_record_a)
         for (int v = 0; v < sc.V; ++v) {
             const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-            const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
+            const kpn_proj q = kpn_project<true>(tb, P[0], P[1], P[2], sc);
             float4 a0, a1, b0, b1;
-            kpn_row_record_a(sc, tb, v, q, P, D, a0, a1);
-            kpn_row_record_b(sc, v, q, b0, b1);
+            kpn_row_record_a<true>(sc, tb, v, q, P, D, a0, a1);
+            kpn_row_record_b<true>(sc, v, q, b0, b1);
             if (tr < nbt) {                                      // an odd batch ends in half a pair
                 float4* rec = reinterpret_cast<float4*>(xscr) + lay.rec(tr, v) * 64;
                 rec[p] = a0; rec[32 + p] = b0; rec[64 + p] = a1; rec[64 + 32 + p] = b1;

@@ -97,11 +97,13 @@ __device__ __forceinline__ void kpn_point_fetch(const kpn_points& ps, int64_t n,
         for (int k = 0; k < 3; ++k) { r.b[k] = ps.dirs[ray * 3 + k]; r.a[k] = 0.0f; }
     }
 }
+// S: strict arithmetic (separate multiply and add, kpn_device.h) — the point as k_mask_compact and the reference form it, bit for bit
+template <bool S = false>
 __device__ __forceinline__ void kpn_point_finish(const kpn_points& ps, const kpn_point_raw& r, float (&P)[3], float (&D)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         D[k] = r.b[k];
-        P[k] = ps.pts ? r.a[k] : RADD(ps.cam_pos[k], RMUL(r.b[k], r.z));
+        P[k] = ps.pts ? r.a[k] : kpn_add<S>(ps.cam_pos[k], kpn_mul<S>(r.b[k], r.z));
     }
 }
 
@@ -136,9 +138,15 @@ __device__ __forceinline__ float kpn_pix_weight_fast(const kpn_proj& q) {
 
 // the colour head's per-(point,view) gather record (query_color, model.py:806-832) in its two parts: A = [r,g,b, pooling
 // weight | ray_diff direction(3), dot] (held by the h=0 lanes of a row), B = the 8 texture channels (model.py:818; h=1 lanes)
+// S = true (k_row_records): the tap positions in the source IMAGE and the texture map are formed with strict arithmetic from a
+// strictly formed point and projection, i.e. bit-identical to the reference's (and the oracle's) pixel coordinates.  With the free-to-
+// contract flavour a coordinate differs by an ulp now and then — 2.4e-4 px in a 4096-px image, which on configs[4]'s white-noise
+// source images (neighbouring pixels differ by 0.3 on average) moved the blended colour of 2 rays in 9,216 by 1.2e-4: above the bar,
+// with nothing for the oracle's conditioning probe to find (round 5, bench.py secondary.configs4_full.parity).
+template <bool S = false>
 __device__ __forceinline__ void kpn_row_record_a(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, const kpn_proj& q,
                                                  const float (&P)[3], const float (&D)[3], float4& rec0, float4& rec1) {
-    const kpn_taps ti = kpn_make_taps(q.xn, q.yn, sc.H, sc.W);
+    const kpn_taps ti = kpn_make_taps<S>(q.xn, q.yn, sc.H, sc.W);
     const float4 c = kpn_tap4(sc.rgbm + (size_t)v * sc.H * sc.W * 4, 4, 0, ti);  // model.py:806
     rec0 = make_float4(c.x, c.y, c.z, kpn_pix_weight(q));
     const float* cp = tb + KPN_TBL_CPOS;                                          // model.py:823-832
@@ -149,16 +157,21 @@ __device__ __forceinline__ void kpn_row_record_a(const kpn_scene_dev& sc, const 
     const float rc = fmaxf(sqrtf(kpn_dot3(r0, r1, r2, r0, r1, r2)), 1e-6f);
     rec1 = make_float4(r0 / rc, r1 / rc, r2 / rc, kpn_dot3(cr[0], cr[1], cr[2], D[0], D[1], D[2]));
 }
+template <bool S = false>
 __device__ __forceinline__ void kpn_row_record_b(const kpn_scene_dev& sc, int v, const kpn_proj& q, float4& rec0, float4& rec1) {
-    const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+    const kpn_taps tt = kpn_make_taps<S>(q.xn, q.yn, sc.th, sc.tw);
     const float* tx = sc.tex + (size_t)v * sc.th * sc.tw * 8;
     rec0 = kpn_tap4(tx, 8, 0, tt);
     rec1 = kpn_tap4(tx, 8, 4, tt);
 }
-// both parts by the lane layout of the row scratch: h = 0 lanes part A, h = 1 lanes part B
-__device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const float* __restrict__ tb, int v, int h,
-                                               const kpn_proj& q, const float (&P)[3], const float (&D)[3], float4& rec0,
-                                               float4& rec1) {
-    if (h == 0) kpn_row_record_a(sc, tb, v, q, P, D, rec0, rec1);
-    else kpn_row_record_b(sc, v, q, rec0, rec1);
+// both parts by the lane layout of the row scratch: h = 0 lanes part A, h = 1 lanes part B (k_geo_rows, rows mode 0).  The point
+// and its projection are formed again HERE with strict arithmetic (see kpn_row_record_a): the records of the three rows kernels are
+// the same bits, whatever flavour the calling kernel uses for its own taps.
+__device__ __forceinline__ void kpn_row_record(const kpn_scene_dev& sc, const kpn_points& ps, int64_t n, const float* __restrict__ tb, int v, int h,
+                                               float4& rec0, float4& rec1) {
+    float P[3], D[3];
+    kpn_get_point<true>(ps, n, P, D);
+    const kpn_proj q = kpn_project<true>(tb, P[0], P[1], P[2], sc);
+    if (h == 0) kpn_row_record_a<true>(sc, tb, v, q, P, D, rec0, rec1);
+    else kpn_row_record_b<true>(sc, v, q, rec0, rec1);
 }

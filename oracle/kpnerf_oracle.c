@@ -243,7 +243,8 @@ static void ibr_head(const kpo_weights* wt, int V, const float (*rgb_feat)[35], 
  * ill-conditioned in others (the last interval of a ray is 1e10, model.py:1166: a density of 1e-11 there is an alpha of 0.1).
  * On such rays any two correct fp32 implementations differ by more than the parity bar.  To tell those rays from real errors
  * MECHANICALLY, kpo_render_rays can be re-run with its own intermediate values disturbed at fp32-rounding level: every new
- * (importance) sample depth times (1 +- eps_z), every field value [density, sdf, r, g, b] times (1 +- eps_f), and the two raw
+ * (importance) sample depth and every coarse depth times (1 +- eps_z), every entry of the resampling cdf times (1 +- eps_z / 4), every field value
+ * [density, sdf, r, g, b] times (1 +- eps_f), and the two raw
  * outputs of layers2 [sdf, rad] plus-minus eps_f times the sum of the magnitudes of their terms (the scale of an fp32
  * summation's rounding error; the density is relu(rad), a hard threshold, model.py:993-996), signs from a hash of (seed, ray,
  * sample, channel).  A ray whose output moves by more than the bar under such a disturbance is ill-conditioned
@@ -504,6 +505,13 @@ void kpo_importance_sample(const float* contrib, const float* z, const float* u,
         cdf[0] = 0.0f;
         float run = 0.0f;
         for (int i = 0; i < Dm2; ++i) { pdf = (c[i] + 1e-5f) / sum; run += pdf; cdf[i + 1] = run; } /* :1122-1123 */
+        /* conditioning probe (kpo_set_perturbation): the cdf entries at the rounding level of ANOTHER summation order (torch.cumsum is
+         * sequential on the CPU and a parallel scan on a GPU): times (1 +- eps_z / 4), i.e. about one ulp at 1.  What it finds: with the
+         * last interior weight at the 1e-5 floor the last bin is 1.1e-5 wide, u = 1 (linspace includes it, :1126) sits on its upper edge,
+         * and whether cdf[-1] rounds to 1 - ulp or 1 + ulp decides between z_mid[-1] and a point 1 % of a bin before it (:1131-1147):
+         * 8.7e-4 in depth, 3.5e-4 in alpha_fine on the ray that showed it (tests/test_gpu_fuzz.py, scene seed 740464, round 5). */
+        if (g_pert_eps_z != 0.0f)
+            for (int i = 1; i < C; ++i) cdf[i] *= 1.0f + 0.25f * g_pert_eps_z * pert_sign((uint64_t)r, (uint64_t)i, 5);
         for (int k = 0; k < n; ++k) {
             float s = u ? u[r * n + k] : linspace01(k, n);
             int idx = 0;                                                          /* searchsorted right=True :1131 */
@@ -614,6 +622,12 @@ void kpo_render_rays(const kpo_scene* sc, const float* wflat, const float* K, co
         for (int i = 0; i < Sc; ++i) {
             float t = linspace01(i, Sc);                                          /* :1045 */
             float zz = nearr[r] + (farr[r] - nearr[r]) * t;                       /* :1055 */
+            /* conditioning probe: the coarse depths too, times (1 +- eps_z) — the ray set-up (inverse(K), normalize, the AABB's divisions,
+             * :1026-1043) is not bit-reproducible between correct implementations (torch.inverse is an LU factorisation, this file uses
+             * the adjugate), so the POINTS differ at rounding level.  What it finds: configs[4]'s 4096 x 4096 white-noise source images
+             * (neighbouring pixels differ by 0.3 on average): a 2e-7 relative shift of a point moves its projection by 1e-3 px and the
+             * blended colour of a ray by 1e-4, whichever kernels evaluate the field (scripts/diag_configs4_parity.py, round 5). */
+            if (g_pert_eps_z != 0.0f) zz *= 1.0f + g_pert_eps_z * pert_sign((uint64_t)r, (uint64_t)i, 6);
             z[r * Sc + i] = zz;
             for (int k = 0; k < 3; ++k) {
                 pts[(r * Sc + i) * 3 + k] = cam_pos[k] + dirs[r * 3 + k] * zz;    /* :1057 */
