@@ -813,19 +813,16 @@ static ProfState g_prof;
 #define KPN_DEFAULT_GEO_ROWS_MODE 3
 #endif
 // The per-point kernel: 1 = k_fuse_color_h (weights as two fp16 pieces per value on v_mfma_f32_32x32x16_f16: the default),
-// 0 = k_fuse_color (fp32 weights on v_mfma_f32_32x32x2_f32).  Process-wide; initial value from KPN_FUSE_MODE.
+// 0 = k_fuse_color (fp32 weights on v_mfma_f32_32x32x2_f32).  Process-wide (kpn_set_fuse_mode) or per call (kpn_render_args.fuse_kernel):
+// two mechanisms, no environment variable (round 5).
 int g_fuse_mode = -1;
 int fuse_mode() {
-    if (g_fuse_mode < 0) { const char* e = getenv("KPN_FUSE_MODE"); g_fuse_mode = (e && atoi(e) == 0) ? 0 : 1; }
+    if (g_fuse_mode < 0) g_fuse_mode = 1;
     return g_fuse_mode;
 }
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
-    if (g_geo_rows_mode < 0) {
-        const char* e = getenv("KPN_GEO_ROWS_MODE");
-        g_geo_rows_mode = e ? atoi(e) : KPN_DEFAULT_GEO_ROWS_MODE;
-        if (g_geo_rows_mode != 0 && g_geo_rows_mode != 2 && g_geo_rows_mode != 3) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
-    }
+    if (g_geo_rows_mode < 0) g_geo_rows_mode = KPN_DEFAULT_GEO_ROWS_MODE;
     return g_geo_rows_mode;
 }
 int pair_grid_blocks() {   // k_geo_rows_h2: one 256-thread workgroup per CU = one wave per SIMD

@@ -722,7 +722,7 @@ def test_rows_kernel_modes(ops, golden_weights):
     scripts/soak_mode2.py, profiles/*soak*)."""
     sd, w = golden_weights
     default_mode = ops.get_geo_rows_mode()
-    assert default_mode == int(os.environ.get("KPN_GEO_ROWS_MODE", 3))      # the library's default rows kernel is mode 3
+    assert default_mode == 3      # the library's default rows kernel is mode 3
     try:
         results = {}
         for mode in (3, 2, 0):
@@ -747,7 +747,7 @@ def test_fuse_kernel_modes(ops, golden_weights):
     bit-identical run to run, fp32-class agreement with each other on 400,000 random points."""
     sd, w = golden_weights
     default_fuse = ops.get_fuse_mode()
-    assert default_fuse == int(os.environ.get("KPN_FUSE_MODE", 1))
+    assert default_fuse == 1
     try:
         results = {}
         for fm in (1, 0):

@@ -461,7 +461,7 @@ def test_split_operand_geo_rows(env):
     hs = sh.HostScene(lib, scene)
     valid = g["query.0.valid"][0].reshape(-1)
     default_mode = lib.kpn_get_geo_rows_mode()
-    assert default_mode == int(os.environ.get("KPN_GEO_ROWS_MODE", 3))   # the library's default rows kernel is mode 3
+    assert default_mode == 3   # the library's default rows kernel is mode 3
     for n_valid in (704, 660):                                       # 22 and 21 tiles
         idx = np.concatenate([np.where(valid)[0][:n_valid], np.where(~valid)[0][:60]])
         pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
@@ -495,7 +495,7 @@ def test_fuse_modes(env):
     idx = np.concatenate([np.where(valid)[0][:320], np.where(~valid)[0][:40]])
     pts, view, ref = g["query.0.pts"][0][idx], g["query.0.view"][0][idx], g["query.0.out"][0][idx]
     default_rows, default_fuse = lib.kpn_get_geo_rows_mode(), lib.kpn_get_fuse_mode()
-    assert default_fuse == int(os.environ.get("KPN_FUSE_MODE", 1))
+    assert default_fuse == 1
     res = {}
     try:
         lib.check(lib.kpn_set_geo_rows_mode(0))
