@@ -567,18 +567,18 @@ def main():
             port, parity = cpu_baseline(args, scene_cpu, sd, fine=fine, frame=frame_np)
             # the timed frame itself, compared with the oracle on the rays the CPU baseline renders anyway
             line["parity"] = parity
+            # `cpu_baseline` = the C port of the reference's arithmetic (the oracle), timed LIVE on this box's host cores on a bounded
+            # sample of the timed frame.  The UNMODIFIED reference (PyTorch CPU, src/model.py) cannot travel to the GPU box; its rate on a
+            # configs[1] tile, timed where /root/reference is mounted (the 8-core build container: scripts/time_reference_cpu.py), rides
+            # along as a recorded figure, labelled as such — until round 4 it was `value`, which is not "this box's host cores".
+            line["cpu_baseline"] = dict(port)
             rj = os.path.join(ROOT, "profiles", "reference_cpu_pytorch.json")
             if os.path.exists(rj):
-                # The headline CPU baseline is the UNMODIFIED reference (PyTorch CPU, src/model.py) on a configs[1] tile, timed where
-                # /root/reference is mounted (the build container: scripts/time_reference_cpu.py; it cannot travel to the GPU
-                # box).  The C port of the same arithmetic, timed live on THIS box's host cores, sits beside it.
                 ref = json.load(open(rj))
-                line["cpu_baseline"] = {"value": ref.get("rays_per_sec", ref.get("value")), "unit": "rays/s", "cores": ref.get("cores"),
-                                        "kind": "reference", "sample": ref.get("sample", ref.get("what")),
-                                        "recorded": "profiles/reference_cpu_pytorch.json (build container; the reference is absent on the GPU box)",
-                                        "reference_pytorch": ref, "port": port}
-            else:
-                line["cpu_baseline"] = port
+                line["cpu_baseline"]["reference_pytorch_recorded"] = {
+                    "value": ref.get("rays_per_sec", ref.get("value")), "unit": "rays/s", "cores": ref.get("cores"), "kind": "reference",
+                    "sample": ref.get("sample", ref.get("what")),
+                    "recorded": "profiles/reference_cpu_pytorch.json (build container, 8 cores; the reference is absent on the GPU box)", "detail": ref}
             ej = os.path.join(ROOT, "profiles", "r04_eager_pytorch_on_mi355x.json")
             if os.path.exists(ej):   # eager PyTorch restatement of the path on an MI355X (scripts/bench_torch_eager.py), recorded
                 e = json.load(open(ej))

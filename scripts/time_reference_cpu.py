@@ -3,7 +3,7 @@
 
 north_star asks for "the reference CPU PyTorch path timed on the same box's host cores (core count stated)".
 /root/reference cannot travel to the GPU box, so this is measured where the reference is mounted and committed as
-profiles/reference_cpu_pytorch.json (bench.py copies it into cpu_baseline.reference_pytorch, labelled with the host it
+profiles/reference_cpu_pytorch.json (bench.py carries it as cpu_baseline.reference_pytorch_recorded, labelled with the host it
 was measured on).  Workload: tiles of BASELINE configs[1] — batch_render_pifu_nerf (src/model.py:942-1108), level 4
 strided tile (64x64 = 4096 rays) of a 512x512 target, V=3 source views 512x512, Sc = Sf = 64, uniform=True,
 fine=True, the bench scene (keypointnerf_amd.synthetic.make_scene seed 1, ellipsoid mask, tar_focal_at_512=800).
