@@ -71,3 +71,14 @@ def test_per_point_kernel_has_no_valu_instruction_in_asm(assembly):
     n_mix, n_cvt = sum(n == "v_fma_mix_f32" for n in names), sum(n == "v_cvt_pk_f16_f32" for n in names)
     assert n_mix >= 300 and abs(n_mix - n_cvt) <= 8, (n_mix, n_cvt)
     assert not any(n.startswith("v_cvt_f32_f16") for n in names), "the fp16 halves are read in place by v_fma_mix_f32"
+
+
+def test_the_audit_finds_the_round4_miscompute():
+    """The instruction window of the build that was wrong and non-deterministic on the MI355X (round 4, `hh hl lh`; kept as a fixture):
+    an asm statement's `v_cvt_pk_f16_f32 v56` three states behind `v_mfma ... v[48:63]`, whose write-back overwrote it.  The audit must
+    flag it as class C (an asm instruction overwrites a register of an MFMA in flight) — what test_no_unpadded_mfma_pair_around_asm_
+    statements asserts the shipped library is free of."""
+    import isa_asm_hazards as ia
+    found, ex = ia.audit(os.path.join(ROOT, "tests", "fixtures", "isa_wrong_build_window.s"), "_Z14k_fuse_color_hEXCERPT", window=12, mfma_states=True)
+    assert found["C"], "the write-after-write pair of the wrong build went unnoticed"
+    assert min(found["C"]) <= 4 and any("v_cvt_pk_f16_f32 v56" in e[1] for e in ex["C"].values())
