@@ -82,3 +82,37 @@ def test_the_audit_finds_the_round4_miscompute():
     found, ex = ia.audit(os.path.join(ROOT, "tests", "fixtures", "isa_wrong_build_window.s"), "_Z14k_fuse_color_hEXCERPT", window=12, mfma_states=True)
     assert found["C"], "the write-after-write pair of the wrong build went unnoticed"
     assert min(found["C"]) <= 4 and any("v_cvt_pk_f16_f32 v56" in e[1] for e in ex["C"].values())
+
+
+def test_audit_classes_on_synthetic_streams(tmp_path):
+    """The four classes of scripts/isa_asm_hazards.py on hand-written streams: what each one flags and what it lets pass."""
+    import isa_asm_hazards as ia
+
+    def run(body, **kw):
+        p = tmp_path / "k.s"
+        p.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
+        return ia.audit(str(p), "_Z1kv", **kw)[0]
+
+    mfma = "\tv_mfma_f32_32x32x16_f16 v[32:47], v[8:11], v[12:15], v[32:47]\n"
+    asm = lambda ins: "\t;;#ASMSTART\n" + "".join("\t" + i + "\n" for i in ins) + "\t;;#ASMEND\n"
+    # A: an operand written inside asm, read by the MFMA one state later (hipcc itself would put two wait states there)
+    f = run(asm(["v_cvt_pk_f16_f32 v12, v1, v2"]) + mfma)
+    assert f["A"] == {0: 1} and not f["B"] and not f["C"]
+    f = run(asm(["v_cvt_pk_f16_f32 v12, v1, v2", "s_nop 1"]) + mfma)
+    assert f["A"] == {2: 1}
+    # B: asm reads the MFMA's result; C: asm overwrites a register of its destination tuple; the same instructions OUTSIDE asm are
+    # hipcc's to pad and are not reported
+    f = run(mfma + "\tv_add_f32 v1, v2, v3\n" + asm(["v_exp_f32 v5, v33"]))
+    assert f["B"] == {1: 1} and not f["C"]
+    f = run(mfma + asm(["v_mov_b32 v40, 0"]))
+    assert f["C"] == {0: 1}
+    f = run(mfma + "\tv_mov_b32 v40, 0\n\tv_exp_f32 v5, v33\n")
+    assert not f["B"] and not f["C"]
+    # an accumulate chain is not a hazard, and MFMAs in between count as their issue interval when asked to
+    f = run(mfma + mfma + asm(["v_mov_b32 v40, 0"]), window=12, mfma_states=True)
+    assert f["C"] == {0: 1, 8: 1}
+    f = run(mfma + "\tv_mfma_f32_32x32x16_f16 v[48:63], v[8:11], v[12:15], v[48:63]\n" * 2 + asm(["v_mov_b32 v40, 0"]), window=12, mfma_states=True)
+    assert not f["C"]                      # 16 states of other MFMAs in between: the write-back has long landed
+    # D (overwriting an A / B operand behind the MFMA) is reported for information only: operands are captured at issue
+    f = run(mfma + asm(["v_mov_b32 v8, 0"]))
+    assert f["D"] == {0: 1} and not f["C"]
