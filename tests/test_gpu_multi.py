@@ -53,7 +53,8 @@ def _strong_rank(rank, world, port, q):
     g = FrameGatherer(world, rank, tuple(band.shape), device="cpu")      # gloo: host staging (RCCL: device, tests above)
     g.submit(band)
     g.finish()
-    q.put((rank, deinterleave_rows(g.frames(0)).clone() if rank == 0 else None))
+    # by value (numpy): a tensor would travel as a file descriptor fetched from THIS process, which may have exited by then
+    q.put((rank, deinterleave_rows(g.frames(0)).cpu().numpy().copy() if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +73,7 @@ def test_strong_scaling_on_the_device_kernels_assembles_the_one_rank_frame():
     res = {}
     for _ in range(2):
         item = q.get(timeout=600)
-        res[item[0]] = item[1]
+        res[item[0]] = None if item[1] is None else torch.from_numpy(item[1])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

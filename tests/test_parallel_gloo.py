@@ -18,6 +18,17 @@ def _free_port():
     return p
 
 
+def _by_value(t):
+    """A tensor put on a multiprocessing queue travels as a file descriptor the RECEIVER fetches from the sending process — which may
+    have exited by then (EOFError in the parent: seen once on the GPU box).  A numpy array is pickled into the pipe itself."""
+    return None if t is None else t.detach().cpu().numpy().copy()
+
+
+def _from_queue(x):
+    import numpy as np
+    return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+
 def _fake_frame(i):
     return torch.full((3, 4, 5), float(i)) + torch.arange(5.0)
 
@@ -33,7 +44,7 @@ def _worker(rank, world, port, n_frames, q):
         return _fake_frame(i)
 
     out = render_job(render, n_frames, rank, world)
-    q.put((rank, rendered, None if out is None else out.clone()))
+    q.put((rank, rendered, _by_value(out)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +65,7 @@ def _gatherer_worker(rank, world, port, rounds, q):
     g.finish()
     if rank == 0:
         got.append(torch.stack(g.frames(rounds - 1)).clone())
-    q.put((rank, None, torch.cat(got) if rank == 0 else None))
+    q.put((rank, None, _by_value(torch.cat(got)) if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,7 +111,7 @@ def _run_world(target, world, *args):
     res = {}
     for _ in range(world):
         item = q.get(timeout=300)
-        res[item[0]] = item[1:]
+        res[item[0]] = tuple(_from_queue(x) for x in item[1:])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -123,7 +134,7 @@ def _real_worker(rank, world, port, n_frames, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = render_job(lambda i: _render_real_frame(i), n_frames, rank, world)
-    q.put((rank, None if out is None else out.clone()))
+    q.put((rank, _by_value(out)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -182,7 +193,7 @@ def _strong_worker(rank, world, port, q):
     g = FrameGatherer(world, rank, tuple(band.shape), device="cpu")
     g.submit(band)
     g.finish()
-    q.put((rank, deinterleave_rows(g.frames(0)).clone() if rank == 0 else None))
+    q.put((rank, _by_value(deinterleave_rows(g.frames(0))) if rank == 0 else None))
     dist.barrier()
     dist.destroy_process_group()
 
