@@ -170,13 +170,15 @@ int kpn_query_backward(const kpn_scene_desc* desc, const void* scene_ws, const f
  *   2 = v_mfma_f32_32x32x16_bf16, three bf16 pieces, six products (k_geo_rows_h2): the same structure in fp32's exponent range.
  *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands, k_geo_rows).
  *   (1, an earlier one-tile-per-wavefront kernel, is refused: not part of the shipped library.)
- * Process-wide; initial value from the environment variable KPN_GEO_ROWS_MODE (default 3). */
+ * Process-wide, default 3; one call may select another kernel through kpn_render_args.rows_kernel (no environment variable:
+ * removed in round 5 — one selection mechanism). */
 int kpn_set_geo_rows_mode(int32_t mode);
 int kpn_get_geo_rows_mode(void);
 /* The per-point kernel (MLPUNet.layers2 + ibr_compress_gfeat + IBRRenderingHead, reference src/utils.py:577-587,
  * src/model.py:819,1267-1302): 1 = weights as two fp16 pieces per value, three products (hh lh hl) on v_mfma_f32_32x32x16_f16
  * (k_fuse_color_h, the default: fp32-class results at less than a fifth of the matrix time); 0 = fp32 weights on
- * v_mfma_f32_32x32x2_f32 (k_fuse_color).  Process-wide; initial value from the environment variable KPN_FUSE_MODE. */
+ * v_mfma_f32_32x32x2_f32 (k_fuse_color).  Process-wide, default 1; per call: kpn_render_args.fuse_kernel.  With V = 3 and no view
+ * dropped mode 1 launches k_fuse_color_h3 (the same arithmetic, the loops over the views unrolled). */
 int kpn_set_fuse_mode(int32_t mode);
 int kpn_get_fuse_mode(void);
 /* *beyond = number of packed weights that fp16 cannot hold (0 = rows mode 3 / fuse mode 1 run on these weights; otherwise the
