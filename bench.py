@@ -386,6 +386,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     L.check(L.kpn_profile_enable(1))
+    dens = [ctypes.c_int64(0), ctypes.c_int64(0)]   # points in the hull whose density was evaluated / of which live (relu(rad) > 0)
+    L.check(L.kpn_density_stats(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -417,6 +419,7 @@ def main():
     # workgroup against the same launches' event time: include/kpnerf.h kpn_profile_collect3)
     L.check(L.kpn_profile_collect3(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus), ctypes.byref(clock_ghz)))
     L.check(L.kpn_profile_enable(0))
+    L.check(L.kpn_density_stats(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -453,6 +456,10 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
+            # of the points inside the visual hull (all of which go through layers1 / layers2): the fraction with relu(rad) == 0, whose
+            # colour head the density-first passes skip (exact: such a sample's compositing weight is 0; include/kpnerf.h)
+            "sigma_zero_fraction": (1.0 - dens[1].value / dens[0].value) if dens[0].value > 0 else None,
+            "density_first": bool(L.kpn_get_density_first()),
             "dtype": ROWS_DTYPE[args.geo_rows_mode],
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if (fine and args.views == 3 and args.samples == 64 and res == 512) else 'custom'}: "
@@ -522,12 +529,20 @@ def main():
                 # hull and the surface): tiles of the valid list without a single live point skip the colour head
                 for db in (-20.0, -30.0):
                     w2 = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=db), device=dev)
+                    cs = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    L.check(L.kpn_density_stats(cs, ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
                     ms2, rows2 = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
+                    L.check(L.kpn_density_stats(cs, ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
+                    L.check(L.kpn_set_density_first(0))    # the fused per-point kernel: short path per 32-point tile only
+                    ms4, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
                     os.environ["KPN_NO_ZERO_SKIP"] = "1"
                     ms3, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
                     os.environ.pop("KPN_NO_ZERO_SKIP")
+                    L.check(L.kpn_set_density_first(1))
                     sec[f"partly_empty_hull_density_bias_{int(db)}"] = {
-                        "ms_per_frame": ms2, "ms_per_frame_without_the_zero_density_short_path": ms3,
+                        "ms_per_frame": ms2, "sigma_zero_fraction": (1.0 - dens[1].value / dens[0].value) if dens[0].value > 0 else None,
+                        "ms_per_frame_fused_per_point_kernel_tile_short_path": ms4,
+                        "ms_per_frame_without_the_zero_density_short_path": ms3,
                         "rays_per_sec": rays_per_step / (ms2 * 1e-3)}
             # the same frame with the other rows kernels: three bf16 pieces (mode 2, roof 2500 / 6) and fp32 MFMA (mode 0, roof 157.3)
             for m, key in ((2, "bf16x3_rows_kernel_mode2"), (0, "fp32_mfma_rows_kernel_mode0"), (3, "fp16x2_rows_kernel_mode3")):

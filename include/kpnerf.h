@@ -181,6 +181,22 @@ int kpn_get_geo_rows_mode(void);
  * dropped mode 1 launches k_fuse_color_h3 (the same arithmetic, the loops over the views unrolled). */
 int kpn_set_fuse_mode(int32_t mode);
 int kpn_get_fuse_mode(void);
+/* DENSITY FIRST (round 6) — reference src/model.py:981-996 (eval_func: sigma = relu(rad)) and :1150-1176 (rgba2out: a sample's
+ * weight is T * (1 - exp(-sigma * delta))): a sample with relu(rad) == 0 contributes EXACTLY 0 to every output, whatever its colour.
+ * The render passes (kpn_render_rays; fuse mode 1 on the pooled scratch layout, i.e. the defaults) therefore evaluate the per-point
+ * part in two passes per batch: k_density_h (pooled vector -> layers2 -> density, the compress layer, and a compact list of the
+ * points with !(rad <= 0)), then k_row_records_live + k_colour_h / k_colour_h3 (gather records and the V-view colour head for the
+ * listed points only).  Per point the arithmetic is the fused kernel's, so frames are bit-identical with the switch on (1, the
+ * default) or off (0: the fused per-point kernel with its per-32-point-tile short path).  kpn_query, the train branch and the
+ * fp32-range kernels behind the range guard always use the fused kernel.  Process-wide; KPN_NO_DENSITY_FIRST=1 sets the initial
+ * value to 0. */
+int kpn_set_density_first(int32_t on);
+int kpn_get_density_first(void);
+/* Measurement hook: *listed = the points whose density the per-point kernels of the render passes decided on since the last reset
+ * (every point inside the visual hull that was sent to the MLPs), *live = those with !(rad <= 0), i.e. the points whose colour can
+ * reach the image; 1 - live / listed is the zero-density fraction bench.py reports.  Counted on the device (one addition per
+ * wavefront), read here: synchronises `stream`.  reset != 0 clears the counters. */
+int kpn_density_stats(void* stream, int64_t* listed, int64_t* live, int32_t reset);
 /* *beyond = number of packed weights that fp16 cannot hold (0 = rows mode 3 / fuse mode 1 run on these weights; otherwise the
  * range guard routes every pass to the fp32-range kernels).  Reads four floats back from the device and synchronises `stream`. */
 int kpn_packed_f16_range_check(const float* packed_weights_dev, void* stream, int32_t* beyond);

@@ -420,11 +420,33 @@ __device__ unsigned long long kpn_fuse_cycles[8];
 // as ONE wave per SIMD with 512 registers (no spills) the frame is 21.8-22.0 ms: hipcc keeps every head's MFMA chain contiguous
 // (12 dependent MFMAs in a row), it does not interleave the three heads, and the accumulators move to AGPRs (518 v_accvgpr_read).
 // VFIX = 0: any V <= KPN_MAXV, any keep mask.
-template <bool F16, int VFIX = 0>
+//
+// kpn_density_counts (kpn_density_stats): [0] points a render pass's per-point kernels took density decisions for, [1] those found
+// live (!(rad <= 0)) — one addition per wave at its exit.  A device global of the module, like the range guard's counter.
+#ifndef KPN_SIMT_EMU
+__device__ unsigned long long kpn_density_counts[2];
+#else
+static unsigned long long kpn_density_counts[2];
+#endif
+// PHASE (round 6) — density first, colour for the LIVE points only (reference src/model.py:981-996 eval_func, :1150-1176 rgba2out:
+// a sample with relu(rad) == 0 composites with weight 1 - exp(-0 * delta) = 0 EXACTLY, so its colour never reaches the image):
+//   0: the fused kernel — density and colour of every listed point in one pass (kpn_query, the train branch, the backward's
+//      forward, the fp32-range kernels behind the range guard); its exact short path works per 32-point TILE;
+//   1: pass A of a render pass (k_density_h): pooled vector -> layers2 -> [sdf, rad] -> the point's density record, + the
+//      compress layer's 24 latent values written IN PLACE over the first four pooled slabs of the tile this wave has just consumed;
+//      a point with !(rad <= 0) (a NaN counts as live: it must reach the range guard) is appended to the batch's LIVE list
+//      (one reservation per tile), a dead one gets rgb = 0 and is done;
+//   2: pass B (k_colour_h / k_colour_h3): tiles of 32 LIVE points, each lane addressing the scratch slot (tile, point) its live
+//      entry names — the latent values, the gather records (k_row_records_live wrote them for live points only) — then the V heads
+//      and the blend; writes rgb only.
+// Per point the arithmetic of 1 + 2 is the fused kernel's instruction for instruction (a point's column of an MFMA depends on no
+// other column), so the frame is bit-identical with the split on or off, whatever order the live list comes out in.
+template <bool F16, int VFIX = 0, int PHASE = 0>
 __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
                                                     const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                     int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                    int /*unused*/, float* __restrict__ out, const kpn_batch& batch, int zero_skip) {
+                                                    int* __restrict__ live, float* __restrict__ out, const kpn_batch& batch, int zero_skip) {
+    static_assert(PHASE == 0 || F16, "the density-first split exists for the two-fp16-piece kernels only");
     using W = kpn_fuse_w<F16>;
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -435,7 +457,11 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
     int t0, t1;
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;   // before the LDS staging
     if (batch.cond == KPN_RUN_IF_UNSAFE && batch.redone != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(batch.redone, 1);
-    const int ntiles = t1 - t0;
+    // tickets: [1] the fused kernel's / pass A's tile ticket, [2] the batch's live count (pass A), [3] pass B's tile ticket
+    const int nlive = PHASE == 2 ? tickets[2] : 0;
+    if (PHASE == 2 && nlive == 0) return;   // before the LDS staging
+    const int ntiles = PHASE == 2 ? (nlive + KPN_TILE - 1) / KPN_TILE : t1 - t0;
+    int* const ticket = tickets + (PHASE == 2 ? 3 : 1);
     const int V = VFIX > 0 ? VFIX : sc.V;
     const kpn_tile_layout lay(batch.pool, V);   // ROWS or POOL layout of the scratch (kpn_field_shared.h)
     // all weights of this kernel live in LDS for the lifetime of the (persistent) workgroup;
@@ -459,24 +485,53 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
     // the NEXT tile's ticket is drawn while the current tile is computed: the atomic's round trip (3.7 k cycles per tile in the
     // round-3 phase counts, in front of the dependent row loads) leaves the critical path
     int next_ticket = 0;
-    if (lane == 0) next_ticket = atomicAdd(tickets + 1, 1);
+    if (lane == 0) next_ticket = atomicAdd(ticket, 1);
+    unsigned stat_listed = 0, stat_live = 0;
     for (;;) {
         KPN_FUSE_STAMP(7);
         const int t = __shfl(next_ticket, 0);
-        if (t >= ntiles) return;            // t: tile relative to the batch = its slot in the row scratch
-        if (lane == 0) next_ticket = atomicAdd(tickets + 1, 1);
-        const int ci_raw = (t0 + t) * KPN_TILE + p;
-        const int ci = ci_raw < count ? ci_raw : count - 1;
-        const int64_t n = list[ci];
+        if (t >= ntiles) {                  // t: tile relative to the batch = its slot in the row scratch (pass B: tile of the live list)
+            if (PHASE != 2 && lane == 0 && stat_listed != 0) {
+                atomicAdd(&kpn_density_counts[0], (unsigned long long)stat_listed);
+                atomicAdd(&kpn_density_counts[1], (unsigned long long)stat_live);
+            }
+            return;
+        }
+        if (lane == 0) next_ticket = atomicAdd(ticket, 1);
+        // this lane's point: entry ci_raw of the valid list (pass B: of the batch's live list, whose entry names the scratch slot
+        // (tile t_scr, point p_scr) pass A found the point in); l_scr = the lane's own position in that tile's slabs
+        const int ci_raw = (PHASE == 2 ? 0 : t0 * KPN_TILE) + t * KPN_TILE + p;
+        const int ci_end = PHASE == 2 ? nlive : count;
+        const int ci = ci_raw < ci_end ? ci_raw : ci_end - 1;
+        int t_scr = t, l_scr = lane;
+        int64_t n;
+        if constexpr (PHASE == 2) {
+            const int slot = live[ci];
+            t_scr = slot >> 5;
+            l_scr = (h << 5) | (slot & 31);
+            n = list[(t0 + t_scr) * KPN_TILE + (slot & 31)];
+        } else {
+            n = list[ci];
+        }
+        const int p_scr = l_scr & 31;
 
         KPN_FUSE_STAMP(0);
-        // ---- pooled mean / var over views of the 64-vector ----
         const float4* const scr = reinterpret_cast<const float4*>(xscr);
-        const int t_scr = t;
         const float4* rows = scr + lay.tile(t_scr) * 64;
         const uint32_t keep = VFIX > 0 ? 0xFFFFFFFFu : sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
+        float sdf_raw = 0.0f, rad = 0.0f;
+        float lat0[16];
+        kpn_u32x4 pooled_h[F16 ? 8 : 1], pooled_l[F16 ? 8 : 1];
+        float pooled[PHASE == 2 ? 1 : 64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
+        if constexpr (PHASE == 2) {   // the compress layer's output of this point, left by pass A in its tile's first four slabs
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) {
+                const float4 x_ = rows[q_ * 64 + l_scr];
+                lat0[4 * q_ + 0] = x_.x; lat0[4 * q_ + 1] = x_.y; lat0[4 * q_ + 2] = x_.z; lat0[4 * q_ + 3] = x_.w;
+            }
+        } else {
+        // ---- pooled mean / var over views of the 64-vector ----
         float pwsum;
-        float pooled[64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
         if (lay.pool) {    // POOL layout: the rows kernel has pooled already (slabs 0..7 mean, 8..15 variance of this tile)
 #pragma unroll
             for (int q_ = 0; q_ < 16; ++q_) {
@@ -490,8 +545,6 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         (void)pwsum;
         KPN_FUSE_STAMP(1);
         // ---- layers2: 128 -> 64 -> 64 -> 2 (utils.py:577-587), activations applied lazily ----
-        float sdf_raw, rad;
-        kpn_u32x4 pooled_h[F16 ? 8 : 1], pooled_l[F16 ? 8 : 1];
         {
             kpn_f32x16 h0[2], h1[2], o2[1];
             kpn_load_bias<2>(wl + W::boff(SEG_G2_0), h, h0);
@@ -528,9 +581,20 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // colour never reaches the image (0 * rgb, rgb finite): when EVERY point of the tile is such a point — free space
         // inside the visual hull of a trained density comes in runs along the rays, i.e. in whole tiles of the ray-ordered
         // valid list — compress and the colour head (77 % of this kernel) are skipped.
-        if (zero_skip && mode == 1 && ps.noise == nullptr) {
+        unsigned long long live_m = 0ull;   // pass A: the tile's live points (h = 0 lanes)
+        int live_base = 0;
+        if constexpr (PHASE == 1) {
+            // (a NaN counts as live: it must reach the range guard, not be dropped as "density 0")
+            live_m = __ballot(h == 0 && ci_raw < count && !(rad <= 0.0f));
+            // one reservation per tile, issued here so that its round trip passes under the compress layer
+            if (lane == 0 && live_m != 0ull) live_base = atomicAdd(tickets + 2, __popcll(live_m));
+            stat_listed += (unsigned)(count - (t0 + t) * KPN_TILE < KPN_TILE ? count - (t0 + t) * KPN_TILE : KPN_TILE);
+            stat_live += (unsigned)__popcll(live_m);
+        } else if (zero_skip && mode == 1 && ps.noise == nullptr) {
             // (a NaN counts as live: it must reach the range guard at the end of the tile, not be skipped as "density 0")
             const unsigned long long live = __ballot(h == 0 && ci_raw < count && !(rad <= 0.0f));
+            stat_listed += (unsigned)(count - (t0 + t) * KPN_TILE < KPN_TILE ? count - (t0 + t) * KPN_TILE : KPN_TILE);
+            stat_live += (unsigned)__popcll(live);
             if (live == 0ull) {
                 if (h == 0 && ci_raw < count) {
                     float* o = out + n * 5;
@@ -541,7 +605,6 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         }
         KPN_FUSE_STAMP(2);
         // ---- ibr_compress_gfeat 128 -> 24 (model.py:819), rows already in x' order ----
-        float lat0[16];
         {
             kpn_f32x16 acc[1];
             kpn_load_bias<1>(wl + W::boff(SEG_CMP), h, acc);
@@ -550,6 +613,25 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }
+        if constexpr (PHASE == 1) {
+            // the latent values over the tile's first four pooled slabs (this wave has consumed all sixteen; no other wave reads them)
+            float4* dstl = const_cast<float4*>(rows) + lane;
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) dstl[q_ * 64] = make_float4(lat0[4 * q_ + 0], lat0[4 * q_ + 1], lat0[4 * q_ + 2], lat0[4 * q_ + 3]);
+            if (h == 0 && ci_raw < count) {   // eval_func with mask = 1 (model.py:981-996); a live point's rgb is pass B's
+                float* o = out + n * 5;
+                o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw;
+                if (!((live_m >> lane) & 1ull)) { o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; }
+            }
+            live_base = __shfl(live_base, 0);
+            if ((live_m >> lane) & 1ull) live[live_base + __popcll(live_m & ((1ull << lane) - 1ull))] = t * KPN_TILE + p;
+            if (batch.bad != nullptr && batch.cond != KPN_RUN_IF_UNSAFE) {   // the range guard, as at the end of the fused kernel
+                const float chk = fabsf(sdf_raw) + fabsf(rad);
+                if (__ballot(h == 0 && ci_raw < count && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
+            }
+            continue;
+        }
+        }   // PHASE != 2
         KPN_FUSE_STAMP(3);
         // ---- IBR head (model.py:1267-1302) ----
         // blend weights (model.py:1287-1289): w_v = (e_v - min_v e) / (sum + 1e-8), e_v = exp(|a|(dot_v - 1))
@@ -560,7 +642,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         for (int pass = 0; pass < 2; ++pass)
 #pragma unroll(VFIX > 0 ? VFIX : 1)
             for (int v = 0; v < V; ++v) {
-                const float dot = scr[(lay.rec(t_scr, v) + 1) * 64 + p].w;
+                const float dot = scr[(lay.rec(t_scr, v) + 1) * 64 + p_scr].w;
                 const float e = kpn_fast_exp(RMUL(ani, RSUB(dot, 1.0f)));
                 if (pass == 0) emin = fminf(emin, e);  // min over ALL views (:1288)
                 else if ((keep >> v) & 1u) esum = RADD(esum, RSUB(e, emin));
@@ -594,7 +676,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 #pragma unroll(VFIX > 0 ? VFIX : 1)
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;
-            kpn_gather_view(scr + lay.rec(t_scr, v) * 64, lane, h, gv);
+            kpn_gather_view(scr + lay.rec(t_scr, v) * 64, l_scr, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             stats(gv.rd[3], iv);
         }
@@ -683,12 +765,20 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
             if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
-            kpn_gather_view(scr + lay.rec(t_scr, v) * 64, lane, h, gv);
+            kpn_gather_view(scr + lay.rec(t_scr, v) * 64, l_scr, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }
         KPN_FUSE_STAMP(5);
         const float r0 = c0 / lden, r1 = c1 / lden, r2 = c2 / lden;
+        if constexpr (PHASE == 2) {
+            if (h == 0 && ci_raw < nlive) { float* o = out + n * 5; o[2] = r0; o[3] = r1; o[4] = r2; }
+            if (batch.bad != nullptr && batch.cond != KPN_RUN_IF_UNSAFE) {
+                const float chk = fabsf(r0) + fabsf(r1) + fabsf(r2);
+                if (__ballot(h == 0 && ci_raw < nlive && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
+            }
+            continue;
+        }
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;
             if (mode == 1) {  // eval_func with mask = 1 (model.py:981-996)
@@ -711,22 +801,42 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 __global__ __launch_bounds__(512, 2) void k_fuse_color(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                        const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                        int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                       int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
-    kpn_fuse_color_body<false>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
+                                                       int /*unused*/, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+    kpn_fuse_color_body<false>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, nullptr, out, batch, zero_skip);
 }
 // the same per-point kernel with its weights as two fp16 pieces per value on v_mfma_f32_32x32x16_f16 (the default)
 __global__ __launch_bounds__(512, 2) void k_fuse_color_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                          const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                          int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                         int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
-    kpn_fuse_color_body<true>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
+                                                         int /*unused*/, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+    kpn_fuse_color_body<true>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, nullptr, out, batch, zero_skip);
 }
 // ... and with the three views of the shipped configuration unrolled (launched when V == 3 and every view is kept)
 __global__ __launch_bounds__(512, 2) void k_fuse_color_h3(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                           const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                           int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
-                                                          int park_x, float* __restrict__ out, kpn_batch batch, int zero_skip) {
-    kpn_fuse_color_body<true, 3>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, park_x, out, batch, zero_skip);
+                                                          int /*unused*/, float* __restrict__ out, kpn_batch batch, int zero_skip) {
+    kpn_fuse_color_body<true, 3>(sc, ps, wp, list, count_ptr, tickets, xscr, mode, nullptr, out, batch, zero_skip);
+}
+// Density first (PHASE above; render passes on the POOL layout with the two-fp16-piece per-point arithmetic).  Pass A:
+__global__ __launch_bounds__(512, 2) void k_density_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                      const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                      int* __restrict__ tickets, float* __restrict__ xscr, int* __restrict__ live,
+                                                      float* __restrict__ out, kpn_batch batch) {
+    kpn_fuse_color_body<true, 0, 1>(sc, ps, wp, list, count_ptr, tickets, xscr, 1, live, out, batch, 0);
+}
+// pass B: any V / the shipped V = 3 with every view kept
+__global__ __launch_bounds__(512, 2) void k_colour_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                     const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                     int* __restrict__ tickets, const float* __restrict__ xscr, int* __restrict__ live,
+                                                     float* __restrict__ out, kpn_batch batch) {
+    kpn_fuse_color_body<true, 0, 2>(sc, ps, wp, list, count_ptr, tickets, xscr, 1, live, out, batch, 0);
+}
+__global__ __launch_bounds__(512, 2) void k_colour_h3(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                      const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                      int* __restrict__ tickets, const float* __restrict__ xscr, int* __restrict__ live,
+                                                      float* __restrict__ out, kpn_batch batch) {
+    kpn_fuse_color_body<true, 3, 2>(sc, ps, wp, list, count_ptr, tickets, xscr, 1, live, out, batch, 0);
 }
 // ---------------------------------------------------------------------------------------------
 // Lane-map self test: D = A(32x2) * B(2x32) with asymmetric operands, written out row-major.

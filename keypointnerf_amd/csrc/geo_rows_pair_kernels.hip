@@ -895,9 +895,12 @@ __global__ KPN_H2_BOUNDS void k_geo_rows_f2p(kpn_scene_dev sc, kpn_points ps, co
 // computes BOTH parts without divergence, with enough waves in flight to hide the taps: a wavefront takes the 64 points of a
 // tile pair for ONE view (the view's table entries are wave-uniform: scalar loads) and writes part A to the row's h = 0 slot
 // and part B to its h = 1 slot.
-__global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_points ps, const int* __restrict__ list,
+__global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp, const int* __restrict__ list,
                                                      const int* __restrict__ count_ptr, float* __restrict__ xscr, kpn_batch batch) {
     const int lane = threadIdx.x & 63, p = lane & 31, tsel = lane >> 5;
+    // (KPN_RUN_IF_UNSAFE: the records of EVERY point for the fp32-range kernels behind a density-first pass, whose own records
+    // cover the live points only — returns at once unless the range guard evaluates the batch again)
+    if (batch.cond != KPN_RUN_ALWAYS && !kpn_batch_gate(batch, sc, wp)) return;
     const int count = *count_ptr;
     int t0, t1;
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;
@@ -932,5 +935,51 @@ __global__ __launch_bounds__(256) void k_row_records(kpn_scene_dev sc, kpn_point
             }
         }
         raw = raw_next;
+    }
+}
+
+// The same records for the LIVE points of a density-first render pass only (field_kernels.hip, PHASE): a lane takes one entry of
+// the batch's live list (pass A, k_density_h: slot = tile * 32 + point of the row scratch), forms that point's records for every
+// view and writes them where the full kernel would have — pass B (k_colour_h*) addresses the scratch by the same slot.  The
+// records of dead points (density exactly 0: their colour never reaches the image) are not formed at all.
+__global__ __launch_bounds__(256) void k_row_records_live(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
+                                                          const int* __restrict__ list, const int* __restrict__ count_ptr,
+                                                          const int* __restrict__ tickets, const int* __restrict__ live,
+                                                          float* __restrict__ xscr, kpn_batch batch) {
+    if (batch.cond != KPN_RUN_ALWAYS && !kpn_batch_gate(batch, sc, wp)) return;
+    const int count = *count_ptr;
+    int t0, t1;
+    if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;
+    const int nlive = tickets[2];
+    const kpn_tile_layout lay(batch.pool, sc.V);
+    const int stride = gridDim.x * blockDim.x;
+    auto fetch = [&](int e, int& slot, kpn_point_raw& raw) {
+        slot = live[e < nlive ? e : nlive - 1];
+        kpn_point_fetch(ps, (int64_t)list[t0 * KPN_TILE + slot], raw);
+    };
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    // wave-uniform trip count (the view tables are read with scalar loads): the lanes beyond the list redo its last entry
+    const int e_wave = e - (threadIdx.x & 63);
+    kpn_point_raw raw, raw_next;
+    int slot = 0, slot_next = 0;
+    if (e_wave < nlive) fetch(e, slot, raw);
+    for (int ew = e_wave; ew < nlive; ew += stride, e += stride) {
+        if (ew + stride < nlive) fetch(e + stride, slot_next, raw_next);
+        float P[3], D[3];
+        kpn_point_finish<true>(ps, raw, P, D);               // strict, as k_row_records
+        const int tr = slot >> 5, pp = slot & 31;
+        for (int v = 0; v < sc.V; ++v) {
+            const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
+            const kpn_proj q = kpn_project<true>(tb, P[0], P[1], P[2], sc);
+            float4 a0, a1, b0, b1;
+            kpn_row_record_a<true>(sc, tb, v, q, P, D, a0, a1);
+            kpn_row_record_b<true>(sc, v, q, b0, b1);
+            if (e < nlive) {
+                float4* rec = reinterpret_cast<float4*>(xscr) + lay.rec(tr, v) * 64;
+                rec[pp] = a0; rec[32 + pp] = b0; rec[64 + pp] = a1; rec[64 + 32 + pp] = b1;
+            }
+        }
+        raw = raw_next;
+        slot = slot_next;
     }
 }

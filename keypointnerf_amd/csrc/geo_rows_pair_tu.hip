@@ -21,9 +21,15 @@ extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_geo_ro
 }
 // the gather records of the same batch (the pair-tile kernels do not write them)
 extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_row_records(
-    int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const int* list, const int* count, float* xscr,
+    int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp, const int* list, const int* count, float* xscr,
     const kpn_batch* batch) {
-    KPN_LAUNCH(k_row_records, dim3(blocks), dim3(256), stream, *sc, *ps, list, count, xscr, *batch);
+    KPN_LAUNCH(k_row_records, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, xscr, *batch);
+}
+// ... of the batch's live points only (density-first render passes)
+extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_row_records_live(
+    int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp, const int* list, const int* count,
+    const int* tickets, const int* live, float* xscr, const kpn_batch* batch) {
+    KPN_LAUNCH(k_row_records_live, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, live, xscr, *batch);
 }
 
 #ifdef KPN_H2_TIMING

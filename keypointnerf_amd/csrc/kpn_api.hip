@@ -17,8 +17,11 @@
 #ifdef KPN_SIMT_EMU
 #include "geo_rows_pair_kernels.hip"   // the device build compiles this kernel as its own translation unit (geo_rows_pair_tu.hip)
 #else
-extern "C" void kpn_internal_launch_row_records(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const int* list,
+extern "C" void kpn_internal_launch_row_records(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp, const int* list,
                                                 const int* count, float* xscr, const kpn_batch* batch);
+extern "C" void kpn_internal_launch_row_records_live(int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
+                                                     const int* list, const int* count, const int* tickets, const int* live, float* xscr,
+                                                     const kpn_batch* batch);
 extern "C" void kpn_internal_launch_geo_rows_pair(int mode, int blocks, void* stream, const kpn_scene_dev* sc, const kpn_points* ps, const float* wp,
                                                   const int* list, const int* count, int* tickets, float* xscr, const kpn_batch* batch);
 #endif
@@ -751,15 +754,20 @@ const int64_t kUncappedPoints = 2048;
 #else
 const int64_t kUncappedPoints = 262144;
 #endif
-struct QueryLayout { size_t count, list, xscr, total; int tiles_cap, nbatch; };  // byte offsets
+struct QueryLayout { size_t count, list, live, xscr, total; int tiles_cap, nbatch; };  // byte offsets
 // pool: the POOL layout of the scratch (kpn_field_shared.h): the render / query passes with the pair-tile rows kernels
 int geo_rows_mode();
-bool pool_layout_selected() { return geo_rows_mode() >= 2 && !(getenv("KPN_NO_POOL") && atoi(getenv("KPN_NO_POOL"))); }
+// (the A/B knob KPN_NO_POOL is read once per process)
+bool pool_layout_selected() {
+    static const bool no_pool = [] { const char* e = getenv("KPN_NO_POOL"); return e && atoi(e) != 0; }();
+    return geo_rows_mode() >= 2 && !no_pool;
+}
 QueryLayout query_layout(int64_t N, int V, bool pool = false) {
     QueryLayout L;
     size_t o = 0;
-    // [0] valid count; batch b owns ints [8 + 8b, 16 + 8b): [0] rows ticket, [1] per-point ticket, [4] / [5] the same for the
-    // fp32-range kernels launched behind them (range guard), [6] the batch's "non-finite result" flag
+    // [0] valid count; batch b owns ints [8 + 8b, 16 + 8b): [0] rows ticket, [1] per-point ticket, [2] live points of the batch and
+    // [3] pass B's ticket (density-first render passes), [4] / [5] the tickets of the fp32-range kernels launched behind them (range
+    // guard), [6] the batch's "non-finite result" flag
     L.count = o; o += kCounterBytes;
     L.list = o; o += align_up((size_t)N * sizeof(int), 256);
     const size_t ntiles = (size_t)(N + KPN_TILE - 1) / KPN_TILE;
@@ -773,6 +781,8 @@ QueryLayout query_layout(int64_t N, int V, bool pool = false) {
     if (cap > ntiles) cap = ntiles ? ntiles : 1;
     L.tiles_cap = (int)cap;
     L.nbatch = (int)((ntiles + cap - 1) / cap);
+    // the live list of ONE batch (density-first render passes, field_kernels.hip PHASE): scratch slots tile * 32 + point
+    L.live = o; o += align_up(cap * KPN_TILE * sizeof(int), 256);
     L.xscr = o; o += align_up(cap * tile_bytes, 256);
     L.total = o;
     return L;
@@ -819,6 +829,14 @@ int g_fuse_mode = -1;
 int fuse_mode() {
     if (g_fuse_mode < 0) g_fuse_mode = 1;
     return g_fuse_mode;
+}
+// Density first (field_kernels.hip, PHASE): the per-point work of a render pass as pass A (density of every listed point + the
+// batch's live list) and pass B (colour of the live points) instead of the fused per-point kernel.  On by default wherever it applies
+// (lean render passes, POOL layout, fuse mode 1); kpn_set_density_first(0) / KPN_NO_DENSITY_FIRST=1 selects the fused kernel (A/B).
+int g_density_first = -1;
+int density_first() {
+    if (g_density_first < 0) { const char* e = getenv("KPN_NO_DENSITY_FIRST"); g_density_first = (e && atoi(e) != 0) ? 0 : 1; }
+    return g_density_first;
 }
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
@@ -914,6 +932,21 @@ void launch_fuse(int fmode, const kpn_scene_dev& sc, const kpn_points& ps, const
     else
         KPN_LAUNCH(k_fuse_color, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
 }
+// the density-first pair of a render pass's batch: pass A, the gather records of the live points, pass B
+void launch_density_first(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, const int* list, const int* count, int* tickets,
+                          float* xscr, int* live, float* out, const kpn_batch& batch, void* stream) {
+    const int fblocks = fuse_grid_blocks();
+    KPN_LAUNCH(k_density_h, dim3(fblocks), dim3(512), stream, sc, ps, wp, list, count, tickets, xscr, live, out, batch);
+#ifdef KPN_SIMT_EMU
+    KPN_LAUNCH(k_row_records_live, dim3(8), dim3(256), stream, sc, ps, wp, list, count, (const int*)tickets, (const int*)live, xscr, batch);
+#else
+    kpn_internal_launch_row_records_live(2048, stream, &sc, &ps, wp, list, count, tickets, live, xscr, &batch);
+#endif
+    if (sc.V == 3 && (sc.keep & 7u) == 7u)
+        KPN_LAUNCH(k_colour_h3, dim3(fblocks), dim3(512), stream, sc, ps, wp, list, count, tickets, (const float*)xscr, live, out, batch);
+    else
+        KPN_LAUNCH(k_colour_h, dim3(fblocks), dim3(512), stream, sc, ps, wp, list, count, tickets, (const float*)xscr, live, out, batch);
+}
 
 // rows_sel / fuse_sel: KPN_ROWS_* / KPN_FUSE_* of kpn_render_args (0 = the process-wide selection)
 int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, int64_t N, int mode, float* out,
@@ -929,6 +962,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     char* base = static_cast<char*>(ws);
     int* count = reinterpret_cast<int*>(base + L.count);
     int* list = reinterpret_cast<int*>(base + L.list);
+    int* live = reinterpret_cast<int*>(base + L.live);
     float* xscr = reinterpret_cast<float*>(base + L.xscr);
     hipMemsetAsync(count, 0, kCounterBytes, (hipStream_t)stream);
     const int ppt = mask_points_per_thread(N);
@@ -942,6 +976,9 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     const char* zs = getenv("KPN_NO_ZERO_SKIP");   // A/B knob, read per call
     const int zero_skip = (lean && !keep_rows && !(zs && atoi(zs))) ? 1 : 0;
     const int park_x = 0;   // (rounds 2-3: x' parked in the row scratch between the per-point kernel's passes; gone with the one-pass statistics)
+    // density first: where the exact short path applies (render passes: eval_func, no density noise), on the POOL layout with the
+    // two-fp16-piece per-point arithmetic — the shipped configuration
+    const bool split = zero_skip && mode == 1 && ps.noise == nullptr && pool && fmode == 1 && density_first();
     for (int b = 0; b < L.nbatch; ++b) {
         int* slots = count + 8 + 8 * b;
         int* bad = guard ? slots + 6 : nullptr;
@@ -965,21 +1002,27 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
             ++g_prof.used;
         }
 #endif
-        if (rmode >= 2) {   // the colour head's gather records (the pair-tile rows kernels leave them to k_row_records)
+        auto launch_records = [&](const kpn_batch& bb) {
 #ifdef KPN_SIMT_EMU
-            KPN_LAUNCH(k_row_records, dim3(8), dim3(256), stream, sc, ps, (const int*)list, (const int*)count, xscr, b_rec);
+            KPN_LAUNCH(k_row_records, dim3(8), dim3(256), stream, sc, ps, wp, (const int*)list, (const int*)count, xscr, bb);
 #else
-            kpn_internal_launch_row_records(2048, stream, &sc, &ps, list, count, xscr, &b_rec);
+            kpn_internal_launch_row_records(2048, stream, &sc, &ps, wp, list, count, xscr, &bb);
 #endif
-        }
+        };
+        // the colour head's gather records (the pair-tile rows kernels leave them to k_row_records; a density-first pass forms
+        // them for its live points only)
+        if (rmode >= 2 && !split) launch_records(b_rec);
         if (!out) continue;   // rows only (the backward entry points run their own per-point kernels)
-        launch_fuse(fmode, sc, ps, wp, list, count, slots, xscr, mode, park_x, out, b_fuse, zero_skip, stream);
+        if (split) launch_density_first(sc, ps, wp, list, count, slots, xscr, live, out, b_fuse, stream);
+        else launch_fuse(fmode, sc, ps, wp, list, count, slots, xscr, mode, park_x, out, b_fuse, zero_skip, stream);
         if (guard) {
             // The same batch again in fp32's exponent range, IF the kernels above stood aside or flagged it: the rows first (the
-            // non-finite value may have come from either kernel; the gather records are intact), then the per-point kernel.
+            // non-finite value may have come from either kernel; the gather records are intact — after a density-first pass they
+            // exist for its live points only, so every point's are formed here), then the fused per-point kernel.
             const kpn_batch r_rows{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, nullptr, pool, nullptr};
             const kpn_batch r_fuse{b, L.tiles_cap, KPN_RUN_IF_UNSAFE, bad, redone, pool, nullptr};
             launch_rows(safe_rmode, sc, ps, wp, list, count, slots + 4, xscr, r_rows, stream);
+            if (split) launch_records(r_rows);
             launch_fuse(0, sc, ps, wp, list, count, slots + 4, xscr, mode, park_x, out, r_fuse, zero_skip, stream);
         }
     }
@@ -999,6 +1042,27 @@ extern "C" int kpn_set_fuse_mode(int32_t mode) {
     return KPN_OK;
 }
 extern "C" int kpn_get_fuse_mode(void) { return fuse_mode(); }
+// points whose density the render passes' per-point kernels looked at since the last reset, and how many of them were live
+extern "C" int kpn_density_stats(void* stream, int64_t* listed_host, int64_t* live_host, int32_t reset) {
+    KPN_REQUIRE(listed_host && live_host, "null pointer");
+    unsigned long long v[2] = {0, 0};
+#ifndef KPN_SIMT_EMU
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(kpn_density_counts)) != hipSuccess) return fail(KPN_ELAUNCH, "no density counters in this module");
+    if (hipMemcpyAsync(v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        (reset && hipMemsetAsync(p, 0, sizeof(v), (hipStream_t)stream) != hipSuccess) ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(KPN_ELAUNCH, "could not read the density counters");
+#else
+    (void)stream;
+    v[0] = kpn_density_counts[0]; v[1] = kpn_density_counts[1];
+    if (reset) kpn_density_counts[0] = kpn_density_counts[1] = 0;
+#endif
+    *listed_host = (int64_t)v[0];
+    *live_host = (int64_t)v[1];
+    return KPN_OK;
+}
+extern "C" int kpn_set_density_first(int32_t on) { g_density_first = on ? 1 : 0; return KPN_OK; }
+extern "C" int kpn_get_density_first(void) { return density_first(); }
 extern "C" int kpn_set_range_guard(int32_t on) { g_range_guard = on ? 1 : 0; return KPN_OK; }
 extern "C" int kpn_get_range_guard(void) { return range_guard(); }
 // Batches of (point, view) rows that the fp32-range kernels evaluated again on the current device since the library was loaded

@@ -86,6 +86,9 @@ _SIGNATURES = {
     "kpn_packed_f16_range_check": (ctypes.c_int, [c_p, c_p, c_p]),
     "kpn_set_fuse_mode": (ctypes.c_int, [c_i32]),
     "kpn_get_fuse_mode": (ctypes.c_int, []),
+    "kpn_set_density_first": (ctypes.c_int, [c_i32]),
+    "kpn_get_density_first": (ctypes.c_int, []),
+    "kpn_density_stats": (ctypes.c_int, [c_p, c_p, c_p, c_i32]),
     "kpn_set_range_guard": (ctypes.c_int, [c_i32]),
     "kpn_get_range_guard": (ctypes.c_int, []),
     "kpn_range_guard_count": (ctypes.c_int, [c_p, c_p]),

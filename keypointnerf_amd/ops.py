@@ -495,6 +495,16 @@ def get_fuse_mode():
     return int(kl.get_library().kpn_get_fuse_mode())
 
 
+def set_density_first(on):
+    """Render passes: density of every listed point first, colour head for the points with relu(rad) > 0 only (kpn_set_density_first,
+    include/kpnerf.h; on by default, frames bit-identical either way)."""
+    kl.get_library().check(kl.get_library().kpn_set_density_first(int(bool(on))))
+
+
+def get_density_first():
+    return int(kl.get_library().kpn_get_density_first())
+
+
 def set_range_guard(on):
     """The range guard of the two-fp16-piece kernels (include/kpnerf.h kpn_set_range_guard): on by default."""
     kl.get_library().check(kl.get_library().kpn_set_range_guard(int(bool(on))))
