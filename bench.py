@@ -387,6 +387,8 @@ def main():
         step(i)
     L.check(L.kpn_profile_enable(1))
     dens = [ctypes.c_int64(0), ctypes.c_int64(0)]   # points in the hull whose density was evaluated / of which live (relu(rad) > 0)
+    dpasses = [ctypes.c_int64(0), ctypes.c_int64(0)]   # timed render passes that ran density first / on the fused per-point kernel
+    L.check(L.kpn_density_first_passes(ctypes.byref(dpasses[0]), ctypes.byref(dpasses[1]), 1))
     L.check(L.kpn_density_stats(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
     if world > 1:
         dist.barrier()
@@ -420,6 +422,7 @@ def main():
     L.check(L.kpn_profile_collect3(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(rows), ctypes.byref(surplus), ctypes.byref(clock_ghz)))
     L.check(L.kpn_profile_enable(0))
     L.check(L.kpn_density_stats(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
+    L.check(L.kpn_density_first_passes(ctypes.byref(dpasses[0]), ctypes.byref(dpasses[1]), 1))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -459,7 +462,10 @@ def main():
             # of the points inside the visual hull (all of which go through layers1 / layers2): the fraction with relu(rad) == 0, whose
             # colour head the density-first passes skip (exact: such a sample's compositing weight is 0; include/kpnerf.h)
             "sigma_zero_fraction": (1.0 - dens[1].value / dens[0].value) if dens[0].value > 0 else None,
-            "density_first": bool(L.kpn_get_density_first()),
+            "density_first": {"mode": {0: "never", 1: "always", 2: "auto"}[L.kpn_get_density_first()],
+                              "passes_density_first": dpasses[0].value, "passes_fused_kernel": dpasses[1].value,
+                              "note": "per-point part of a render pass as density pass + colour of the live points only, or the fused kernel; "
+                                      "auto = from the dead fraction earlier passes measured on the device (>= 25 %: density first); bit-identical frames"},
             "dtype": ROWS_DTYPE[args.geo_rows_mode],
             "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if (fine and args.views == 3 and args.samples == 64 and res == 512) else 'custom'}: "
@@ -530,17 +536,23 @@ def main():
                 for db in (-20.0, -30.0):
                     w2 = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=db), device=dev)
                     cs = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    nst = max(2, min(args.steps, 5))
                     L.check(L.kpn_density_stats(cs, ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
-                    ms2, rows2 = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
+                    ms2, rows2 = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=nst, warmup=3)   # auto (the default)
                     L.check(L.kpn_density_stats(cs, ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
-                    L.check(L.kpn_set_density_first(0))    # the fused per-point kernel: short path per 32-point tile only
-                    ms4, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
-                    os.environ["KPN_NO_ZERO_SKIP"] = "1"
-                    ms3, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=max(2, min(args.steps, 5)))
-                    os.environ.pop("KPN_NO_ZERO_SKIP")
+                    L.check(L.kpn_density_first_passes(ctypes.byref(dpasses[0]), ctypes.byref(dpasses[1]), 1))
                     L.check(L.kpn_set_density_first(1))
+                    ms5, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=nst)
+                    L.check(L.kpn_set_density_first(0))    # the fused per-point kernel: short path per 32-point tile only
+                    ms4, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=nst)
+                    os.environ["KPN_NO_ZERO_SKIP"] = "1"
+                    ms3, _ = time_frames(L, ops, torch, scene, w2, res, args.samples, fine, steps=nst)
+                    os.environ.pop("KPN_NO_ZERO_SKIP")
+                    L.check(L.kpn_set_density_first(2))
                     sec[f"partly_empty_hull_density_bias_{int(db)}"] = {
                         "ms_per_frame": ms2, "sigma_zero_fraction": (1.0 - dens[1].value / dens[0].value) if dens[0].value > 0 else None,
+                        "passes_density_first_of_the_last_timed_frames": [dpasses[0].value, dpasses[0].value + dpasses[1].value],
+                        "ms_per_frame_density_first_always": ms5,
                         "ms_per_frame_fused_per_point_kernel_tile_short_path": ms4,
                         "ms_per_frame_without_the_zero_density_short_path": ms3,
                         "rays_per_sec": rays_per_step / (ms2 * 1e-3)}

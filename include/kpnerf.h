@@ -183,15 +183,22 @@ int kpn_set_fuse_mode(int32_t mode);
 int kpn_get_fuse_mode(void);
 /* DENSITY FIRST (round 6) — reference src/model.py:981-996 (eval_func: sigma = relu(rad)) and :1150-1176 (rgba2out: a sample's
  * weight is T * (1 - exp(-sigma * delta))): a sample with relu(rad) == 0 contributes EXACTLY 0 to every output, whatever its colour.
- * The render passes (kpn_render_rays; fuse mode 1 on the pooled scratch layout, i.e. the defaults) therefore evaluate the per-point
- * part in two passes per batch: k_density_h (pooled vector -> layers2 -> density, the compress layer, and a compact list of the
- * points with !(rad <= 0)), then k_row_records_live + k_colour_h / k_colour_h3 (gather records and the V-view colour head for the
- * listed points only).  Per point the arithmetic is the fused kernel's, so frames are bit-identical with the switch on (1, the
- * default) or off (0: the fused per-point kernel with its per-32-point-tile short path).  kpn_query, the train branch and the
- * fp32-range kernels behind the range guard always use the fused kernel.  Process-wide; KPN_NO_DENSITY_FIRST=1 sets the initial
- * value to 0. */
-int kpn_set_density_first(int32_t on);
+ * The render passes (kpn_render_rays; fuse mode 1 on the pooled scratch layout, i.e. the defaults) can therefore evaluate the
+ * per-point part in two passes per batch: k_density_h (pooled vector -> layers2 -> density, the compress layer, and a compact list
+ * of the points with !(rad <= 0)), then k_row_records_live + k_colour_h / k_colour_h3 (gather records and the V-view colour head
+ * for the listed points only).  Per point the arithmetic is the fused kernel's: frames are bit-identical either way.
+ *   mode 0: never (the fused per-point kernel, whose short path needs a whole 32-point tile dead);
+ *   mode 1: always;
+ *   mode 2: auto, the default: per render pass, from the dead fraction the earlier passes measured on the device (>= 15 %: density
+ *           first; the pair is 0.16 ms per launch slower than the fused kernel when every point is live and 3 % of a frame faster
+ *           when 82 % are dead; no host synchronisation: DESIGN.md).
+ * kpn_query, the train branch and the fp32-range kernels behind the range guard always use the fused kernel.  Process-wide;
+ * KPN_DENSITY_FIRST=0/1/2 sets the initial value. */
+int kpn_set_density_first(int32_t mode);
 int kpn_get_density_first(void);
+/* How many render passes (coarse / fine pass of a kpn_render_rays call) ran density first and how many on the fused kernel since
+ * the library was loaded or the counts were reset (host-side counts; which form mode 2 chose). */
+int kpn_density_first_passes(int64_t* density_first, int64_t* fused, int32_t reset);
 /* Measurement hook: *listed = the points whose density the per-point kernels of the render passes decided on since the last reset
  * (every point inside the visual hull that was sent to the MLPs), *live = those with !(rad <= 0), i.e. the points whose colour can
  * reach the image; 1 - live / listed is the zero-density fraction bench.py reports.  Counted on the device (one addition per

@@ -430,23 +430,32 @@ static unsigned long long kpn_density_counts[2];
 #endif
 // PHASE (round 6) — density first, colour for the LIVE points only (reference src/model.py:981-996 eval_func, :1150-1176 rgba2out:
 // a sample with relu(rad) == 0 composites with weight 1 - exp(-0 * delta) = 0 EXACTLY, so its colour never reaches the image):
-//   0: the fused kernel — density and colour of every listed point in one pass (kpn_query, the train branch, the backward's
-//      forward, the fp32-range kernels behind the range guard); its exact short path works per 32-point TILE;
+//   0: the fused kernel — density and colour of every listed point, tile by tile (kpn_query, the train branch, the backward's
+//      forward, the fp32-range kernels behind the range guard, and the render passes of a density that is live nearly everywhere);
+//      its exact short path works per 32-point TILE;
 //   1: pass A of a render pass (k_density_h): pooled vector -> layers2 -> [sdf, rad] -> the point's density record, + the
-//      compress layer's 24 latent values written IN PLACE over the first four pooled slabs of the tile this wave has just consumed;
-//      a point with !(rad <= 0) (a NaN counts as live: it must reach the range guard) is appended to the batch's LIVE list
-//      (one reservation per tile), a dead one gets rgb = 0 and is done;
-//   2: pass B (k_colour_h / k_colour_h3): tiles of 32 LIVE points, each lane addressing the scratch slot (tile, point) its live
-//      entry names — the latent values, the gather records (k_row_records_live wrote them for live points only) — then the V heads
-//      and the blend; writes rgb only.
-// Per point the arithmetic of 1 + 2 is the fused kernel's instruction for instruction (a point's column of an MFMA depends on no
-// other column), so the frame is bit-identical with the split on or off, whatever order the live list comes out in.
+//      compress layer's 24 latent values written IN PLACE over the first four pooled slabs of the tile (this wave has just consumed
+//      all sixteen; nobody else reads them).  A point with !(rad <= 0) (a NaN counts as live: it must reach the range guard) is
+//      pushed on the wave's queue of live scratch slots (tile * 32 + point) in LDS, which is appended to the batch's LIVE list 256
+//      slots at a time (one reservation); a dead point gets rgb = 0 and is done;
+//   2: pass B (k_colour_h / k_colour_h3): tiles of 32 LIVE points, each lane addressing the scratch by the slot its list entry names
+//      — the latent values, the gather records (k_row_records_live forms them for the listed points only) — V heads, blend, rgb.
+// Per point the arithmetic is the fused kernel's instruction for instruction (a point's column of an MFMA depends on no other
+// column), so the frame is bit-identical with density first on or off, whichever points end up sharing a tile.
+// Measured on the MI355X (profiles/r06_a_density_first.txt): pass A is HBM-bound (it reads the 512-B pooled vector of every point:
+// 0.53 ms per launch), pass B costs what the fused kernel's colour part costs (1.13 ms with every point live), so on a density that
+// is live everywhere the pair is 0.16 ms per launch SLOWER than the fused kernel (1.50 ms), at 25 % dead points it is even, at 82 %
+// it wins 3 % of the frame on top of the fused kernel's own short path.  Which of the two runs is therefore decided per render call
+// from the dead fraction the previous calls measured (kpn_api.hip density_first_now).  A third form — one kernel, the colour part
+// run on a per-wave LDS queue of live slots as soon as it holds 32 — was built and measured as well: 1.59 ms all-live (30 spilled
+// VGPRs) and no better than the fused kernel at 82 % dead; not kept.
 template <bool F16, int VFIX = 0, int PHASE = 0>
 __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, const kpn_points& ps, const float* __restrict__ wp,
                                                     const int* __restrict__ list, const int* __restrict__ count_ptr,
                                                     int* __restrict__ tickets, const float* __restrict__ xscr, int mode,
                                                     int* __restrict__ live, float* __restrict__ out, const kpn_batch& batch, int zero_skip) {
-    static_assert(PHASE == 0 || F16, "the density-first split exists for the two-fp16-piece kernels only");
+    static_assert(PHASE == 0 || F16, "density first exists for the two-fp16-piece kernels only");
+    static_assert(PHASE >= 0 && PHASE <= 2, "PHASE");
     using W = kpn_fuse_w<F16>;
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, h = lane >> 5;
@@ -457,7 +466,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
     int t0, t1;
     if (!kpn_batch_range(batch, (count + KPN_TILE - 1) / KPN_TILE, t0, t1)) return;   // before the LDS staging
     if (batch.cond == KPN_RUN_IF_UNSAFE && batch.redone != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(batch.redone, 1);
-    // tickets: [1] the fused kernel's / pass A's tile ticket, [2] the batch's live count (pass A), [3] pass B's tile ticket
+    // tickets: [1] the tile ticket of the fused kernel / pass A, [2] the number of slots on the batch's live list, [3] pass B's ticket
     const int nlive = PHASE == 2 ? tickets[2] : 0;
     if (PHASE == 2 && nlive == 0) return;   // before the LDS staging
     const int ntiles = PHASE == 2 ? (nlive + KPN_TILE - 1) / KPN_TILE : t1 - t0;
@@ -482,31 +491,27 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 #ifdef KPN_FUSE_TIMING
     unsigned long long fstamp_ = clock64();
 #endif
-    // the NEXT tile's ticket is drawn while the current tile is computed: the atomic's round trip (3.7 k cycles per tile in the
-    // round-3 phase counts, in front of the dependent row loads) leaves the critical path
-    int next_ticket = 0;
-    if (lane == 0) next_ticket = atomicAdd(ticket, 1);
     unsigned stat_listed = 0, stat_live = 0;
-    for (;;) {
-        KPN_FUSE_STAMP(7);
-        const int t = __shfl(next_ticket, 0);
-        if (t >= ntiles) {                  // t: tile relative to the batch = its slot in the row scratch (pass B: tile of the live list)
-            if (PHASE != 2 && lane == 0 && stat_listed != 0) {
-                atomicAdd(&kpn_density_counts[0], (unsigned long long)stat_listed);
-                atomicAdd(&kpn_density_counts[1], (unsigned long long)stat_live);
-            }
-            return;
-        }
-        if (lane == 0) next_ticket = atomicAdd(ticket, 1);
+    const float4* const scr_base = reinterpret_cast<const float4*>(xscr);
+    // pass A: the wave's queue of live scratch slots in LDS, appended to the batch's live list KPN_LIVEQ slots (or what is left) at a
+    // time: one reservation per 256 slots instead of one per tile
+    constexpr int KPN_LIVEQ = 256;
+    __shared__ int liveq[PHASE == 1 ? 8 : 1][PHASE == 1 ? KPN_LIVEQ : 1];
+    int* const myq = liveq[PHASE == 1 ? (threadIdx.x >> 6) & 7 : 0];
+    int qn = 0;
+    // One tile.  PH = 0: the fused tile (PHASE 0); 1: the density part of valid-list tile t; 2: the colour part of the 32 live slots
+    // live_src[t * 32 ...] (nlive_src of them in all).
+    auto tile = [&](auto phase_c, const int t, const int* __restrict__ live_src, const int nlive_src) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phase_c)::value;
         // this lane's point: entry ci_raw of the valid list (pass B: of the batch's live list, whose entry names the scratch slot
         // (tile t_scr, point p_scr) pass A found the point in); l_scr = the lane's own position in that tile's slabs
-        const int ci_raw = (PHASE == 2 ? 0 : t0 * KPN_TILE) + t * KPN_TILE + p;
-        const int ci_end = PHASE == 2 ? nlive : count;
+        const int ci_raw = (PH == 2 ? 0 : t0 * KPN_TILE) + t * KPN_TILE + p;
+        const int ci_end = PH == 2 ? nlive_src : count;
         const int ci = ci_raw < ci_end ? ci_raw : ci_end - 1;
         int t_scr = t, l_scr = lane;
         int64_t n;
-        if constexpr (PHASE == 2) {
-            const int slot = live[ci];
+        if constexpr (PH == 2) {
+            const int slot = live_src[ci];
             t_scr = slot >> 5;
             l_scr = (h << 5) | (slot & 31);
             n = list[(t0 + t_scr) * KPN_TILE + (slot & 31)];
@@ -516,14 +521,14 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         const int p_scr = l_scr & 31;
 
         KPN_FUSE_STAMP(0);
-        const float4* const scr = reinterpret_cast<const float4*>(xscr);
+        const float4* const scr = scr_base;
         const float4* rows = scr + lay.tile(t_scr) * 64;
         const uint32_t keep = VFIX > 0 ? 0xFFFFFFFFu : sc.keep;  // train-time view dropout (all ones in eval): weights of dropped views are 0
         float sdf_raw = 0.0f, rad = 0.0f;
         float lat0[16];
         kpn_u32x4 pooled_h[F16 ? 8 : 1], pooled_l[F16 ? 8 : 1];
-        float pooled[PHASE == 2 ? 1 : 64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
-        if constexpr (PHASE == 2) {   // the compress layer's output of this point, left by pass A in its tile's first four slabs
+        float pooled[PH == 2 ? 1 : 64];  // K-steps 0..31 = mean (block b, reg r), 32..63 = var
+        if constexpr (PH == 2) {   // the compress layer's output of this point, left by pass A in its tile's first four slabs
 #pragma unroll
             for (int q_ = 0; q_ < 4; ++q_) {
                 const float4 x_ = rows[q_ * 64 + l_scr];
@@ -582,14 +587,25 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // inside the visual hull of a trained density comes in runs along the rays, i.e. in whole tiles of the ray-ordered
         // valid list — compress and the colour head (77 % of this kernel) are skipped.
         unsigned long long live_m = 0ull;   // pass A: the tile's live points (h = 0 lanes)
-        int live_base = 0;
-        if constexpr (PHASE == 1) {
+        int live_base = 0, flush_n = 0;
+        if constexpr (PH == 1) {
             // (a NaN counts as live: it must reach the range guard, not be dropped as "density 0")
             live_m = __ballot(h == 0 && ci_raw < count && !(rad <= 0.0f));
-            // one reservation per tile, issued here so that its round trip passes under the compress layer
-            if (lane == 0 && live_m != 0ull) live_base = atomicAdd(tickets + 2, __popcll(live_m));
             stat_listed += (unsigned)(count - (t0 + t) * KPN_TILE < KPN_TILE ? count - (t0 + t) * KPN_TILE : KPN_TILE);
             stat_live += (unsigned)__popcll(live_m);
+            // the queue cannot take this tile's live points: reserve list space for what it holds — the atomic is issued here so
+            // that its round trip passes under the compress layer; the copy follows it
+            if (qn + __popcll(live_m) > KPN_LIVEQ) {
+                flush_n = qn;
+                if (lane == 0) live_base = atomicAdd(tickets + 2, qn);
+            }
+            if (live_m == 0ull) {   // nobody needs this tile's latent values
+                if (h == 0 && ci_raw < count) {
+                    float* o = out + n * 5;
+                    o[0] = 0.0f; o[1] = sdf_raw; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
+                }
+                return;
+            }
         } else if (zero_skip && mode == 1 && ps.noise == nullptr) {
             // (a NaN counts as live: it must reach the range guard at the end of the tile, not be skipped as "density 0")
             const unsigned long long live = __ballot(h == 0 && ci_raw < count && !(rad <= 0.0f));
@@ -600,7 +616,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
                     float* o = out + n * 5;
                     o[0] = 0.0f; o[1] = sdf_raw; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
                 }
-                continue;
+                return;
             }
         }
         KPN_FUSE_STAMP(2);
@@ -613,7 +629,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];
         }
-        if constexpr (PHASE == 1) {
+        if constexpr (PH == 1) {
             // the latent values over the tile's first four pooled slabs (this wave has consumed all sixteen; no other wave reads them)
             float4* dstl = const_cast<float4*>(rows) + lane;
 #pragma unroll
@@ -623,15 +639,22 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
                 o[0] = fmaxf(rad, 0.0f); o[1] = sdf_raw;
                 if (!((live_m >> lane) & 1ull)) { o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; }
             }
-            live_base = __shfl(live_base, 0);
-            if ((live_m >> lane) & 1ull) live[live_base + __popcll(live_m & ((1ull << lane) - 1ull))] = t * KPN_TILE + p;
+            if (flush_n > 0) {
+                KPN_WAVE_SYNC();
+                live_base = __shfl(live_base, 0);
+                for (int i = lane; i < flush_n; i += 64) live[live_base + i] = myq[i];
+                KPN_WAVE_SYNC();
+                qn = 0;
+            }
+            if ((live_m >> lane) & 1ull) myq[qn + __popcll(live_m & ((1ull << lane) - 1ull))] = t * KPN_TILE + p;
+            qn += __popcll(live_m);
             if (batch.bad != nullptr && batch.cond != KPN_RUN_IF_UNSAFE) {   // the range guard, as at the end of the fused kernel
                 const float chk = fabsf(sdf_raw) + fabsf(rad);
                 if (__ballot(h == 0 && ci_raw < count && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
             }
-            continue;
+            return;
         }
-        }   // PHASE != 2
+        }   // PH != 2
         KPN_FUSE_STAMP(3);
         // ---- IBR head (model.py:1267-1302) ----
         // blend weights (model.py:1287-1289): w_v = (e_v - min_v e) / (sum + 1e-8), e_v = exp(|a|(dot_v - 1))
@@ -675,7 +698,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // frame SLOWER than recomputing.
 #pragma unroll(VFIX > 0 ? VFIX : 1)
         for (int v = 0; v < V; ++v) {
-            if (!((keep >> v) & 1u)) continue;
+            if (!((keep >> v) & 1u)) return;
             kpn_gather_view(scr + lay.rec(t_scr, v) * 64, l_scr, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             stats(gv.rd[3], iv);
@@ -764,20 +787,20 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // block, i.e. no HBM misses at all, the frame is 0.9 ms faster: profiles/r04_z_ab_experiments.txt)
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
+            if (!((keep >> v) & 1u)) return;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
             kpn_gather_view(scr + lay.rec(t_scr, v) * 64, l_scr, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
         }
         KPN_FUSE_STAMP(5);
         const float r0 = c0 / lden, r1 = c1 / lden, r2 = c2 / lden;
-        if constexpr (PHASE == 2) {
-            if (h == 0 && ci_raw < nlive) { float* o = out + n * 5; o[2] = r0; o[3] = r1; o[4] = r2; }
+        if constexpr (PH == 2) {
+            if (h == 0 && ci_raw < nlive_src) { float* o = out + n * 5; o[2] = r0; o[3] = r1; o[4] = r2; }
             if (batch.bad != nullptr && batch.cond != KPN_RUN_IF_UNSAFE) {
                 const float chk = fabsf(r0) + fabsf(r1) + fabsf(r2);
-                if (__ballot(h == 0 && ci_raw < nlive && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
+                if (__ballot(h == 0 && ci_raw < nlive_src && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
             }
-            continue;
+            return;
         }
         if (h == 0 && ci_raw < count) {
             float* o = out + n * 5;
@@ -795,6 +818,41 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
             const float chk = fabsf(sdf_raw) + fabsf(rad) + fabsf(r0) + fabsf(r1) + fabsf(r2);
             if (__ballot(h == 0 && ci_raw < count && !(chk < 3.0e38f)) != 0ull && lane == 0) atomicOr(batch.bad, 1);
         }
+    };
+    // The NEXT ticket is drawn while the current tiles are computed: the atomic's round trip (3.7 k cycles per tile in the round-3
+    // phase counts, in front of the dependent row loads) leaves the critical path.  A ticket names CH consecutive tiles:
+    // same-address atomics retire at about one per 12 ns on this chip (measured, round 6: a pass A drawing one ticket and making
+    // one list reservation per tile took 2.0 ms per launch for 85 k tiles — 170 k atomics on one cache line — and 0.53 ms with a
+    // quarter of the tickets and one reservation per 256 slots; the fused kernel on a hull that is 82 % empty, i.e. mostly short-path
+    // tiles: frame 18.5 -> 17.1 ms with two tiles per ticket).
+    constexpr int CH = PHASE == 1 ? 4 : 2;
+    int next_ticket = 0;
+    if (lane == 0) next_ticket = atomicAdd(ticket, 1);
+    int cur = 0, sub = CH;
+    for (;;) {
+        KPN_FUSE_STAMP(7);
+        if (sub == CH) {
+            cur = __shfl(next_ticket, 0);
+            sub = 0;
+            if (cur * CH < ntiles && lane == 0) next_ticket = atomicAdd(ticket, 1);
+        }
+        const int t = cur * CH + sub;       // tile relative to the batch = its slot in the row scratch (PHASE 2: tile of the live list)
+        ++sub;
+        if (t >= ntiles) break;
+        tile(std::integral_constant<int, PHASE>{}, t, live, nlive);
+    }
+    if constexpr (PHASE == 1) {
+        if (qn > 0) {                       // what is left in the queue
+            KPN_WAVE_SYNC();
+            int base = 0;
+            if (lane == 0) base = atomicAdd(tickets + 2, qn);
+            base = __shfl(base, 0);
+            for (int i = lane; i < qn; i += 64) live[base + i] = myq[i];
+        }
+    }
+    if (PHASE != 2 && lane == 0 && stat_listed != 0) {
+        atomicAdd(&kpn_density_counts[0], (unsigned long long)stat_listed);
+        atomicAdd(&kpn_density_counts[1], (unsigned long long)stat_live);
     }
 }
 
@@ -821,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void k_fuse_color_h3(kpn_scene_dev sc, kpn_
 // Density first (PHASE above; render passes on the POOL layout with the two-fp16-piece per-point arithmetic).  Pass A:
 __global__ __launch_bounds__(512, 2) void k_density_h(kpn_scene_dev sc, kpn_points ps, const float* __restrict__ wp,
                                                       const int* __restrict__ list, const int* __restrict__ count_ptr,
-                                                      int* __restrict__ tickets, float* __restrict__ xscr, int* __restrict__ live,
+                                                      int* __restrict__ tickets, float* xscr, int* __restrict__ live,
                                                       float* __restrict__ out, kpn_batch batch) {
     kpn_fuse_color_body<true, 0, 1>(sc, ps, wp, list, count_ptr, tickets, xscr, 1, live, out, batch, 0);
 }

@@ -831,12 +831,86 @@ int fuse_mode() {
     return g_fuse_mode;
 }
 // Density first (field_kernels.hip, PHASE): the per-point work of a render pass as pass A (density of every listed point + the
-// batch's live list) and pass B (colour of the live points) instead of the fused per-point kernel.  On by default wherever it applies
-// (lean render passes, POOL layout, fuse mode 1); kpn_set_density_first(0) / KPN_NO_DENSITY_FIRST=1 selects the fused kernel (A/B).
+// batch's live list) and pass B (colour of the live points) instead of the fused per-point kernel — where it applies (lean render
+// passes, POOL layout, fuse mode 1).  kpn_set_density_first: 0 = never (the fused kernel), 1 = always, 2 = AUTO (the default;
+// KPN_DENSITY_FIRST=0/1/2 sets the initial value): the pair wins when enough of the hull is empty and loses 0.16 ms per launch when
+// nothing is (field_kernels.hip), so each render pass takes the form the dead fraction of the EARLIER passes calls for — the
+// per-point kernels count listed / live points on the device (kpn_density_counts), a 16-byte copy into pinned host memory is queued
+// behind every pass, and the next pass looks at whatever has arrived: no synchronisation, and since both forms give the same bits
+// the choice never shows in a frame.  A stream that is being captured neither allocates nor copies (the captured graph keeps the
+// form chosen at capture time).
 int g_density_first = -1;
 int density_first() {
-    if (g_density_first < 0) { const char* e = getenv("KPN_NO_DENSITY_FIRST"); g_density_first = (e && atoi(e) != 0) ? 0 : 1; }
+    if (g_density_first < 0) {
+        const char* e = getenv("KPN_DENSITY_FIRST");
+        g_density_first = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 2;
+    }
     return g_density_first;
+}
+const float kDensityFirstDeadFraction = 0.25f;   // AUTO: density first when at least this fraction of the hull's points was dead
+struct DensityHint {
+    unsigned long long* pinned = nullptr;   // [listed, live] as last copied from the device
+    unsigned long long seen[2] = {0, 0};    // the snapshot the current decision was taken from
+    bool split = false;                     // nothing measured yet: the fused kernel
+};
+DensityHint g_density_hint[16];
+DensityHint* density_hint() {
+#ifndef KPN_SIMT_EMU
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    return &g_density_hint[dev];
+#else
+    return &g_density_hint[0];
+#endif
+}
+bool stream_is_capturing(void* stream) {
+#ifndef KPN_SIMT_EMU
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+#else
+    (void)stream; return false;
+#endif
+}
+long long g_density_first_passes[2] = {0, 0};   // eligible passes run density first / on the fused kernel (kpn_density_first_passes)
+// the form of THIS pass
+bool density_first_now() {
+    const int m = density_first();
+    if (m != 2) return m == 1;
+    DensityHint* hnt = density_hint();
+    if (!hnt) return false;
+#ifndef KPN_SIMT_EMU
+    if (!hnt->pinned) return hnt->split;
+    const unsigned long long now[2] = {hnt->pinned[0], hnt->pinned[1]};
+#else
+    const unsigned long long now[2] = {kpn_density_counts[0], kpn_density_counts[1]};
+#endif
+    const bool was_reset = now[0] < hnt->seen[0];
+    const unsigned long long d0 = was_reset ? now[0] : now[0] - hnt->seen[0], d1 = was_reset ? now[1] : now[1] - hnt->seen[1];
+    if (d0 > 0 && d1 <= d0) {
+        hnt->split = (float)(d0 - d1) >= kDensityFirstDeadFraction * (float)d0;
+        hnt->seen[0] = now[0]; hnt->seen[1] = now[1];
+    }
+    return hnt->split;
+}
+// behind a pass: the counters on their way to the host
+void density_hint_refresh(void* stream) {
+#ifndef KPN_SIMT_EMU
+    if (density_first() != 2 || stream_is_capturing(stream)) return;
+    DensityHint* hnt = density_hint();
+    if (!hnt) return;
+    if (!hnt->pinned) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        hnt->pinned = static_cast<unsigned long long*>(hp);
+        hnt->pinned[0] = hnt->pinned[1] = 0;
+    }
+    void* dp = nullptr;
+    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(kpn_density_counts)) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipMemcpyAsync(hnt->pinned, dp, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream);
+#else
+    (void)stream;
+#endif
 }
 int g_geo_rows_mode = -1;
 int geo_rows_mode() {
@@ -978,7 +1052,9 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
     const int park_x = 0;   // (rounds 2-3: x' parked in the row scratch between the per-point kernel's passes; gone with the one-pass statistics)
     // density first: where the exact short path applies (render passes: eval_func, no density noise), on the POOL layout with the
     // two-fp16-piece per-point arithmetic — the shipped configuration
-    const bool split = zero_skip && mode == 1 && ps.noise == nullptr && pool && fmode == 1 && density_first();
+    const bool eligible = zero_skip && mode == 1 && ps.noise == nullptr && pool && fmode == 1;
+    const bool split = eligible && density_first_now();
+    if (eligible) ++g_density_first_passes[split ? 0 : 1];
     for (int b = 0; b < L.nbatch; ++b) {
         int* slots = count + 8 + 8 * b;
         int* bad = guard ? slots + 6 : nullptr;
@@ -1026,6 +1102,7 @@ int run_field(const kpn_scene_dev& sc, const kpn_points& ps, const float* wp, in
             launch_fuse(0, sc, ps, wp, list, count, slots + 4, xscr, mode, park_x, out, r_fuse, zero_skip, stream);
         }
     }
+    if (eligible) density_hint_refresh(stream);
     return check_launch("field query");
 }
 }  // namespace
@@ -1061,7 +1138,18 @@ extern "C" int kpn_density_stats(void* stream, int64_t* listed_host, int64_t* li
     *live_host = (int64_t)v[1];
     return KPN_OK;
 }
-extern "C" int kpn_set_density_first(int32_t on) { g_density_first = on ? 1 : 0; return KPN_OK; }
+extern "C" int kpn_density_first_passes(int64_t* density_first_host, int64_t* fused_host, int32_t reset) {
+    KPN_REQUIRE(density_first_host && fused_host, "null pointer");
+    *density_first_host = g_density_first_passes[0];
+    *fused_host = g_density_first_passes[1];
+    if (reset) g_density_first_passes[0] = g_density_first_passes[1] = 0;
+    return KPN_OK;
+}
+extern "C" int kpn_set_density_first(int32_t mode) {
+    KPN_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (fused per-point kernel), 1 (density first) or 2 (auto)");
+    g_density_first = mode;
+    return KPN_OK;
+}
 extern "C" int kpn_get_density_first(void) { return density_first(); }
 extern "C" int kpn_set_range_guard(int32_t on) { g_range_guard = on ? 1 : 0; return KPN_OK; }
 extern "C" int kpn_get_range_guard(void) { return range_guard(); }

@@ -495,10 +495,10 @@ def get_fuse_mode():
     return int(kl.get_library().kpn_get_fuse_mode())
 
 
-def set_density_first(on):
-    """Render passes: density of every listed point first, colour head for the points with relu(rad) > 0 only (kpn_set_density_first,
-    include/kpnerf.h; on by default, frames bit-identical either way)."""
-    kl.get_library().check(kl.get_library().kpn_set_density_first(int(bool(on))))
+def set_density_first(mode):
+    """Render passes: density of every point in the hull first, colour head for the points with relu(rad) > 0 only
+    (kpn_set_density_first, include/kpnerf.h): 0 = never, 1 = always, 2 = auto (default); frames bit-identical in every mode."""
+    kl.get_library().check(kl.get_library().kpn_set_density_first(int(mode)))
 
 
 def get_density_first():

@@ -191,7 +191,7 @@ def test_density_first_passes_equal_the_fused_per_point_kernel(ops):
     from keypointnerf_amd import lib as kl
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
     L = kl.get_library()
-    assert L.kpn_get_density_first() == 1
+    assert L.kpn_get_density_first() == 2
     old = L.kpn_row_scratch_cap_bytes()
 
     def stats():
@@ -223,8 +223,33 @@ def test_density_first_passes_equal_the_fused_per_point_kernel(ops):
                     assert 0.1 * st[0][0] < st[0][1] < 0.9 * st[0][0], st
                 if bias == -60.0:
                     assert st[0][1] == 0 and float(outs[0]["alpha_fine"].abs().max()) == 0.0
+        # mode 2 (auto, the default): the form follows the dead fraction the earlier passes measured on the device — an empty hull
+        # ends up density first, a live one on the fused kernel — and the frames stay the same bits throughout
+        L.check(L.kpn_set_density_first(2))
+        scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(64, 64), mask="ellipsoid", seed=1, tar_focal_at_512=800.0)
+        s, ps = _prep(ops, scene)
+        plan = ops.RenderPlan(ps, (0, 0, 1, 64, 64), 64, 64, fine=True)
+
+        def passes():
+            a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+            L.check(L.kpn_density_first_passes(ctypes.byref(a), ctypes.byref(b), 1))
+            return a.value, b.value
+
+        for bias, expect_split in ((-30.0, True), (0.0, False), (-30.0, True)):
+            w = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=bias))
+            frames = []
+            for i in range(4):
+                frames.append({k: v.clone() for k, v in ops.render_rays(ps, w, s["cam_tar"], s["bounds"], plan=plan).items()})
+                torch.cuda.synchronize()           # (lets the 16-byte statistics copy behind the pass land before the next call looks)
+                if i == 2:
+                    passes()
+            df, fused = passes()                   # the passes of the fourth frame
+            assert (df, fused) == ((2, 0) if expect_split else (0, 2)), (bias, df, fused)
+            for f in frames[1:]:
+                for k in f:
+                    assert torch.equal(f[k], frames[0][k]), (bias, k)
     finally:
-        L.check(L.kpn_set_density_first(1))
+        L.check(L.kpn_set_density_first(2))
         L.check(L.kpn_set_row_scratch_cap_bytes(old))
 
 

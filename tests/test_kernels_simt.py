@@ -650,7 +650,7 @@ def test_density_first_passes_equal_the_fused_per_point_kernel(env):
     (k_colour_h); a 26 x 26 frame whose coarse pass (the emulator build caps the scratch at 64 tiles) runs in more than one batch."""
     from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
     lib = env[0]
-    assert lib.kpn_get_density_first() == 1
+    assert lib.kpn_get_density_first() == 2
     try:
         for V, n in ((3, 12), (2, 12), (3, 26)):
             scene = make_scene(n_views=V, src_hw=(64, 64), tar_hw=(n, n), mask="ellipsoid", seed=1, tar_focal_at_512=800.0)
@@ -668,7 +668,7 @@ def test_density_first_passes_equal_the_fused_per_point_kernel(env):
                 if bias == -60.0:
                     assert pair[0]["alpha_fine"].max() == 0.0
     finally:
-        lib.check(lib.kpn_set_density_first(1))
+        lib.check(lib.kpn_set_density_first(2))
 
 
 def _guard_count(lib):
