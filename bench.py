@@ -96,10 +96,13 @@ def parse():
     return ap.parse_args()
 
 
-def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, ref):
+def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, ref, render_one=None):
     """The HIP frame against the oracle's rays at the pixels `pix` (x, y): worst |difference| per output and the verdict of the
     parity gate (tests/parity_gate.py: <= 1e-4 on every ray unless the oracle's own conditioning probe explains the ray; the
-    probe is run on the rays above the bar only).  `frame`: {key: (3,H,W) / (H,W) numpy arrays}.  The checker, not the product."""
+    probe is run on the rays above the bar only).  `frame`: {key: (3,H,W) / (H,W) numpy arrays}.  The checker, not the product.
+    Round 6: a ray the gate widens counts as explained only if the CONDITIONAL re-check passes for it (parity_gate.recheck_widened:
+    each stage of the oracle on the kernels' own inputs of that stage, strict stage bars; render_one() = the product's one-pixel
+    render with kpn_render_stages): `conditional_ok`, and per widened ray the stage excesses in `widened_rays`."""
     import numpy as np
     from tests import parity_gate
     keys = [k for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine") if k in ref and k in frame]
@@ -121,6 +124,14 @@ def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, 
         try:
             rep = parity_gate.check_rays(sub, subref, env, keys=keys, max_widened_fraction=1.0, what="bench frame")
             res["widened"] = len(rep["widened"])
+            if render_one is not None and rep["widened"]:
+                parity_gate.recheck_widened(rep, render_one(), oracle, osc, wflat, cam_tar, bounds, pix[idx], Sc, Sf, fine=fine)   # render_one: a factory
+                res["conditional_ok"] = bool(rep["conditional_ok"])
+                res["widened_rays"] = [{"pixel": [int(v) for v in pix[idx][r["ray"]]], "err": r["err"], "oracle_envelope": r["oracle_envelope"],
+                                        "conditional_ok": r["conditional_ok"], "stage_excess_over_bar": r["conditional"]["stages"],
+                                        "bin_flips": r["conditional"]["bin_flips"]} for r in rep["widened"]]
+            elif rep["widened"]:
+                res["conditional_ok"] = None    # not re-checked (no product render available)
         except AssertionError as e:
             res["unexplained"] = int(above.sum())
             res["error"] = str(e)[:400]
@@ -128,7 +139,7 @@ def frame_parity(frame, oracle, osc, wflat, cam_tar, bounds, pix, Sc, Sf, fine, 
     return res
 
 
-def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True, frame=None):
+def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True, frame=None, render_one=None):
     """Oracle (C restatement, OpenMP over points) on a strided sub-lattice of the SAME frame, sized from a
     short probe so that the timed run is about `target_s` seconds of CPU work.  With `frame` (the HIP frame of the timed
     region, numpy) the oracle's rays are also COMPARED with it: -> (baseline, parity)."""
@@ -161,7 +172,8 @@ def cpu_baseline(args, scene_cpu, sd, target_s=15.0, fine=True, frame=None):
                       f"samples/ray, {dt:.1f} s of wall time, C oracle with OpenMP over points on {os.cpu_count()} hardware threads"}
     parity = None
     if frame is not None:
-        parity = frame_parity(frame, oracle, osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples, fine, last["ref"])
+        parity = frame_parity(frame, oracle, osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, args.samples, args.samples, fine, last["ref"],
+                              render_one=render_one)
         parity["sample"] = f"the {pix.shape[0]} rays of the cpu_baseline lattice ({n}x{n}, step {step}) of the timed {args.res}x{args.res} frame"
     return base, parity
 
@@ -233,8 +245,13 @@ def time_configs4(L, ops, torch, dev, sd, mode, with_parity=True):
             try:
                 rep = parity_gate.check_rays(got, ref, parity_gate.oracle_envelope(oracle, osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, samples, samples, fine=False),
                                              keys=keys, max_widened_fraction=0.01, what="configs[4] subset")
+                # round 6: widened rays count only if every stage agrees given the kernels' own inputs (strict stage bars)
+                parity_gate.recheck_widened(rep, parity_gate.product_render_one(ops, ps, w, scene["cam_tar"], scene["bounds"], samples, samples, fine=False),
+                                            oracle, osc, wflat, scene_cpu["cam_tar"], scene_cpu["bounds"], pix, samples, samples, fine=False)
                 parity = {"rays": int(pix.shape[0]), "max_abs_rgb": rep["max_err"]["tex_fg"], "max_abs_alpha": rep["max_err"]["alpha"],
-                          "rays_above_1e-4": rep["above_bar"], "widened": len(rep["widened"]), "unexplained": 0, "ok": True}
+                          "rays_above_1e-4": rep["above_bar"], "widened": len(rep["widened"]), "unexplained": 0, "ok": True,
+                          "conditional_ok": rep.get("conditional_ok"),
+                          "widened_rays": [{"pixel": [int(v) for v in pix[r["ray"]]], "err": r["err"], "stage_excess_over_bar": r["conditional"]["stages"]} for r in rep["widened"]]}
             except AssertionError as e:
                 parity = {"rays": int(pix.shape[0]), "ok": False, "error": str(e)[:400]}
             parity["sample"] = "9,216 rays (96 x 96 lattice, step 42) of this 4096 x 4096 frame vs the C oracle, V = 10, 128 flat samples"
@@ -591,7 +608,12 @@ def main():
             line["roofline"]["workloads"] = {k: {kk: vv for kk, vv in v.items() if kk in ("frac", "achieved", "peak", "avg_launch_ms", "ms_per_frame", "rays_per_sec", "parity_ok")}
                                              for k, v in side.items()}
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            port, parity = cpu_baseline(args, scene_cpu, sd, fine=fine, frame=frame_np)
+            def make_render_one():   # the product's one-pixel render with its per-sample stages, for the rays the gate widens
+                from tests import parity_gate
+                sc1 = to_device(scene_cpu, dev)
+                ps1 = ops.PreparedScene(sc1["img"], sc1["cam"], sc1["feat_geo"], sc1["feat_tex"], sc1["sp_data"], sc1["src_foreground_mask"])
+                return parity_gate.product_render_one(ops, ps1, w, sc1["cam_tar"], sc1["bounds"], args.samples, args.samples, fine)
+            port, parity = cpu_baseline(args, scene_cpu, sd, fine=fine, frame=frame_np, render_one=make_render_one)
             # the timed frame itself, compared with the oracle on the rays the CPU baseline renders anyway
             line["parity"] = parity
             # `cpu_baseline` = the C port of the reference's arithmetic (the oracle), timed LIVE on this box's host cores on a bounded

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KPN_ABI_VERSION 2
+#define KPN_ABI_VERSION 3
 #define KPN_N_KPT 24      /* configs/zju.json:44 sp_args.n_kpt */
 #define KPN_MAX_VIEWS 16
 
@@ -189,7 +189,7 @@ int kpn_get_fuse_mode(void);
  * for the listed points only).  Per point the arithmetic is the fused kernel's: frames are bit-identical either way.
  *   mode 0: never (the fused per-point kernel, whose short path needs a whole 32-point tile dead);
  *   mode 1: always;
- *   mode 2: auto, the default: per render pass, from the dead fraction the earlier passes measured on the device (>= 15 %: density
+ *   mode 2: auto, the default: per render pass, from the dead fraction the earlier passes measured on the device (>= 25 %: density
  *           first; the pair is 0.16 ms per launch slower than the fused kernel when every point is live and 3 % of a frame faster
  *           when 82 % are dead; no host synchronisation: DESIGN.md).
  * kpn_query, the train branch and the fp32-range kernels behind the range guard always use the fused kernel.  Process-wide;
@@ -240,6 +240,16 @@ int kpn_query(const kpn_scene_desc* desc, const void* scene_ws, const float* pac
  * which visits exactly the same rays.  Outputs are planar like the reference's out dict (B=1):
  * tex_fg (3,ny,nx), depth (ny,nx), alpha (ny,nx), and if fine: tex_fg_fine, depth_fine, alpha_fine,
  * sdf.  Any output pointer may be NULL. */
+/* Optional per-sample outputs of a render call, in ray order (ray = iy * nx + ix) — what the reference holds in z_vals / raw
+ * between its stages (src/model.py:1058-1085): the depths and eval_func'ed field values [sigma, sdf, r, g, b] of the coarse pass
+ * and of the merged, sorted fine pass.  For the CONDITIONAL parity check of tests/parity_gate.py (each stage of the oracle run on
+ * the kernel's own inputs); any pointer may be NULL.  rgb of a sample with sigma == 0 is unspecified (never composited). */
+typedef struct kpn_render_stages {
+    float* z_coarse;       /* (R, n_coarse) */
+    float* rgba_coarse;    /* (R, n_coarse, 5) */
+    float* z_fine;         /* (R, n_coarse + n_fine) */
+    float* rgba_fine;      /* (R, n_coarse + n_fine, 5) */
+} kpn_render_stages;
 typedef struct kpn_render_args {
     const float* K;          /* cam_tar["K"]  (4,4) */
     const float* RT;         /* cam_tar["RT"] (4,4) */
@@ -258,6 +268,7 @@ typedef struct kpn_render_args {
     int32_t fuse_kernel;        /* KPN_FUSE_*: the per-point kernel of THIS call; 0 = the process-wide selection (kpn_set_fuse_mode).
                                  * kpn_render_rays only: the kpn_render_rays_train* entry points (forward, kept state, backward
                                  * recompute must run the same kernels) refuse a non-zero selection with KPN_EINVAL */
+    const kpn_render_stages* stages;   /* NULL (the default): nothing but the images leaves the call (ABI 3) */
 } kpn_render_args;
 /* per-call kernel selection (kpn_render_args): the same kernels as kpn_set_geo_rows_mode(0 / 2 / 3) and kpn_set_fuse_mode(0 / 1) */
 enum { KPN_ROWS_DEFAULT = 0, KPN_ROWS_F32 = 1, KPN_ROWS_BF16X3 = 2, KPN_ROWS_F16X2 = 3 };

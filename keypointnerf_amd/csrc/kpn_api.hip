@@ -1616,6 +1616,16 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
         const int allow_pool = t == nullptr;   // eval: pooled inside the rows kernel; the train branch keeps the per-view rows
         if (int e = run_field(sc, ps, wp, n * Sc, 1, rgba_coarse, nullptr, base + L.query, stream, 1, 0, allow_pool, a->rows_kernel, a->fuse_kernel)) return e;   // model.py:1062
         if (int e = kpn_rgba2out(rgba_coarse, F(L.zc), n, Sc, F(L.color), F(L.depth), F(L.alpha), F(L.contrib), F(L.sdf), stream)) return e;
+        const kpn_render_stages* st = a->stages;
+        auto copy_out = [&](float* dst, const float* src_, size_t floats) {   // device to device, on the call's stream
+#ifndef KPN_SIMT_EMU
+            (void)hipMemcpyAsync(dst, src_, floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+#else
+            memcpy(dst, src_, floats * sizeof(float));
+#endif
+        };
+        if (st && st->z_coarse) copy_out(st->z_coarse + r0 * Sc, F(L.zc), (size_t)n * Sc);
+        if (st && st->rgba_coarse) copy_out(st->rgba_coarse + r0 * Sc * 5, rgba_coarse, (size_t)n * Sc * 5);
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);
         if (a->depth) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth);
         if (a->alpha) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.alpha), a->alpha);
@@ -1634,6 +1644,12 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
                               (t && t->rand_noise_std != 0.0f) ? t->noise_fine + r0 * Sfull : nullptr, t ? t->rand_noise_std : 0.0f};
                 if (int e = run_field(sc, pf, wp, n * Sfull, 1, F(L.rgba), nullptr, base + L.query, stream, 1, 0, allow_pool, a->rows_kernel, a->fuse_kernel)) return e;  // :1082
                 if (int e = kpn_rgba2out(F(L.rgba), F(L.zf), n, Sfull, F(L.color), F(L.depth), F(L.alpha), nullptr, F(L.sdf), stream)) return e;
+            }
+            if (st && st->z_fine) copy_out(st->z_fine + r0 * Sfull, F(L.zf), (size_t)n * Sfull);
+            if (st && st->rgba_fine) {
+                if (reuse) KPN_LAUNCH(k_merge_rgba, grid1d(n * Sfull, 256), dim3(256), stream, n, Sfull, Sc, (const float*)F(L.rgba_c), (const float*)F(L.rgba_n),
+                                      (const int16_t*)src, st->rgba_fine + r0 * Sfull * 5);
+                else copy_out(st->rgba_fine + r0 * Sfull * 5, F(L.rgba), (size_t)n * Sfull * 5);
             }
             if (a->tex_fg_fine) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg_fine);
             if (a->depth_fine) KPN_LAUNCH(k_store_planar, grid1d(n, 256), dim3(256), stream, r0, n, R, 1, (const float*)F(L.depth), a->depth_fine);

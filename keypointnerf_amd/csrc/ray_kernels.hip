@@ -225,6 +225,19 @@ __global__ void k_coarse_z(int64_t R, int S, const float* __restrict__ near_i, c
 #define KPN_MAX_PER_LANE 8  // supports S <= 512
 template <int PER>
 struct kpn_ray_samples { float sig[PER], sd[PER], cr[PER], cg[PER], cb[PER], z[PER], dist[PER]; };
+// the merged field records of a fine pass that re-used the coarse values (k_rgba2out reads them through `src` in place), written
+// out sample by sample: kpn_render_stages.rgba_fine
+__global__ __launch_bounds__(256) void k_merge_rgba(int64_t n, int S, int Sc, const float* __restrict__ rgba_c, const float* __restrict__ rgba_n,
+                                                    const int16_t* __restrict__ src, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sample index r * S + k
+    if (i >= n * S) return;
+    const int64_t r = i / S;
+    const int id = src[i];
+    const float* q = id < Sc ? rgba_c + (r * Sc + id) * 5 : rgba_n + (r * (S - Sc) + (id - Sc)) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) out[i * 5 + c] = q[c];
+}
+
 template <int PER>
 __global__ __launch_bounds__(256) void k_rgba2out(int64_t R, int S, const float* __restrict__ rgba,
                                                   const float* __restrict__ z, float* __restrict__ color,

@@ -34,11 +34,17 @@ class SceneDesc(ctypes.Structure):
                [(n, c_p) for n in ("KRT", "extrin", "kpt3d", "img", "fg_mask", "geo0", "geo1", "tex")]
 
 
+class RenderStages(ctypes.Structure):
+    """struct kpn_render_stages"""
+    _fields_ = [(n, c_p) for n in ("z_coarse", "rgba_coarse", "z_fine", "rgba_fine")]
+
+
 class RenderArgs(ctypes.Structure):
     """struct kpn_render_args"""
     _fields_ = [(n, c_p) for n in ("K", "RT", "bounds")] + [("znear", c_f), ("zfar", c_f)] + \
                [(n, c_i32) for n in ("x0", "y0", "step", "nx", "ny", "n_coarse", "n_fine", "fine", "chunk_rays")] + \
-               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")] + [("step_y", c_i32), ("rows_kernel", c_i32), ("fuse_kernel", c_i32)]
+               [(n, c_p) for n in ("tex_fg", "depth", "alpha", "tex_fg_fine", "depth_fine", "alpha_fine", "sdf")] + \
+               [("step_y", c_i32), ("rows_kernel", c_i32), ("fuse_kernel", c_i32), ("stages", ctypes.POINTER(RenderStages))]
 
 
 class TrainArgs(ctypes.Structure):
@@ -120,7 +126,7 @@ _SIGNATURES = {
     "kpn_set_row_scratch_cap_bytes": (ctypes.c_int, [ctypes.c_size_t]),
     "kpn_selftest_mfma": (ctypes.c_int, [c_p, c_p, c_p]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KpnError(RuntimeError):

@@ -361,10 +361,12 @@ class RenderPlan:
         return self.grid[3] * self.grid[4]
 
 
-def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=64, fine=True, chunk_rays=0, plan=None):
+def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=64, fine=True, chunk_rays=0, plan=None, stages=False):
     """Eval-mode batch_render_pifu_nerf for the pixel grid (x0, y0, step, nx, ny) of the target camera
     cam_tar {K (1,4,4), RT (1,4,4), znear, zfar}.  Returns the reference's out dict (B=1):
-    tex_fg (1,3,ny,nx), depth/alpha (1,ny,nx) [, tex_fg_fine, depth_fine, alpha_fine, sdf]."""
+    tex_fg (1,3,ny,nx), depth/alpha (1,ny,nx) [, tex_fg_fine, depth_fine, alpha_fine, sdf].
+    stages=True: -> (out, {z_coarse (R,Sc), rgba_coarse (R,Sc,5) [, z_fine (R,Sc+Sf), rgba_fine (R,Sc+Sf,5)]}), the per-sample depths
+    and eval_func'ed field values of the call in ray order (kpn_render_stages: the conditional parity check of tests/parity_gate.py)."""
     L = kl.get_library()
     if plan is None:
         plan = RenderPlan(scene, grid, n_coarse, n_fine, fine, chunk_rays)
@@ -372,10 +374,25 @@ def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=
     a = plan.args
     a.K, a.RT, a.bounds = K.data_ptr(), RT.data_ptr(), b.data_ptr()
     a.znear, a.zfar = float(cam_tar["znear"]), float(cam_tar["zfar"])
-    L.check(L.kpn_render_rays(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), _p(plan.ws),
-                              plan.nbytes, _stream()))
+    st = None
+    if stages:
+        R, Sc, Sf = plan.n_rays(), int(a.n_coarse), int(a.n_fine) if plan.fine else 0
+        st = {"z_coarse": torch.empty(R, Sc, dtype=_f32, device=plan.ws.device), "rgba_coarse": torch.empty(R, Sc, 5, dtype=_f32, device=plan.ws.device)}
+        if plan.fine:
+            st.update({"z_fine": torch.empty(R, Sc + Sf, dtype=_f32, device=plan.ws.device),
+                       "rgba_fine": torch.empty(R, Sc + Sf, 5, dtype=_f32, device=plan.ws.device)})
+        cst = kl.RenderStages()
+        for k, v in st.items():
+            setattr(cst, k, v.data_ptr())
+        a.stages = ctypes.pointer(cst)
+    try:
+        L.check(L.kpn_render_rays(ctypes.byref(scene.desc), _p(scene.ws), _p(weights.tensor), ctypes.byref(a), _p(plan.ws),
+                                  plan.nbytes, _stream()))
+    finally:
+        if stages:
+            a.stages = ctypes.POINTER(kl.RenderStages)()
     plan._keep = (K, RT, b)  # keep the small tensors alive until the stream has consumed them
-    return plan.out
+    return (plan.out, st) if stages else plan.out
 
 
 def render_rays_train(scene, weights, cam_tar, bounds, pix, u_coarse, u_fine, keep_coarse, keep_fine, noise_coarse=None,

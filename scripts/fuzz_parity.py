@@ -38,6 +38,7 @@ def main():
         print(f"scene {i}: {cfg['V']} views, {cfg['tar']} rays, {cfg['Sc']}+{cfg['Sf'] if cfg['fine'] else 0} {cfg['mask']}: max err "
               + ", ".join(f"{k} {v:.1e}" for k, v in rep["max_err"].items()) + f"; above 1e-4: {rep['above_bar']}", flush=True)
     res = {"scenes": n_scenes, "rays": rays, "rows_mode": ops.get_geo_rows_mode(), "rays_above_1e-4": above, "rays_explained_by_the_oracle_envelope": len(widened),
+           "widened_rays_conditional_ok": sum(1 for w in widened if w.get("conditional_ok")),
            "fuse_mode": ops.get_fuse_mode(), "rays_unexplained": 0, "max_error": worst, "seconds": time.time() - t0,
            "what": "keypointnerf_amd HIP render vs C oracle, random scenes / weights / cameras / sample counts; gate = tests/parity_gate.py"}
     print(json.dumps(res))

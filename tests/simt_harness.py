@@ -104,8 +104,8 @@ def query(lib, hs, packed, pts, view, mode=0):
     return out, valid.astype(bool)
 
 
-def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays=0):
-    """grid = (x0, y0, step, nx, ny[, step_y])."""
+def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays=0, stages=False):
+    """grid = (x0, y0, step, nx, ny[, step_y]).  stages: -> (outputs, kpn_render_stages arrays in ray order)."""
     x0, y0, step, nx, ny = grid[:5]
     K, RT, b = f32(cam_tar["K"]).reshape(4, 4), f32(cam_tar["RT"]).reshape(4, 4), f32(bounds).reshape(2, 3)
     R = nx * ny
@@ -122,11 +122,20 @@ def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays
     a.n_coarse, a.n_fine, a.fine, a.chunk_rays = Sc, Sf, int(fine), chunk_rays
     for k, v in o.items():
         setattr(a, k, v.ctypes.data)
+    st = None
+    if stages:
+        st = {"z_coarse": np.full((R, Sc), np.nan, np.float32), "rgba_coarse": np.full((R, Sc, 5), np.nan, np.float32)}
+        if fine:
+            st.update({"z_fine": np.full((R, Sc + Sf), np.nan, np.float32), "rgba_fine": np.full((R, Sc + Sf, 5), np.nan, np.float32)})
+        cst = kl.RenderStages()
+        for k, v in st.items():
+            setattr(cst, k, v.ctypes.data)
+        a.stages = ctypes.pointer(cst)
     nb = lib.kpn_render_workspace_bytes(ctypes.byref(hs.desc), ctypes.byref(a))
     assert nb > 0, lib.kpn_last_error()
     ws = np.zeros(nb, np.uint8)
     lib.check(lib.kpn_render_rays(ctypes.byref(hs.desc), ptr(hs.ws), ptr(packed), ctypes.byref(a), ptr(ws), nb, None))
-    return o
+    return (o, st) if stages else o
 
 
 def render_train(lib, hs, packed, cam_tar, bounds, pix, Sc, Sf, u_c, noise_c, noise_f, u_f, keep_c, keep_f, noise_std, chunk_rays=0):

@@ -1,6 +1,6 @@
 """Randomised parity sweep as a gate (-m gpu): HIP render (through the C ABI) against the C oracle on seeded random scenes —
 view counts, resolutions, sample counts, masks, target cameras, density biases, ragged chunks.  Every ray must be within 1e-4
-(RGB and alpha, coarse and fine) unless the oracle's own conditioning probe explains it (tests/parity_gate.py): rays that a
+(RGB and alpha, coarse and fine) unless the oracle's own conditioning probe explains it (tests/parity_gate.py) AND, since round 6, the conditional re-check passes for it: rays that a
 hard validity threshold of a resampled point or the 1e10 last interval makes ill-conditioned in the reference itself.
 No tolerated-outlier count: an unexplained ray fails the test.  (scripts/fuzz_parity.py runs the same sweep at any size.)"""
 import numpy as np
@@ -44,9 +44,14 @@ def run_scene(ops, cfg):
     ref = oracle.render_rays(osc, wf, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=cfg["fine"])
     keys = ("tex_fg", "alpha") + (("tex_fg_fine", "alpha_fine") if cfg["fine"] else ())
     got = {k: (out[k][0].permute(1, 2, 0).reshape(-1, 3) if k.startswith("tex") else out[k].reshape(-1)).cpu().numpy() for k in keys}
-    return parity_gate.check_rays(
+    rep = parity_gate.check_rays(
         got, ref, parity_gate.oracle_envelope(oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=cfg["fine"]),
         keys=keys, max_widened_fraction=0.01, what=str(cfg))
+    # round 6: a widened ray is accepted only if every stage of the oracle, run on the kernels' own inputs of that stage, agrees with
+    # the kernels at the strict stage bars (parity_gate.conditional_check); raises otherwise
+    w = ops.PackedWeights(sd)
+    return parity_gate.recheck_widened(rep, parity_gate.product_render_one(ops, ps, w, s["cam_tar"], s["bounds"], cfg["Sc"], cfg["Sf"], cfg["fine"]),
+                                       oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=cfg["fine"])
 
 
 @pytest.mark.parametrize("rows_mode", [3, 0])

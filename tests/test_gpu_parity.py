@@ -339,6 +339,9 @@ def test_render_vs_oracle(ops, n_views, mask, src_hw, tar_hw, Sc, Sf):
     rep = parity_gate.check_rays(got, ref, parity_gate.oracle_envelope(oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, Sc, Sf),
                                  max_widened_fraction=0.01, what=f"V={n_views} {mask} {Sc}+{Sf}")
     assert len(rep["widened"]) <= 1
+    # ... and such a ray is accepted only when the conditional re-check passes (each stage of the oracle on the kernels' own inputs)
+    parity_gate.recheck_widened(rep, parity_gate.product_render_one(ops, ps, w, s["cam_tar"], s["bounds"], Sc, Sf), oracle, osc, wf,
+                                scene["cam_tar"], scene["bounds"], pix, Sc, Sf)
 
 
 def test_query_edge_cases(ops, golden_weights):

@@ -108,7 +108,10 @@ def run_case(ops, scene, sd):
 
     def gate(got):
         try:
-            return parity_gate.check_rays(got, ref, envelope, keys=keys, max_widened_fraction=0.02), None
+            rep = parity_gate.check_rays(got, ref, envelope, keys=keys, max_widened_fraction=0.02)
+            ps1 = ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"])
+            return parity_gate.recheck_widened(rep, parity_gate.product_render_one(ops, ps1, ops.PackedWeights(sd), s["cam_tar"], s["bounds"], SC, SF),
+                                               oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF), None
         except AssertionError as e:
             return None, str(e)[:300]
 
