@@ -698,7 +698,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // frame SLOWER than recomputing.
 #pragma unroll(VFIX > 0 ? VFIX : 1)
         for (int v = 0; v < V; ++v) {
-            if (!((keep >> v) & 1u)) return;
+            if (!((keep >> v) & 1u)) continue;
             kpn_gather_view(scr + lay.rec(t_scr, v) * 64, l_scr, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             stats(gv.rd[3], iv);
@@ -787,7 +787,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         // block, i.e. no HBM misses at all, the frame is 0.9 ms faster: profiles/r04_z_ab_experiments.txt)
 #pragma unroll 1
         for (int v = 0; v < V; ++v) {
-            if (!((keep >> v) & 1u)) return;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
+            if (!((keep >> v) & 1u)) continue;  // logit -1e9 (masked_fill, :1300): softmax weight exactly 0
             kpn_gather_view(scr + lay.rec(t_scr, v) * 64, l_scr, h, gv);
             kpn_encode_view<F16>(wl, lane, h, gv, lat0, iv);
             head(gv, iv);
