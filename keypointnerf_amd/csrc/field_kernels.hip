@@ -282,13 +282,13 @@ template <> struct kpn_fuse_w<true> {
 template <bool F16, int SEG, int KS, int NOB, class InFn>
 __device__ __forceinline__ void kpn_fuse_layer(const float* __restrict__ wl, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
     static_assert(KS == kpn_seg_shapes[SEG].ks && NOB == kpn_seg_shapes[SEG].nob, "segment shape");
-    if constexpr (F16) kpn_hlayer<KS, NOB>(wl + kpn_fuse_w<true>::woff(SEG), lane, in_fn, acc);
+    if constexpr (F16) kpn_hlayer<KS, NOB, SEG>(wl + kpn_fuse_w<true>::woff(SEG), lane, in_fn, acc);
     else kpn_mfma_layer<KS, NOB, 4, 1>(wl + kpn_fuse_w<false>::woff(SEG), lane, in_fn, acc);
 }
 template <bool F16, int SEG, int KS, int NOB, int NSRC>
 __device__ __forceinline__ void kpn_fuse_layer_regs(const float* __restrict__ wl, int lane, const float (&src)[NSRC], kpn_f32x16 (&acc)[NOB]) {
     static_assert(KS == kpn_seg_shapes[SEG].ks && NOB == kpn_seg_shapes[SEG].nob, "segment shape");
-    if constexpr (F16) kpn_hlayer_regs<KS, NOB>(wl + kpn_fuse_w<true>::woff(SEG), lane, src, acc);
+    if constexpr (F16) kpn_hlayer_regs<KS, NOB, SEG>(wl + kpn_fuse_w<true>::woff(SEG), lane, src, acc);
     else kpn_mfma_layer_regs<KS, NOB, 4, 1>(wl + kpn_fuse_w<false>::woff(SEG), lane, src, acc);
 }
 
@@ -561,7 +561,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
                     for (int i = 0; i < 8; ++i) x8[i] = pooled[8 * c + i];
                     kpn_split_f16x8(x8, pooled_h[c], pooled_l[c]);
                 }
-                kpn_hlayer_presplit<8, 2>(wl + W::woff(SEG_G2_0), lane, pooled_h, pooled_l, h0);
+                kpn_hlayer_presplit<8, 2, SEG_G2_0>(wl + W::woff(SEG_G2_0), lane, pooled_h, pooled_l, h0);
             } else {
                 kpn_fuse_layer_regs<F16, SEG_G2_0, 64, 2>(wl, lane, pooled, h0);
             }
@@ -624,7 +624,7 @@ __device__ __forceinline__ void kpn_fuse_color_body(const kpn_scene_dev& sc, con
         {
             kpn_f32x16 acc[1];
             kpn_load_bias<1>(wl + W::boff(SEG_CMP), h, acc);
-            if constexpr (F16) kpn_hlayer_presplit<8, 1>(wl + W::woff(SEG_CMP), lane, pooled_h, pooled_l, acc);
+            if constexpr (F16) kpn_hlayer_presplit<8, 1, SEG_CMP>(wl + W::woff(SEG_CMP), lane, pooled_h, pooled_l, acc);
             else kpn_fuse_layer_regs<F16, SEG_CMP, 64, 1>(wl, lane, pooled, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) lat0[r] = acc[0][r];

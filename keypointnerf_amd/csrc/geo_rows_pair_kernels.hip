@@ -395,6 +395,21 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     kpn_static_for<0, KS16>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int cur = s & 1, nxt = cur ^ 1;
+#ifdef KPN_PRECISION_PROBE   // probe builds only (kpn_common.h): this step's lo pieces of B / A replaced by zero
+        if constexpr (NP == 2) {
+            constexpr int lid = KS16 == 16 ? 0 : (KS16 == 9 ? 2 : (NOB == 2 ? 3 : 1));
+            constexpr int grp = SMAP::at(s) < 12 ? 4 : 5;          // layers1.0: keypoint-encoding steps / sampled-channel steps
+            const bool drop_b = KPN_PROBE(lid, 0) || (lid == 0 && KPN_PROBE(grp, 0));
+            const bool drop_a = KPN_PROBE(lid, 1) || (lid == 0 && KPN_PROBE(grp, 1));
+            if (drop_b) { xp[cur][0][1] = kpn_u32x4{0u, 0u, 0u, 0u}; xp[cur][1][1] = kpn_u32x4{0u, 0u, 0u, 0u}; }
+            if (drop_a) {
+#pragma unroll
+                for (int k = 0; k < H0; ++k) wa[wsel(s)][1][k] = kpn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < H1; ++k) wb[wsel(s)][1][k] = kpn_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#endif
         kpn_static_for<0, MF>([&](auto mi) {
             constexpr int m = decltype(mi)::value;
             mfma(mi, kpn_ic<wsel(s)>{}, xp[cur]);

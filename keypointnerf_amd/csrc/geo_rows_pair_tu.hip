@@ -32,6 +32,11 @@ extern "C" __attribute__((visibility("hidden"))) void kpn_internal_launch_row_re
     KPN_LAUNCH(k_row_records_live, dim3(blocks), dim3(256), stream, *sc, *ps, wp, list, count, tickets, live, xscr, *batch);
 }
 
+#ifdef KPN_PRECISION_PROBE
+extern "C" __attribute__((visibility("hidden"))) int kpn_internal_probe_set_mask_pair(unsigned long long m) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(kpn_probe_mask_dev), &m, sizeof(m)) != hipSuccess;
+}
+#endif
 #ifdef KPN_H2_TIMING
 // debug builds only: read (and clear) the per-phase cycle sums of k_geo_rows_h2
 extern "C" int kpn_h2_timing(unsigned long long* out8) {

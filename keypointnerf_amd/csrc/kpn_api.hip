@@ -1138,6 +1138,15 @@ extern "C" int kpn_density_stats(void* stream, int64_t* listed_host, int64_t* li
     *live_host = (int64_t)v[1];
     return KPN_OK;
 }
+#if defined(KPN_PRECISION_PROBE) && !defined(KPN_SIMT_EMU)
+// probe builds only (scripts/precision_budget.py): which lo pieces the two-fp16-piece kernels replace by zero (kpn_common.h)
+extern "C" int kpn_internal_probe_set_mask_pair(unsigned long long m);
+extern "C" int kpn_probe_set_mask(unsigned long long m) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(kpn_probe_mask_dev), &m, sizeof(m)) != hipSuccess) return fail(KPN_ELAUNCH, "probe mask");
+    if (kpn_internal_probe_set_mask_pair(m)) return fail(KPN_ELAUNCH, "probe mask (pair unit)");
+    return hipDeviceSynchronize() == hipSuccess ? KPN_OK : KPN_ELAUNCH;
+}
+#endif
 extern "C" int kpn_density_first_passes(int64_t* density_first_host, int64_t* fused_host, int32_t reset) {
     KPN_REQUIRE(density_first_host && fused_host, "null pointer");
     *density_first_host = g_density_first_passes[0];

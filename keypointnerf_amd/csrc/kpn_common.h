@@ -107,6 +107,15 @@ __device__ __forceinline__ float kpn_opaque_minus_one() {
     asm("s_mov_b32 %0, -1.0" : "=s"(m));   // pure: hoisted out of loops and merged by CSE
     return m;
 }
+#ifdef KPN_PRECISION_PROBE
+// PRECISION-BUDGET PROBE BUILDS ONLY (scripts/precision_budget.py, profiles/r06_precision_budget.md; never defined in the shipped
+// library): bit 2 * id + 0 of the mask drops the LO piece of the B operand (activations) of layer `id`, bit 2 * id + 1 the lo piece
+// of its A operand (weights) — the product hl resp. lh then multiplies by zero, i.e. that operand is carried as ONE fp16 piece.
+// ids: 0..3 = layers1.0 .. 1.3 (rows kernel), 4 / 5 = the keypoint-encoding / the sampled-channel K steps of layers1.0 only,
+// 8 + (SEG - SEG_G2_0) = the per-point kernel's layers.  One copy of the mask per translation unit (kpn_probe_set_mask sets both).
+static __device__ unsigned long long kpn_probe_mask_dev;
+#define KPN_PROBE(id, operand) (((kpn_probe_mask_dev) >> (2 * (id) + (operand))) & 1ull)
+#endif
 __device__ __forceinline__ void kpn_split_f16x8(const float (&x)[8], kpn_u32x4& h, kpn_u32x4& l) {
     const float m1 = kpn_opaque_minus_one();
 #pragma unroll

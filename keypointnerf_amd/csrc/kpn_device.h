@@ -302,7 +302,7 @@ __device__ __forceinline__ void kpn_mfma_layer_regs(const float* __restrict__ ws
 // segment (kpn_common.h), KS fp32 K-steps taken eight at a time.  in_fn has kpn_mfma_layer's signature with G = 4
 // (in_fn(kpn_ic<g>, float (&x)[4]) = K-steps 4g .. 4g+3); a chunk is two such groups.  Compiler-scheduled, every instruction
 // compiler-selected (no asm statement: hipcc pads every MFMA <-> VALU pair itself); two waves share a SIMD in this kernel.  3 MFMAs of 32 cycles per (chunk, block) against 8 of 64 on the fp32 pipe.
-template <int KS, int NOB, class InFn>
+template <int KS, int NOB, int LID = -1, class InFn>
 __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int lane, InFn&& in_fn, kpn_f32x16 (&acc)[NOB]) {
     constexpr int NC = (KS + 7) / 8, NG = (KS + 3) / 4;
     const kpn_lptr4 base = KPN_LDS4(wseg) + lane;
@@ -321,9 +321,16 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
         }
         kpn_u32x4 bh, bl;
         kpn_split_f16x8(x, bh, bl);
+#ifdef KPN_PRECISION_PROBE
+        if (LID >= 0 && KPN_PROBE(8 + LID - SEG_G2_0, 0)) bl = kpn_u32x4{0u, 0u, 0u, 0u};
+#endif
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
-            const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
+            const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64];
+            kpn_f32x4 al = base[((c * NOB + ob) * 2 + 1) * 64];
+#ifdef KPN_PRECISION_PROBE
+            if (LID >= 0 && KPN_PROBE(8 + LID - SEG_G2_0, 1)) al = kpn_f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
             // Three products (ll dropped: <= 2^-24 of a term, as in the rows kernel), in the order hh lh hl.  (Round 4: with the order
             // hh hl lh this kernel came out wrong and non-deterministic on the MI355X.  Not the order: the operand splits were asm
             // statements then, and in that build the register allocator had put their outputs into dead registers of an MFMA's
@@ -338,25 +345,33 @@ __device__ __forceinline__ void kpn_hlayer(const float* __restrict__ wseg, int l
 }
 // the same layer with B operands that are ALREADY split (one kpn_split_f16x8 per chunk, shared by several layers that consume the
 // same vector: layers2.0 and ibr_compress_gfeat both take the pooled 128-vector)
-template <int NC, int NOB>
-__device__ __forceinline__ void kpn_hlayer_presplit(const float* __restrict__ wseg, int lane, const kpn_u32x4 (&bh)[NC], const kpn_u32x4 (&bl)[NC],
+template <int NC, int NOB, int LID = -1>
+__device__ __forceinline__ void kpn_hlayer_presplit(const float* __restrict__ wseg, int lane, const kpn_u32x4 (&bh)[NC], const kpn_u32x4 (&bl_in)[NC],
                                                     kpn_f32x16 (&acc)[NOB]) {
     const kpn_lptr4 base = KPN_LDS4(wseg) + lane;
     kpn_static_for<0, NC>([&](auto ci) {
         constexpr int c = decltype(ci)::value;
+        kpn_u32x4 blc = bl_in[c];
+#ifdef KPN_PRECISION_PROBE
+        if (LID >= 0 && KPN_PROBE(8 + LID - SEG_G2_0, 0)) blc = kpn_u32x4{0u, 0u, 0u, 0u};
+#endif
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
-            const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64], al = base[((c * NOB + ob) * 2 + 1) * 64];
+            const kpn_f32x4 ah = base[((c * NOB + ob) * 2 + 0) * 64];
+            kpn_f32x4 al = base[((c * NOB + ob) * 2 + 1) * 64];
+#ifdef KPN_PRECISION_PROBE
+            if (LID >= 0 && KPN_PROBE(8 + LID - SEG_G2_0, 1)) al = kpn_f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
             acc[ob] = kpn_mfma_f16(ah, bh[c], acc[ob]);
-            if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, bl[c], acc[ob]); }
-            else { acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(ah, bl[c], acc[ob]); }
+            if constexpr (KPN_FUSE_F16_PRODUCTS == 4) { acc[ob] = kpn_mfma_f16(ah, blc, acc[ob]); acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(al, blc, acc[ob]); }
+            else { acc[ob] = kpn_mfma_f16(al, bh[c], acc[ob]); acc[ob] = kpn_mfma_f16(ah, blc, acc[ob]); }
         }
     });
 }
-template <int KS, int NOB, int NSRC>
+template <int KS, int NOB, int LID = -1, int NSRC>
 __device__ __forceinline__ void kpn_hlayer_regs(const float* __restrict__ wseg, int lane, const float (&src)[NSRC], kpn_f32x16 (&acc)[NOB]) {
     static_assert(NSRC >= KS, "operand array too short");
-    kpn_hlayer<KS, NOB>(wseg, lane, [&](auto gi, float (&x)[4]) {
+    kpn_hlayer<KS, NOB, LID>(wseg, lane, [&](auto gi, float (&x)[4]) {
         constexpr int g = decltype(gi)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = (g * 4 + i < KS) ? src[g * 4 + i] : 0.0f;

@@ -12,8 +12,13 @@ TILED_CASE = "case_d_v3_tiled_frame"
 REAL_ENCODER_CASE = "case_s_v3_real_encoder_maps"
 
 
-def load_weights():
-    z = np.load(os.path.join(GOLDEN_DIR, "weights_ref_seed0.npz"))
+# Round 6: the reference's hot-path modules after 300 Adam steps of its own train branch + compute_error on textured-ellipsoid scenes
+# (oracle/make_trained_golden.py), and a configs[1] tile rendered by the reference with THOSE weights and its encoders' maps
+TRAINED_CASE, TRAINED_WEIGHTS = "case_t_v3_trained_tile", "weights_trained_seed0.npz"
+
+
+def load_weights(name="weights_ref_seed0.npz"):
+    z = np.load(os.path.join(GOLDEN_DIR, name))
     return {k: torch.from_numpy(z[k]) for k in z.files}
 
 

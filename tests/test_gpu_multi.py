@@ -18,6 +18,20 @@ def test_bench_two_ranks_over_rccl():
     assert p.stdout.count('"rccl_ranks": 2') == 2, p.stdout
 
 
+def test_rccl_branch_with_one_rank_on_one_gpu():
+    """Round 6: what one GPU allows of the RCCL branch — init_process_group("nccl", world_size=1) on cuda:0 and FrameGatherer's
+    DEVICE path (device staging, stream-ordered copy, dist.gather(async_op=True), buffer reuse after wait) over five rounds of frames
+    rendered by the HIP kernels: every gathered frame bit-equal to the rendered one (scripts/rccl_one_rank.py).  With two GPUs the
+    test above runs the real exchange."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_one_rank.py"), "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl" and d["rounds"] == 5 and d["asynchronous"] is True
+    assert d["dist_library"].startswith("RCCL ")
+
+
 # ---- the N > 1 flow on ONE GPU (the box the driver's GPU tier runs on): two gloo ranks, both on cuda:0, the DEVICE kernels ----
 def _free_port():
     import socket

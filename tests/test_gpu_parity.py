@@ -155,6 +155,44 @@ def test_headline_configs_vs_reference(ops, golden_weights, case, fine, rows_mod
     assert (v.cpu().numpy().reshape(-1) != bits).sum() <= 4   # a point within an ulp of a mask / frustum threshold may flip
 
 
+@pytest.mark.parametrize("rows_mode", [3, 2, 0], indirect=True)
+def test_trained_weights_tile_vs_reference(ops, rows_mode):
+    """Round 6: HIP against the reference with TRAINED hot-path weights — 300 Adam steps of the reference's own train branch +
+    compute_error (L1 terms) at lr 5e-4 on textured-ellipsoid scenes with its encoders' maps (oracle/make_trained_golden.py):
+    weight_g / weight_v / biases have drifted by up to 0.09, the density has begun to sharpen — on a configs[1] tile (4096 rays of a
+    512 x 512 target, V = 3, 64 + 64 samples), strict 1e-4 on every ray, in each of the three rows kernels, the range guard untouched;
+    the field at the reference's own query points; density first on and off."""
+    from tests.golden_io import TRAINED_CASE, TRAINED_WEIGHTS
+    from keypointnerf_amd import lib as kl
+    L = kl.get_library()
+    scene, cfg, g = load_case(TRAINED_CASE)
+    sd = load_weights(TRAINED_WEIGHTS)
+    w = ops.PackedWeights(sd)
+    s, ps = _prep(ops, scene)
+    step = 2 ** (cfg["level"] - 1)
+    ny, nx = s["cam_tar"]["height"] // step, s["cam_tar"]["width"] // step
+    c0 = ops.range_guard_count()
+    frames = []
+    try:
+        for df in (2, 1, 0):
+            L.check(L.kpn_set_density_first(df))
+            out = ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(cfg["stride_j"], cfg["stride_i"], step, nx, ny), n_coarse=cfg["Sc"], n_fine=cfg["Sf"])
+            frames.append({k: v.clone() for k, v in out.items()})
+    finally:
+        L.check(L.kpn_set_density_first(2))
+    for k in frames[0]:
+        ref = g["out." + k]
+        if k.startswith(("tex", "alpha")):
+            assert np.abs(frames[0][k].cpu().numpy() - ref).max() <= RGBA_TOL, (k, np.abs(frames[0][k].cpu().numpy() - ref).max())
+        else:
+            np.testing.assert_allclose(frames[0][k].cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+        assert torch.equal(frames[0][k], frames[1][k]) and torch.equal(frames[0][k], frames[2][k]), k
+    assert ops.range_guard_count() == c0                    # range_guard_batches_redone: 0 with the trained weights
+    for i in range(2):
+        o, v = ops.query(ps, w, torch.from_numpy(g[f"query.{i}.pts"]).cuda(), torch.from_numpy(g[f"query.{i}.view"]).cuda(), mode=0)
+        check_query_against_reference(o.cpu().numpy()[0], v.cpu().numpy().reshape(-1), g, i, scene, 2e-5)
+
+
 def test_zero_density_tiles_take_the_short_path_exactly(ops, monkeypatch):
     """Tiles of the valid list whose 32 points all have relu(rad) == 0 skip compress + the colour head in the render passes
     (their colours are multiplied by a contribution of exactly 0): with a density head biased so that half of the visual

@@ -116,6 +116,29 @@ def test_headline_configs_vs_reference(env, case, fine):
         check_query_against_reference(out, valid, gs, i, scene, 2e-5)
 
 
+def test_trained_weights_tile_vs_reference(env):
+    """Round 6: the kernel sources on the emulator against the reference with TRAINED weights (tests/golden_io.py TRAINED_CASE): a
+    strided subset of the configs[1] tile's rays and the field at the recorded query points; the range guard stays out of it."""
+    from tests.golden_io import TRAINED_CASE, TRAINED_WEIGHTS
+    lib = env[0]
+    sd = load_weights(TRAINED_WEIGHTS)
+    packed = sh.pack_weights(lib, sd)
+    scene, cfg, g = load_case(TRAINED_CASE)
+    hs = sh.HostScene(lib, scene)
+    step, sub = 2 ** (cfg["level"] - 1), 8
+    c0 = _guard_count(lib)
+    o = sh.render(lib, hs, packed, scene["cam_tar"], scene["bounds"], (cfg["stride_j"], cfg["stride_i"], step * sub, 64 // sub, 64 // sub), cfg["Sc"], cfg["Sf"])
+    assert _guard_count(lib) == c0
+    for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+        ref = g["out." + k][0][..., ::sub, ::sub]
+        assert np.abs(o[k] - ref).max() < 3e-5, (k, np.abs(o[k] - ref).max())
+    for i in range(2):
+        n = 512
+        out, valid = sh.query(lib, hs, packed, g[f"query.{i}.pts"][0][:n], g[f"query.{i}.view"][0][:n])
+        gs = {k: (v[:, :n] if k.startswith(f"query.{i}.") and v.ndim >= 2 else v) for k, v in g.items()}
+        check_query_against_reference(out, valid, gs, i, scene, 2e-5)
+
+
 @pytest.mark.parametrize("step,Sc,Sf", [(8, 70, 66), (12, 128, 128), (6, 3, 1)])
 def test_render_sample_count_extremes(env, step, Sc, Sf):
     """Sc, Sf > 64 take the sampler's two-elements-per-lane path (k_fine_samples_w<false>); the largest (128 + 128) and the

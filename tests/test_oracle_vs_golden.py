@@ -124,6 +124,26 @@ def test_headline_configs_vs_reference(case, fine, wflat):
     assert n_masked > 300                                  # every one of them compared, not a quantile
 
 
+def test_trained_weights_tile_vs_reference():
+    """Round 6: the oracle against the reference with TRAINED hot-path weights (300 Adam steps of the reference's own train branch,
+    oracle/make_trained_golden.py) on a configs[1] tile whose maps come from the reference's encoders: all 4096 rays, all keys, and
+    the field at the reference's own query points."""
+    from tests.golden_io import TRAINED_CASE, TRAINED_WEIGHTS
+    scene, cfg, g = load_case(TRAINED_CASE)
+    wf = oracle.flat_weights(load_weights(TRAINED_WEIGHTS))
+    assert float(np.abs(wf - oracle.flat_weights(load_weights())).max()) > 0.02      # the weights really moved
+    osc = oracle.OracleScene(scene)
+    pix, _ = pixel_list(cfg, scene["cam_tar"])
+    assert pix.shape[0] == 4096 and (cfg["Sc"], cfg["Sf"]) == (64, 64)
+    o = oracle.render_rays(osc, wf, scene["cam_tar"], scene["bounds"], pix, cfg["Sc"], cfg["Sf"], fine=True)
+    for k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine"):
+        assert np.abs(o[k] - out_as_rays(g, k)).max() < 2e-5, (k, np.abs(o[k] - out_as_rays(g, k)).max())
+    assert 0.1 < float(out_as_rays(g, "alpha_fine").mean()) < 0.9
+    for i in range(2):
+        out, valid = oracle.query(osc, wf, g[f"query.{i}.pts"][0], g[f"query.{i}.view"][0])
+        check_query_against_reference(out, valid, g, i, scene, 1e-5)
+
+
 def test_full_frame_equals_tiles(wflat):
     """The reference assembles a frame from stride^2 strided tiles + pixel_shuffle (src/model.py:916-938);
     rendering every pixel directly must give the same image."""
