@@ -61,9 +61,9 @@ def scenes(n_random):
         if wfile:
             z = np.load(os.path.join(ROOT, "tests", "golden", wfile))
             sd = {k: torch.from_numpy(z[k]) for k in z.files}
-        pix, _ = pixel_list(cfg, scene["cam_tar"])
-        if pix.shape[0] > 1024:
-            pix = pix[::4]
+        pix, (h, w) = pixel_list(cfg, scene["cam_tar"])
+        if pix.shape[0] > 1024:                  # every second row and column of the tile's lattice
+            pix = np.ascontiguousarray(pix.reshape(h, w, 2)[::2, ::2].reshape(-1, 2))
         out.append((case, scene, sd, pix, cfg["Sc"], cfg["Sf"], fine))
     rng = np.random.default_rng(7)
     for i in range(n_random):
