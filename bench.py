@@ -296,19 +296,60 @@ def time_training(ops, torch, dev, sd, steps=10, patch=32):
                                                  state=kept["state"], **kw)
     bwd_classic = lambda: ops.render_rays_train_backward(ps, w, scene["cam_tar"], scene["bounds"], pix, u_c, u_f, 0b111, 0b101, grads, **kw)
     out = {}
+    from keypointnerf_amd import lib as kl
+    L = kl.get_library()
     for name, fn in (("forward_ms", fwd), ("backward_ms", bwd), ("backward_repeating_the_forward_ms", bwd_classic)):
         fn()
         torch.cuda.synchronize()
+        if name == "backward_ms":
+            L.check(L.kpn_bwd_profile_enable(1))
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / steps * 1e3
+        if name == "backward_ms":
+            out["backward_roofline"] = backward_roofline(L, steps)
+            L.check(L.kpn_bwd_profile_enable(0))
     out["iterations_per_sec"] = 1e3 / (out["forward_ms"] + out["backward_ms"])
     out["rays_per_sec"] = R * out["iterations_per_sec"]
     out["workload"] = (f"configs[3] field part: {R} rays x (64 coarse + 128 fine-pass) evaluations, V=3, view dropout + density noise, "
                        "fwd (kpn_render_rays_train_keep) + bwd (kpn_render_rays_train_backward_kept) in HIP")
     return out
+
+
+def backward_roofline(L, steps):
+    """Per kernel group of the training backward (HIP events inside the library, kpn_bwd_profile_*): time per iteration, achieved
+    TFLOP/s against the roof of the arithmetic it runs on, and the bytes of layer inputs / output gradients it dumps or reads back
+    against HBM.  FLOP models, 2 x MAC (layer shapes: SURVEY Appendix A; reference src/utils.py:691-720, src/model.py:1267-1302):
+      k_geo_rows_bwd   per (point, view) row: recompute layers1.0-1.2 (29,696 + 16,384 + 16,320) + dX = W^T dY of layers1.3, 1.2, 1.1
+                       and the 64 sampled-channel columns of layers1.0 (7,680 + 16,320 + 16,384 + 8,192) = 110,976 MAC; three bf16
+                       pieces per operand, six products: roof 2500 / 6 = 416.7 fp32-equivalent TFLOP/s
+      k_weight_grad    dW = dY^T X of every layer: 70,080 (layers1) + 13,256 (colour head) MAC per row + 15,488 (layers2 + compress)
+                       per point; three bf16 pieces, six products: roof 416.7
+      k_color_bwd      per kept row: the head's recompute + its reverse (2 x 13,256 MAC), + compress per point (3,072): fp32 MFMA, roof 157.3
+      k_fuse_bwd       per point: layers2 recompute + reverse (2 x 12,416) + the compress reverse (3,072): fp32 MFMA, roof 157.3
+    Dumps: k_geo_rows_bwd writes 4,288 B per row (X0..X3, D0..D3), k_color_bwd 2,920 B per kept row; k_weight_grad reads both once."""
+    ms, n = (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+    rows, kept, pts = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.kpn_bwd_profile_collect(ms, n, ctypes.byref(rows), ctypes.byref(kept), ctypes.byref(pts)))
+    rows, kept, pts = rows.value / steps, kept.value / steps, pts.value / steps
+    flop = {"k_geo_rows_bwd": (3, 2.0 * 110976 * rows, 2500.0 / 6, 4288.0 * rows, "written"),
+            "k_weight_grad": (4, 2.0 * ((70080 + 13256) * rows + 15488 * pts), 2500.0 / 6, 4288.0 * rows + 2920.0 * kept, "read"),
+            "k_color_bwd": (1, 2.0 * (2 * 13256 * kept + 3072 * pts), FP32_MFMA_PEAK_TFLOPS, 2920.0 * kept, "written"),
+            "k_fuse_bwd": (2, 2.0 * ((2 * 12416 + 3072) * pts), FP32_MFMA_PEAK_TFLOPS, None, None)}
+    res = {"rows_per_iteration": rows, "kept_rows_per_iteration": kept, "valid_points_per_iteration": pts, "kernels": {}}
+    for k, (i, f, peak, dump, how) in flop.items():
+        t = ms[i] / steps
+        e = {"ms_per_iteration": t, "achieved": f / max(t * 1e-3, 1e-12) / 1e12, "peak": peak, "unit": "TFLOP/s",
+             "frac": f / max(t * 1e-3, 1e-12) / 1e12 / peak, "bound": "mfma"}
+        if dump:
+            e["dump_bytes_" + how] = dump
+            e["dump_GBps"] = dump / max(t * 1e-3, 1e-12) / 1e9
+            e["dump_frac_of_hbm_8TBps"] = e["dump_GBps"] / 8000.0
+        res["kernels"][k] = e
+    res["sum_of_kernels_ms"] = sum(ms[i] for i in range(5)) / steps
+    return res
 
 
 def launch_ranks(args):

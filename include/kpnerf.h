@@ -332,6 +332,13 @@ int kpn_profile_collect2(double* geo_rows_ms_host, int64_t* launches_host, int64
  * 2.4 GHz peak): a roofline fraction against the 2.4 GHz peak understates what the kernel does per cycle.  0 if not measured. */
 int kpn_profile_collect3(double* geo_rows_ms_host, int64_t* launches_host, int64_t* rows_host, int64_t* surplus_launches_host,
                          double* clock_ghz_host);
+/* The same for the BACKWARD (kpn_query_backward, kpn_render_rays_train_backward[_kept]): HIP events around each kernel group of
+ * every pass while enabled.  kpn_bwd_profile_collect: ms5 / launches5 = time and launch groups of [0] k_geo_rows (the forward's rows,
+ * only when the pass recomputes them), [1] k_color_bwd, [2] k_fuse_bwd, [3] k_geo_rows_bwd, [4] k_weight_grad<*> + reduce;
+ * *rows = valid points x V of the recorded passes (the rows k_geo_rows_bwd and k_weight_grad process), *kept_rows = valid points x
+ * views kept by the pass's dropout mask (the rows k_color_bwd processes), *points = valid points.  Synchronises the device. */
+int kpn_bwd_profile_enable(int32_t on);
+int kpn_bwd_profile_collect(double* ms5, int64_t* launches5, int64_t* rows, int64_t* kept_rows, int64_t* points);
 size_t kpn_row_scratch_cap_bytes(void);
 /* Process-wide; workspace sizes queried before a change are stale (query kpn_*_workspace_bytes again). */
 int kpn_set_row_scratch_cap_bytes(size_t bytes);

@@ -667,8 +667,13 @@ __global__ __launch_bounds__(256, KPN_COLOR_OCC) void k_color_bwd(kpn_scene_dev 
             // d tex: x' rows 27..34 = tex 0..7: row 27 = reg 15 (h=0); rows 28..31 = regs 12..15 (h=1); rows 32..34 = block 1 (h=0)
             {
                 const float* tb = sc.table + (size_t)v * KPN_TBL_STRIDE;
-                const kpn_proj q = kpn_project(tb, P[0], P[1], P[2], sc);
-                const kpn_taps tt = kpn_make_taps(q.xn, q.yn, sc.th, sc.tw);
+                // strict arithmetic, like the forward's gather record (kpn_row_record_b<true>): the gradient goes back through the very
+                // texels the forward sampled (an advisor finding of round 5: the contracting flavour can land one texel off at an
+                // integer boundary)
+                float Ps[3], Ds[3];
+                kpn_get_point<true>(ps, n, Ps, Ds);
+                const kpn_proj q = kpn_project<true>(tb, Ps[0], Ps[1], Ps[2], sc);
+                const kpn_taps tt = kpn_make_taps<true>(q.xn, q.yn, sc.th, sc.tw);
                 float* sg = scat_s[w4][p];
                 if (h == 0) {
                     sg[0] = dq[15]; sg[5] = dq[16]; sg[6] = dq[17]; sg[7] = dq[18];

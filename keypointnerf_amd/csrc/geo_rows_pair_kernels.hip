@@ -10,8 +10,11 @@
 //    instructions hide under one of these MFMAs, MI355X_MICROARCH.md);
 //  * both tiles multiply by the same weights: every A operand fetched from L2 serves 64 points instead of 32 (the weight
 //    stream of this layer set is 444 KB per work item — half the L2 traffic per row);
-//  * one wave per SIMD is also the configuration in which the split-bf16 chain has never produced a wrong value (section 9.2:
-//    the unexplained failures need two waves sharing a SIMD).
+//  * (rounds 2-3 also noted that the one-tile kernel at two waves per SIMD produced rare wrong half-tiles and this shape never
+//    did.  Round 5 found the cause, and it is not the occupancy: an inline-asm operand split whose output registers the allocator
+//    had placed inside the destination tuple of an MFMA still in flight loses against the MFMA's write-back — DESIGN.md 4.5, 9.2,
+//    scripts/repro_asm_waw_hazard.hip.  The asm slices of THIS kernel are hand-placed and audited on every build:
+//    tests/test_isa_audit.py.)
 //
 // The instruction stream is pipelined BY HAND (the compiler's scheduler, left alone or steered with sched_group_barrier,
 // clumps a step's VALU work and then issues its 48 MFMAs back to back — measured 9.7 ms per launch, no faster than the fp32
@@ -47,8 +50,10 @@
 //                 sum of |terms|) — EXCEPT for operands far below 1e-2, where the floor shows: layers1.3's weights, scaled
 //                 by ln(2)/100 for the log2-unit activation, are therefore packed times 2^10 and the rows multiplied by 2^-10
 //                 when they are stored.  The price is fp16's range: an operand beyond 65504 (a pre-activation beyond 454 in
-//                 natural units, a packed weight beyond 65504) becomes inf and the row NaN — loudly wrong, never silently;
-//                 kpn_set_geo_rows_mode(2) is the range-safe alternative.
+//                 natural units, a packed weight beyond 65504) becomes inf and the row NaN.  (Round 3 called that "loudly
+//                 wrong"; it was not — a clamp or a v_med3 turns the NaN back into a finite, wrong number.  Since round 4 every
+//                 activation of these kernels keeps a NaN and the RANGE GUARD, kpn_field_shared.h, has such a batch evaluated
+//                 again by the fp32-range kernels: DESIGN.md 4.6.)  kpn_set_geo_rows_mode(2) is the range-safe alternative.
 struct kpn_sc_bf16x3 {
     static constexpr int NP = 3, NPROD = 6, NSLICE = 6;
     static constexpr int pa(int pr) { return pr == 2 || pr == 3 ? 1 : (pr == 5 ? 2 : 0); }   // A piece of product pr: h h m m h l
@@ -324,7 +329,8 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     kpn_h2_pair pr{0.f, 0.f, 0.f, 0.f, 0u};
     // A step's pieces are contiguous ([step][block][piece][lane] x 16 B: 8 KB with four output blocks): ONE uniform base for the
     // layer (SGPR pair), a per-lane byte offset in a VGPR that points at the MIDDLE of the current step, and immediate offsets of
-    // -4 .. +3 KB (the 13-bit signed range of global_load) for its eight 1-KB rows: the offset register is advanced once per step
+    // -4 .. +3 KB (the 13-bit signed range of global_load; NP = 2 only — the three-piece scheme's 12-KB steps need base
+    // adjustments) for its eight 1-KB rows: the offset register is advanced once per step
     // by one v_add_u32 (re-defined through an empty asm so that the loads cannot rise above it).  Until round 4 the base was a
     // running SGPR pointer advanced per HALF step: s_add_u32 + s_addc_u32 = 290 scalar instructions per (tile pair, view) in a
     // kernel that is bound by its issue slots at one wave per SIMD (profiles/r05_b_rows_kernel_ablations.txt).  (Computed as
@@ -336,7 +342,9 @@ __device__ __forceinline__ void kpn_mfma16_layer2(const float* __restrict__ hseg
     asm volatile("" : "+v"(voff));
 #endif
     auto load_half = [&](int s, int ob0, int n, auto& w) {
-        if (ob0 == 0 && s != prev_step) {           // (compile-time: s and prev_step are constants after unrolling)
+        // (the offset follows the step whichever half asks first — an advisor finding of round 5: with `ob0 == 0 &&` in the condition
+        // a future reorder of the load_virtual calls would have read the previous step's weights for a second half)
+        if (s != prev_step) {                       // (compile-time: s and prev_step are constants after unrolling)
             voff += (uint32_t)((s - prev_step) * STEP_BYTES);
             prev_step = s;
 #ifndef KPN_SIMT_EMU

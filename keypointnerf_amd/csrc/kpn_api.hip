@@ -999,7 +999,8 @@ void launch_fuse(int fmode, const kpn_scene_dev& sc, const kpn_points& ps, const
                  int* tickets, const float* xscr, int mode, int park_x, float* out, const kpn_batch& batch, int zero_skip, void* stream) {
     const int fblocks = fuse_grid_blocks();  // one 512-thread workgroup per CU: its 137 / 141 KB of weights sit in LDS
     static const int fthreads = [] { const char* e = getenv("KPN_FUSE_THREADS"); return e ? atoi(e) : 512; }();  // tuning knob
-    if (fmode == 1 && sc.V == 3 && (sc.keep & 7u) == 7u)   // the shipped view count, no view dropped: the unrolled variant
+    const char* no_h3 = getenv("KPN_NO_FUSE_H3");   // A/B and test knob, read per call: the generic kernel for V = 3 as well
+    if (fmode == 1 && sc.V == 3 && (sc.keep & 7u) == 7u && !(no_h3 && atoi(no_h3)))   // the shipped view count, no view dropped: the unrolled variant
         KPN_LAUNCH(k_fuse_color_h3, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
     else if (fmode == 1)
         KPN_LAUNCH(k_fuse_color_h, dim3(fblocks), dim3(fthreads), stream, sc, ps, wp, list, count, tickets, xscr, mode, park_x, out, batch, zero_skip);
@@ -1016,7 +1017,8 @@ void launch_density_first(const kpn_scene_dev& sc, const kpn_points& ps, const f
 #else
     kpn_internal_launch_row_records_live(2048, stream, &sc, &ps, wp, list, count, tickets, live, xscr, &batch);
 #endif
-    if (sc.V == 3 && (sc.keep & 7u) == 7u)
+    const char* no_h3 = getenv("KPN_NO_FUSE_H3");
+    if (sc.V == 3 && (sc.keep & 7u) == 7u && !(no_h3 && atoi(no_h3)))
         KPN_LAUNCH(k_colour_h3, dim3(fblocks), dim3(512), stream, sc, ps, wp, list, count, tickets, (const float*)xscr, live, out, batch);
     else
         KPN_LAUNCH(k_colour_h, dim3(fblocks), dim3(512), stream, sc, ps, wp, list, count, tickets, (const float*)xscr, live, out, batch);
@@ -1281,6 +1283,32 @@ __global__ void k_bwd_rows(const int* __restrict__ count, int V, int64_t* __rest
 }
 
 namespace {
+// ---- measurement hooks of the backward (kpn_bwd_profile_enable / _collect): HIP events around each kernel group of a pass ----
+enum { BP_ROWS_FWD = 0, BP_COLOR_BWD, BP_FUSE_BWD, BP_ROWS_BWD, BP_WGRAD, BP_KINDS };
+#ifndef KPN_SIMT_EMU
+struct BwdProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;        // pairs
+    std::vector<int> kind;
+    int* counts_host = nullptr;        // pinned: per recorded PASS the valid count and the view count / keep mask
+    size_t used = 0, cap = 0, passes = 0;
+};
+static BwdProf g_bprof;
+struct BwdProfScope {                  // brackets the launches made while it lives
+    int slot = -1;
+    void* stream;
+    BwdProfScope(int kind, void* st) : stream(st) {
+        if (!g_bprof.on || g_bprof.used >= g_bprof.cap) return;
+        slot = (int)g_bprof.used++;
+        g_bprof.kind[slot] = kind;
+        (void)hipEventRecord(g_bprof.ev[2 * slot], (hipStream_t)stream);
+    }
+    ~BwdProfScope() { if (slot >= 0) (void)hipEventRecord(g_bprof.ev[2 * slot + 1], (hipStream_t)stream); }
+};
+#define KPN_BPROF(kind) BwdProfScope bprof_scope_(kind, stream)
+#else
+#define KPN_BPROF(kind) ((void)0)
+#endif
 // d_x != nullptr: geometry rows only, upstream gradient given per (point, view).  Otherwise the whole-query reverse from
 // d_out (N,5): its geometry columns only (d_tex == nullptr) or all five incl. the colour head (d_tex != nullptr).
 int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp, int64_t N, const float* pts, const float* view,
@@ -1397,17 +1425,30 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
                        (uint8_t*)nullptr, list, count);
         }
         KPN_LAUNCH(k_bwd_rows, dim3(1), dim3(1), stream, vcount, V, rows_dev);
+#ifndef KPN_SIMT_EMU
+        if (g_bprof.on && g_bprof.passes < g_bprof.cap) {   // the pass's valid count, for the FLOP models of kpn_bwd_profile_collect
+            (void)hipMemcpyAsync(g_bprof.counts_host + 3 * g_bprof.passes, vcount, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+            g_bprof.counts_host[3 * g_bprof.passes + 1] = V;
+            g_bprof.counts_host[3 * g_bprof.passes + 2] = (int)(keep_mask & ((V >= 31) ? 0x7FFFFFFFu : ((1u << V) - 1u)));
+            ++g_bprof.passes;
+        }
+#endif
         if (full) {
-            if (!fwd_query_ws)
+            if (!fwd_query_ws) {
+                KPN_BPROF(BP_ROWS_FWD);
                 KPN_LAUNCH(k_geo_rows, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 1, xscr,
                            kpn_batch{0, 1 << 30});
+            }
             if (full == 2) {
+                KPN_BPROF(BP_COLOR_BWD);
                 if (V <= 3)
                     KPN_LAUNCH(k_color_bwd<3>, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
                                (const float*)xscr, d_out + c0 * 5, C);
                 else
                     KPN_LAUNCH(k_color_bwd<KPN_MAXV>, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 4,
                                (const float*)xscr, d_out + c0 * 5, C);
+            }
+            if (full == 2) {
                 wgrad(1, 0, C.Do2, 2, 1, C.Xo2, 8, 8, 8, P_O_2, 0, 0);
                 wgrad(1, 0, C.Do1, 8, 8, C.Xo1, 16, 16, 16, P_O_1, 0, 0);
                 wgrad(1, 0, C.Do0, 16, 16, C.Xo0, KPN_LD_XO0, KPN_LD_XO0, 37, P_O_0, 0, 0);
@@ -1420,21 +1461,30 @@ int run_backward(const kpn_scene_desc* d, const void* scene_ws, const float* wp,
                 wgrad(2, 0, C.Dre1, KPN_LD_XDIR, 35, C.Xe1, 16, 16, 16, P_RE_1, 0, 1);
                 wgrad(1, 0, C.Dre0, 16, 16, C.Xrd, 4, 4, 4, P_RE_0, 0, 0);
             }
-            KPN_LAUNCH(k_fuse_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 2,
-                       (const float*)xscr, mode, d_out + c0 * 5, F);
+            {
+                KPN_BPROF(BP_FUSE_BWD);
+                KPN_LAUNCH(k_fuse_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 2,
+                           (const float*)xscr, mode, d_out + c0 * 5, F);
+            }
             wgrad(2, 1, F.D20, 64, 64, F.Xp, 128, 128, 128, P_G2_0, 0, 0);
             wgrad(2, 1, F.D21, 64, 64, F.Xh0, 64, 64, 64, P_G2_1, 0, 0);
             wgrad(1, 1, F.D22, 2, 2, F.Xh1, 64, 64, 64, P_G2_2, 0, 0);
             if (full == 2) wgrad(1, 1, C.Dcmp, 24, 24, F.Xp, 128, 128, 128, P_CMP, 0, 0);
         }
-        KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 3,
-                   full ? (const float*)F.dxrows : d_x + c0 * V * 64, full ? 1 : 0, B);
+        {
+            KPN_BPROF(BP_ROWS_BWD);
+            KPN_LAUNCH(k_geo_rows_bwd, dim3(blocks), dim3(256), stream, sc, ps, wp, (const int*)list, vcount, count + 3,
+                       full ? (const float*)F.dxrows : d_x + c0 * V * 64, full ? 1 : 0, B);
+        }
         wgrad(4, 0, B.D0, 128, 128, B.X0, KPN_LDX0, 232, 232, P_G1_0, 1, 0);
         wgrad(4, 0, B.D1, 128, 128, B.X1, 128, 128, 128, P_G1_1, 0, 0);
         wgrad(4, 0, B.D2, 128, 120, B.X2, KPN_LDX2, 136, 136, P_G1_2, 0, 0);
         wgrad(2, 0, B.D3, 64, 64, B.X3, 128, 120, 120, P_G1_3, 0, 0);
         if (overflow) return fail(KPN_EWORKSPACE, "weight-gradient scratch too small (internal)");
-        run_jobs();
+        {
+            KPN_BPROF(BP_WGRAD);
+            run_jobs();
+        }
     }
     return check_launch("field backward");
 }
@@ -1531,8 +1581,11 @@ RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
     L.zc = take((size_t)C * a->n_coarse * 4);
     L.zf = take((size_t)C * Sfull * 4);
     L.rgba = take((size_t)C * Sfull * 5 * 4);
-    L.rgba_c = take((size_t)C * a->n_coarse * 5 * 4);                 // coarse values kept for the fine pass (eval)
-    L.rgba_n = take((size_t)C * (a->fine ? a->n_fine : 0) * 5 * 4);   // values at the new samples
+    // eval with coarse re-use (the default): the coarse values kept for the fine pass and the values at the new samples share the
+    // block a pass without re-use fills as a whole — never both in one call (round 6: 671 MB less per 512 x 512 plan)
+    L.rgba_c = L.rgba;
+    L.rgba_n = L.rgba + align_up((size_t)C * a->n_coarse * 5 * 4, 256);
+    o += 256;                                                          // (the alignment of rgba_n inside the block)
     L.zn = take((size_t)C * (a->fine ? a->n_fine : 0) * 4);
     L.src = take((size_t)C * Sfull * sizeof(int16_t));
     L.contrib = take((size_t)C * Sfull * 4);
@@ -1938,6 +1991,45 @@ extern "C" int kpn_ssim(const float* pred_chw, const float* gt_chw, int32_t H, i
     return check_launch("kpn_ssim");
 }
 
+extern "C" int kpn_bwd_profile_enable(int32_t on) {
+#ifndef KPN_SIMT_EMU
+    if (on && g_bprof.cap == 0) {
+        g_bprof.cap = 4096;
+        g_bprof.ev.resize(2 * g_bprof.cap);
+        g_bprof.kind.resize(g_bprof.cap);
+        for (auto& e : g_bprof.ev) if (hipEventCreate(&e) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventCreate failed");
+        if (hipHostMalloc((void**)&g_bprof.counts_host, g_bprof.cap * 3 * sizeof(int), 0) != hipSuccess) return fail(KPN_ELAUNCH, "hipHostMalloc failed");
+    }
+    g_bprof.on = on != 0;
+    g_bprof.used = 0;
+    g_bprof.passes = 0;
+#endif
+    return KPN_OK;
+}
+extern "C" int kpn_bwd_profile_collect(double* ms5, int64_t* launches5, int64_t* rows_host, int64_t* kept_rows_host, int64_t* points_host) {
+    KPN_REQUIRE(ms5 && launches5 && rows_host && kept_rows_host && points_host, "null pointer");
+    for (int i = 0; i < BP_KINDS; ++i) { ms5[i] = 0.0; launches5[i] = 0; }
+    *rows_host = *kept_rows_host = *points_host = 0;
+#ifndef KPN_SIMT_EMU
+    for (size_t i = 0; i < g_bprof.used; ++i) {
+        if (hipEventSynchronize(g_bprof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventSynchronize failed");
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, g_bprof.ev[2 * i], g_bprof.ev[2 * i + 1]) != hipSuccess) return fail(KPN_ELAUNCH, "hipEventElapsedTime failed");
+        ms5[g_bprof.kind[i]] += ms;
+        ++launches5[g_bprof.kind[i]];
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(KPN_ELAUNCH, "hipDeviceSynchronize failed");
+    for (size_t p_ = 0; p_ < g_bprof.passes; ++p_) {
+        const int64_t cnt = g_bprof.counts_host[3 * p_], V = g_bprof.counts_host[3 * p_ + 1];
+        *points_host += cnt;
+        *rows_host += cnt * V;
+        *kept_rows_host += cnt * __builtin_popcount((unsigned)g_bprof.counts_host[3 * p_ + 2]);
+    }
+    g_bprof.used = 0;
+    g_bprof.passes = 0;
+#endif
+    return KPN_OK;
+}
 extern "C" int kpn_profile_enable(int32_t on) {
 #ifndef KPN_SIMT_EMU
     if (on && g_prof.cap == 0) {

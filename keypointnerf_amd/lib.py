@@ -96,6 +96,8 @@ _SIGNATURES = {
     "kpn_get_density_first": (ctypes.c_int, []),
     "kpn_density_stats": (ctypes.c_int, [c_p, c_p, c_p, c_i32]),
     "kpn_density_first_passes": (ctypes.c_int, [c_p, c_p, c_i32]),
+    "kpn_bwd_profile_enable": (ctypes.c_int, [c_i32]),
+    "kpn_bwd_profile_collect": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "kpn_set_range_guard": (ctypes.c_int, [c_i32]),
     "kpn_get_range_guard": (ctypes.c_int, []),
     "kpn_range_guard_count": (ctypes.c_int, [c_p, c_p]),

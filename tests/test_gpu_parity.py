@@ -291,6 +291,31 @@ def test_density_first_passes_equal_the_fused_per_point_kernel(ops):
         L.check(L.kpn_set_row_scratch_cap_bytes(old))
 
 
+def test_unrolled_v3_per_point_kernels_equal_the_generic_ones(ops, monkeypatch):
+    """k_fuse_color_h3 / k_colour_h3 (V = 3, every view kept: what ships) against k_fuse_color_h / k_colour_h forced by
+    KPN_NO_FUSE_H3=1 on the same V = 3 frame: include/kpnerf.h claims "the same arithmetic" — asserted here bit for bit (an advisor
+    finding of round 5: -ffp-contract could fuse differently in the unrolled body), fused and density-first."""
+    from keypointnerf_amd import lib as kl
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict
+    L = kl.get_library()
+    scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(64, 64), mask="ellipsoid", seed=9, tar_focal_at_512=800.0)
+    s, ps = _prep(ops, scene)
+    w = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=-10.0))
+    try:
+        for df in (0, 1):
+            L.check(L.kpn_set_density_first(df))
+            outs = []
+            for no_h3 in ("0", "1"):
+                monkeypatch.setenv("KPN_NO_FUSE_H3", no_h3)
+                outs.append({k: v.clone() for k, v in ops.render_rays(ps, w, s["cam_tar"], s["bounds"], grid=(0, 0, 1, 64, 64), n_coarse=64, n_fine=64).items()})
+            for k in outs[0]:
+                assert torch.equal(outs[0][k], outs[1][k]), (df, k)
+            assert float(outs[0]["alpha_fine"].mean()) > 0.02
+    finally:
+        L.check(L.kpn_set_density_first(2))
+        monkeypatch.setenv("KPN_NO_FUSE_H3", "0")
+
+
 def test_capped_row_scratch_batches_are_bit_identical(ops):
     """The row scratch between k_geo_rows and k_fuse_color is capped and reused by batches of a pass: a frame rendered with
     a cap that forces many batches (and surplus launches) equals the single-batch frame bit for bit."""

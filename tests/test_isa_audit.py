@@ -22,7 +22,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def assembly(tmp_path_factory):
     from keypointnerf_amd import build as kb
     # the assembly the library's own build kept (same compile as the shipped objects); compiled here only if that is stale
-    if not kb.needs_build():
+    if not kb.needs_build() and all(os.path.exists(f) for f in kb.assembly_files()):
         return kb.assembly_files()
     out = tmp_path_factory.mktemp("isa")
     procs = []
@@ -62,15 +62,19 @@ def test_no_unpadded_mfma_pair_around_asm_statements(assembly):
 def test_per_point_kernel_has_no_valu_instruction_in_asm(assembly):
     import isa_asm_hazards as ia
     path = [p for p in assembly if os.path.basename(p).startswith("kpn_api.")][0]
-    k = [k for k in kernels_of(path) if "k_fuse_color_h" in k][0]
-    prog = ia.parse(path, k)
-    inside = [i["text"] for i in prog if i["kind"] == "ins" and i["asm"] >= 0 and i["name"].startswith("v_")]
-    assert not inside, inside[:4]
-    # and the operand splits are the four-instruction form per pair of values (kpn_common.h kpn_split_f16x8)
-    names = [i["name"] for i in prog if i["kind"] == "ins"]
-    n_mix, n_cvt = sum(n == "v_fma_mix_f32" for n in names), sum(n == "v_cvt_pk_f16_f32" for n in names)
-    assert n_mix >= 300 and abs(n_mix - n_cvt) <= 8, (n_mix, n_cvt)
-    assert not any(n.startswith("v_cvt_f32_f16") for n in names), "the fp16 halves are read in place by v_fma_mix_f32"
+    # every instantiation of the two-fp16-piece per-point body: the fused kernel (any V / V = 3 unrolled: the one that ships) and
+    # the density-first passes (round 5's test looked at whichever sorted first)
+    ks = [k for k in kernels_of(path) if any(n in k for n in ("k_fuse_color_h", "k_density_h", "k_colour_h"))]
+    assert len(ks) == 5, ks
+    for k in ks:
+        prog = ia.parse(path, k)
+        inside = [i["text"] for i in prog if i["kind"] == "ins" and i["asm"] >= 0 and i["name"].startswith("v_")]
+        assert not inside, (k, inside[:4])
+        # and the operand splits are the four-instruction form per pair of values (kpn_common.h kpn_split_f16x8)
+        names = [i["name"] for i in prog if i["kind"] == "ins"]
+        n_mix, n_cvt = sum(n == "v_fma_mix_f32" for n in names), sum(n == "v_cvt_pk_f16_f32" for n in names)
+        assert n_mix >= (100 if "k_density_h" in k else 200) and abs(n_mix - n_cvt) <= 8, (k, n_mix, n_cvt)
+        assert not any(n.startswith("v_cvt_f32_f16") for n in names), "the fp16 halves are read in place by v_fma_mix_f32"
 
 
 def test_the_audit_finds_the_round4_miscompute():
