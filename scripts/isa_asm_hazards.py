@@ -57,7 +57,12 @@ def defs_uses(name, body):
 
 def parse(path, sym):
     s = open(path).read()
-    m = re.search(r'^(' + re.escape(sym) + r'[^\n:]*):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M)
+    # the whole function, up to its .Lfunc_end label (round 6: a kernel whose early-exit block is laid out first has an s_endpgm long
+    # before its body — stopping at the first one audited 53 instructions of the per-point kernels); hand-written test streams
+    # without that label end at their last s_endpgm
+    m = re.search(r'^(' + re.escape(sym) + r'[^\n:]*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:', s, re.S | re.M)
+    if m is None:
+        m = re.search(r'^(' + re.escape(sym) + r'[^\n:]*):[^\n]*\n(.*)s_endpgm', s, re.S | re.M)
     if m is None:
         raise SystemExit(f"kernel {sym} not found in {path}")
     out = []
