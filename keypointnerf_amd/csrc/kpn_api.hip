@@ -1588,7 +1588,7 @@ RenderLayout render_layout(const kpn_scene_desc* d, const kpn_render_args* a) {
     o += 256;                                                          // (the alignment of rgba_n inside the block)
     L.zn = take((size_t)C * (a->fine ? a->n_fine : 0) * 4);
     L.src = take((size_t)C * Sfull * sizeof(int16_t));
-    L.contrib = take((size_t)C * Sfull * 4);
+    L.contrib = take((size_t)C * a->n_coarse * 4);                    // the coarse compositor's weights (the fine one writes none)
     L.color = take((size_t)C * 3 * 4);
     L.depth = take((size_t)C * 4);
     L.alpha = take((size_t)C * 4);
