@@ -249,6 +249,8 @@ typedef struct kpn_render_stages {
     float* rgba_coarse;    /* (R, n_coarse, 5) */
     float* z_fine;         /* (R, n_coarse + n_fine) */
     float* rgba_fine;      /* (R, n_coarse + n_fine, 5) */
+    float* dirs;           /* (R, 3) the rays' unit directions and */
+    float* cam_pos;        /* (3) their common origin, as the call's ray set-up formed them (src/model.py:1019-1043) */
 } kpn_render_stages;
 typedef struct kpn_render_args {
     const float* K;          /* cam_tar["K"]  (4,4) */

@@ -1686,6 +1686,8 @@ static int render_impl(const kpn_scene_desc* d, const void* scene_ws, const floa
             memcpy(dst, src_, floats * sizeof(float));
 #endif
         };
+        if (st && st->dirs) copy_out(st->dirs + r0 * 3, dirs, (size_t)n * 3);
+        if (st && st->cam_pos && r0 == 0) copy_out(st->cam_pos, F(L.cam_pos), 3);
         if (st && st->z_coarse) copy_out(st->z_coarse + r0 * Sc, F(L.zc), (size_t)n * Sc);
         if (st && st->rgba_coarse) copy_out(st->rgba_coarse + r0 * Sc * 5, rgba_coarse, (size_t)n * Sc * 5);
         if (a->tex_fg) KPN_LAUNCH(k_store_planar, grid1d(n * 3, 256), dim3(256), stream, r0, n, R, 3, (const float*)F(L.color), a->tex_fg);

@@ -36,7 +36,7 @@ class SceneDesc(ctypes.Structure):
 
 class RenderStages(ctypes.Structure):
     """struct kpn_render_stages"""
-    _fields_ = [(n, c_p) for n in ("z_coarse", "rgba_coarse", "z_fine", "rgba_fine")]
+    _fields_ = [(n, c_p) for n in ("z_coarse", "rgba_coarse", "z_fine", "rgba_fine", "dirs", "cam_pos")]
 
 
 class RenderArgs(ctypes.Structure):

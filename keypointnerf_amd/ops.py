@@ -365,7 +365,7 @@ def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=
     """Eval-mode batch_render_pifu_nerf for the pixel grid (x0, y0, step, nx, ny) of the target camera
     cam_tar {K (1,4,4), RT (1,4,4), znear, zfar}.  Returns the reference's out dict (B=1):
     tex_fg (1,3,ny,nx), depth/alpha (1,ny,nx) [, tex_fg_fine, depth_fine, alpha_fine, sdf].
-    stages=True: -> (out, {z_coarse (R,Sc), rgba_coarse (R,Sc,5) [, z_fine (R,Sc+Sf), rgba_fine (R,Sc+Sf,5)]}), the per-sample depths
+    stages=True: -> (out, {dirs (R,3), cam_pos (3), z_coarse (R,Sc), rgba_coarse (R,Sc,5) [, z_fine (R,Sc+Sf), rgba_fine (R,Sc+Sf,5)]}), the rays, the per-sample depths
     and eval_func'ed field values of the call in ray order (kpn_render_stages: the conditional parity check of tests/parity_gate.py)."""
     L = kl.get_library()
     if plan is None:
@@ -377,7 +377,8 @@ def render_rays(scene, weights, cam_tar, bounds, grid=None, n_coarse=64, n_fine=
     st = None
     if stages:
         R, Sc, Sf = plan.n_rays(), int(a.n_coarse), int(a.n_fine) if plan.fine else 0
-        st = {"z_coarse": torch.empty(R, Sc, dtype=_f32, device=plan.ws.device), "rgba_coarse": torch.empty(R, Sc, 5, dtype=_f32, device=plan.ws.device)}
+        st = {"z_coarse": torch.empty(R, Sc, dtype=_f32, device=plan.ws.device), "rgba_coarse": torch.empty(R, Sc, 5, dtype=_f32, device=plan.ws.device),
+              "dirs": torch.empty(R, 3, dtype=_f32, device=plan.ws.device), "cam_pos": torch.empty(3, dtype=_f32, device=plan.ws.device)}
         if plan.fine:
             st.update({"z_fine": torch.empty(R, Sc + Sf, dtype=_f32, device=plan.ws.device),
                        "rgba_fine": torch.empty(R, Sc + Sf, 5, dtype=_f32, device=plan.ws.device)})

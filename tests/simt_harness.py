@@ -124,7 +124,8 @@ def render(lib, hs, packed, cam_tar, bounds, grid, Sc, Sf, fine=True, chunk_rays
         setattr(a, k, v.ctypes.data)
     st = None
     if stages:
-        st = {"z_coarse": np.full((R, Sc), np.nan, np.float32), "rgba_coarse": np.full((R, Sc, 5), np.nan, np.float32)}
+        st = {"z_coarse": np.full((R, Sc), np.nan, np.float32), "rgba_coarse": np.full((R, Sc, 5), np.nan, np.float32),
+              "dirs": np.full((R, 3), np.nan, np.float32), "cam_pos": np.full(3, np.nan, np.float32)}
         if fine:
             st.update({"z_fine": np.full((R, Sc + Sf), np.nan, np.float32), "rgba_fine": np.full((R, Sc + Sf, 5), np.nan, np.float32)})
         cst = kl.RenderStages()

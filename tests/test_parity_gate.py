@@ -143,4 +143,4 @@ def test_gate_constants_are_frozen():
     assert (parity_gate.RGBA_TOL, parity_gate.ENVELOPE_TRIALS) == (1e-4, 64)
     assert {k: sig.parameters[k].default for k in ("tol", "cap", "cap_envelopes", "max_widened_fraction")} == \
         {"tol": 1e-4, "cap": 0.1, "cap_envelopes": 20.0, "max_widened_fraction": 2e-3}
-    assert (parity_gate.FIELD_TOL, parity_gate.COMPOSITE_TOL, parity_gate.DEPTH_TOL) == (2e-5, 5e-6, 5e-6)
+    assert (parity_gate.FIELD_TOL, parity_gate.COMPOSITE_TOL, parity_gate.DEPTH_TOL, parity_gate.HEAD_TERMS, parity_gate.RAY_TOL) == (2e-5, 5e-6, 5e-6, 4.0, 1e-6)
