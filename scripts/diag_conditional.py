@@ -61,3 +61,20 @@ for row in rep["widened"]:
         print(f"  {name}: worst sample {i} of {z.shape[1]} z={z[0, i]:.6f} valid={bool(valid[i])}\n    kernel {rk[0, i]}\n    oracle {o[i]}\n    |diff| {d[i]}\n    spread {spread}")
         if i > 0:
             print(f"    neighbours: kernel sigma {rk[0, max(0, i - 2):i + 3, 0]}, oracle sigma {o[max(0, i - 2):i + 3, 0]}")
+
+    if fine:   # the resampling stage: the kernel's new depths against the oracle's from the kernel's coarse weights
+        zc, rc = np.asarray(st["z_coarse"], np.float32).reshape(1, -1), np.asarray(st["rgba_coarse"], np.float32).reshape(1, -1, 5)
+        _, _, _, contrib, _ = oracle.rgba2out(rc, zc)
+        zmid = 0.5 * (zc[:, 1:] + zc[:, :-1])
+        cin = np.ascontiguousarray(contrib[:, 1:Sc - 1])
+        zn = oracle.importance_sample(cin, zmid, Sf)
+        zf_o = np.sort(np.concatenate([zc, zn], -1), -1)[0]
+        zf_k = np.asarray(st["z_fine"], np.float32).reshape(-1)
+        w = cin[0].astype(np.float64) + 1e-5
+        cdf = np.concatenate([[0.0], np.cumsum(w / w.sum())])
+        u = np.linspace(0.0, 1.0, Sf)
+        bad = np.nonzero(np.abs(zf_k - zf_o) > 5e-6)[0]
+        print("  resample: differing merged samples", bad, "kernel", zf_k[bad], "oracle", zf_o[bad])
+        print("    bin widths (cdf):", np.diff(cdf)[:8], "... min", np.diff(cdf).min(), "sum of weights", w.sum())
+        j = np.searchsorted(cdf, u, side="right")
+        print("    distance of every u to its nearest cdf entry:", np.abs(u[:, None] - cdf[None]).min(-1).min(), "; den of the bins used:", (cdf[np.minimum(j, len(cdf) - 1)] - cdf[np.maximum(j - 1, 0)]))
