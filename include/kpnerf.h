@@ -189,7 +189,7 @@ int kpn_get_fuse_mode(void);
  * for the listed points only).  Per point the arithmetic is the fused kernel's: frames are bit-identical either way.
  *   mode 0: never (the fused per-point kernel, whose short path needs a whole 32-point tile dead);
  *   mode 1: always;
- *   mode 2: auto, the default: per render pass, from the dead fraction the earlier passes measured on the device (>= 25 %: density
+ *   mode 2: auto, the default: per render pass, from the dead fraction the earlier passes measured on the device (>= 20 %: density
  *           first; the pair is 0.16 ms per launch slower than the fused kernel when every point is live and 3 % of a frame faster
  *           when 82 % are dead; no host synchronisation: DESIGN.md).
  * kpn_query, the train branch and the fp32-range kernels behind the range guard always use the fused kernel.  Process-wide;

@@ -444,7 +444,7 @@ static unsigned long long kpn_density_counts[2];
 // column), so the frame is bit-identical with density first on or off, whichever points end up sharing a tile.
 // Measured on the MI355X (profiles/r06_a_density_first.txt): pass A is HBM-bound (it reads the 512-B pooled vector of every point:
 // 0.53 ms per launch), pass B costs what the fused kernel's colour part costs (1.13 ms with every point live), so on a density that
-// is live everywhere the pair is 0.16 ms per launch SLOWER than the fused kernel (1.50 ms), at 25 % dead points it is even, at 82 %
+// is live everywhere the pair is 0.16 ms per launch SLOWER than the fused kernel (1.50 ms), at 25 % dead points it is 1 % of a frame ahead, at 82 %
 // it wins 3 % of the frame on top of the fused kernel's own short path.  Which of the two runs is therefore decided per render call
 // from the dead fraction the previous calls measured (kpn_api.hip density_first_now).  A third form — one kernel, the colour part
 // run on a per-wave LDS queue of live slots as soon as it holds 32 — was built and measured as well: 1.59 ms all-live (30 spilled

@@ -847,7 +847,7 @@ int density_first() {
     }
     return g_density_first;
 }
-const float kDensityFirstDeadFraction = 0.25f;   // AUTO: density first when at least this fraction of the hull's points was dead
+const float kDensityFirstDeadFraction = 0.20f;   // AUTO: density first when at least this fraction of the hull's points was dead
 struct DensityHint {
     unsigned long long* pinned = nullptr;   // [listed, live] as last copied from the device
     unsigned long long seen[2] = {0, 0};    // the snapshot the current decision was taken from

@@ -38,7 +38,7 @@ cp profiles/geo_rows_traffic.json gpurun_out/geo_rows_traffic.json
 (timeout 600 python scripts/soak_mode2.py --mode 3 --repeats 3000 --mask ellipsoid) 2>/dev/null | tail -1 | tee -a gpurun_out/soak_$TAG.jsonl | cut -c1-300
 (timeout 1200 python scripts/fuzz_parity.py 200) > gpurun_out/fuzz_$TAG.log 2>&1; echo "fuzz rc=$?"; tail -1 gpurun_out/fuzz_$TAG.log | cut -c1-500; cp gpurun_out/fuzz_parity.json gpurun_out/fuzz_parity_200_scenes_default_$TAG.json
 (timeout 1800 python scripts/fuzz_parity.py 400 7) > gpurun_out/fuzz400_$TAG.log 2>&1; echo "fuzz400 rc=$?"; tail -1 gpurun_out/fuzz400_$TAG.log | cut -c1-500; cp gpurun_out/fuzz_parity.json gpurun_out/fuzz_400scenes_seed7_$TAG.json
-(timeout 600 python scripts/rccl_one_rank.py 5) 2>/dev/null | tail -1 | tee gpurun_out/rccl_one_rank_$TAG.json | cut -c1-300
+(timeout 600 python scripts/rccl_one_rank.py 5) 2>/dev/null | grep '^{' | tail -1 | tee gpurun_out/rccl_one_rank_$TAG.json | cut -c1-300
 (timeout 900 python scripts/range_gate.py) > gpurun_out/range_gate_$TAG.log 2>&1; echo "range rc=$?"; tail -2 gpurun_out/range_gate_$TAG.log | cut -c1-300
 (timeout 900 python scripts/render_orbit.py --frames 200; timeout 900 python scripts/render_orbit.py --frames 200 --with-encoders) > gpurun_out/orbit_$TAG.txt 2>&1; grep -v amdgpu gpurun_out/orbit_$TAG.txt | tail -2
 (timeout 600 python scripts/bench_dropin_train.py) 2>&1 | tail -1 | tee gpurun_out/dropin_train_$TAG.txt
