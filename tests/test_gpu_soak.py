@@ -45,3 +45,31 @@ def test_field_kernels_are_deterministic_and_fp32_class(mask):
         assert differing == 0, f"{differing} point results differed between runs"
     finally:
         ops.set_geo_rows_mode(rows_default); ops.set_fuse_mode(fuse_default)
+
+
+@pytest.mark.parametrize("bias", [-20.0, -30.0])
+def test_density_first_frames_are_deterministic(bias):
+    """Round 6: the density-first passes build their live list with atomics (its order differs from run to run) and pass B reads the
+    scratch through it: 150 renders of a 128 x 128 frame whose hull is 25 % / 82 % empty, density first forced on, every output of
+    every render bit-identical to the first — and to the fused kernel's frame."""
+    from keypointnerf_amd import lib as kl
+    from keypointnerf_amd import ops
+    from keypointnerf_amd.synthetic import make_scene, random_hotpath_state_dict, to_device
+    L = kl.get_library()
+    dev = torch.device("cuda", 0)
+    sc = to_device(make_scene(n_views=3, src_hw=(256, 256), tar_hw=(128, 128), mask="ellipsoid", seed=1, tar_focal_at_512=800.0), dev)
+    w = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=bias), device=dev)
+    ps = ops.PreparedScene(sc["img"], sc["cam"], sc["feat_geo"], sc["feat_tex"], sc["sp_data"], sc["src_foreground_mask"])
+    plan = ops.RenderPlan(ps, (0, 0, 1, 128, 128), 64, 64, fine=True)
+    try:
+        L.check(L.kpn_set_density_first(0))
+        fused = {k: v.clone() for k, v in ops.render_rays(ps, w, sc["cam_tar"], sc["bounds"], plan=plan).items()}
+        L.check(L.kpn_set_density_first(1))
+        differing = 0
+        for _ in range(150):
+            out = ops.render_rays(ps, w, sc["cam_tar"], sc["bounds"], plan=plan)
+            differing += sum(int((out[k] != fused[k]).sum()) for k in fused)
+        assert differing == 0, f"{differing} output values differed"
+        assert float(fused["alpha_fine"].max()) > 0.05
+    finally:
+        L.check(L.kpn_set_density_first(2))
