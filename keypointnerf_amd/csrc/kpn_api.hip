@@ -851,6 +851,7 @@ const float kDensityFirstDeadFraction = 0.20f;   // AUTO: density first when at 
 struct DensityHint {
     unsigned long long* pinned = nullptr;   // [listed, live] as last copied from the device
     unsigned long long seen[2] = {0, 0};    // the snapshot the current decision was taken from
+    double avg[2] = {0.0, 0.0};             // moving sums of listed / live points over the looks
     bool split = false;                     // nothing measured yet: the fused kernel
 };
 DensityHint g_density_hint[16];
@@ -888,7 +889,11 @@ bool density_first_now() {
     const bool was_reset = now[0] < hnt->seen[0];
     const unsigned long long d0 = was_reset ? now[0] : now[0] - hnt->seen[0], d1 = was_reset ? now[1] : now[1] - hnt->seen[1];
     if (d0 > 0 && d1 <= d0) {
-        hnt->split = (float)(d0 - d1) >= kDensityFirstDeadFraction * (float)d0;
+        // a look may cover one pass only (a coarse pass's hull is emptier than a fine pass's): the decision follows a moving
+        // average over the last few looks, not the last one
+        hnt->avg[0] = 0.5 * hnt->avg[0] + (double)d0;
+        hnt->avg[1] = 0.5 * hnt->avg[1] + (double)d1;
+        hnt->split = (hnt->avg[0] - hnt->avg[1]) >= (double)kDensityFirstDeadFraction * hnt->avg[0];
         hnt->seen[0] = now[0]; hnt->seen[1] = now[1];
     }
     return hnt->split;

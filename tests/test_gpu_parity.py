@@ -276,12 +276,12 @@ def test_density_first_passes_equal_the_fused_per_point_kernel(ops):
         for bias, expect_split in ((-30.0, True), (0.0, False), (-30.0, True)):
             w = ops.PackedWeights(random_hotpath_state_dict(seed=3, density_bias=bias))
             frames = []
-            for i in range(4):
+            for i in range(7):
                 frames.append({k: v.clone() for k, v in ops.render_rays(ps, w, s["cam_tar"], s["bounds"], plan=plan).items()})
                 torch.cuda.synchronize()           # (lets the 16-byte statistics copy behind the pass land before the next call looks)
-                if i == 2:
+                if i == 5:
                     passes()
-            df, fused = passes()                   # the passes of the fourth frame
+            df, fused = passes()                   # the passes of the seventh frame (the decision follows a moving average of the looks)
             assert (df, fused) == ((2, 0) if expect_split else (0, 2)), (bias, df, fused)
             for f in frames[1:]:
                 for k in f:
