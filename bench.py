@@ -90,6 +90,9 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank renders its own frame of the orbit per step (frames sharded, the production job); "
                          "strong = ONE frame per step, its rows dealt round-robin to the N ranks (SURVEY 8(e))")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: run the N > 1 code path anyway (process group of one rank, "
+                    "FrameGatherer, barriers, the MAX all-reduce of the time) — what one GPU allows of the RCCL branch; "
+                    "needs MASTER_ADDR / MASTER_PORT (RANK / WORLD_SIZE default to 0 / 1)")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: gather each frame before the next one starts (default: the "
                     "gather of frame i overlaps the rendering of frame i + 1)")
     ap.add_argument("--no-configs4", action="store_true", help="skip secondary.configs4_full (4096^2 rays, 10 views, 128 flat samples: ~15 s + set-up)")
@@ -384,8 +387,12 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to report a "
                  f"number for a different GPU count")
-    if world > 1:
+    multi = world > 1 or args.force_dist          # the distributed code path (world 1 with --force-dist: a process group of one rank)
+    if multi:
         import torch.distributed as dist
+        if args.force_dist and world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             if torch.cuda.device_count() < world:
                 sys.exit(f"bench.py: --gpus {world} needs {world} visible GPUs (found {torch.cuda.device_count()}); "
@@ -430,15 +437,15 @@ def main():
         sys.exit("bench.py: --scaling strong needs the frame height to be a multiple of the rank count (equal bands gather into one frame)")
     plan = ops.RenderPlan(ps, (0, y0, 1, res, nrows, step_y), args.samples, args.samples, fine=fine, chunk_rays=args.chunk_rays)
     gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    gatherer = FrameGatherer(world, rank, (3, nrows, res), device=gdev) if world > 1 else None
+    gatherer = FrameGatherer(world, rank, (3, nrows, res), device=gdev) if multi else None
 
     def step(i):
         # weak: frame i of the job, rank r renders target camera (i*world + r) of the orbit; strong: camera i, band r of its rows
-        cam_tar = orbit_target_camera(scene["cam_tar"], i if strong else i * world + rank) if world > 1 else scene["cam_tar"]
+        cam_tar = orbit_target_camera(scene["cam_tar"], i if strong else i * world + rank) if multi else scene["cam_tar"]
         L.check(L.kpn_scene_prepare(ctypes.byref(ps.desc), ctypes.c_void_p(ps.ws.data_ptr()),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         out = ops.render_rays(ps, w, cam_tar, scene["bounds"], plan=plan)
-        if world > 1:  # the job's only exchange: finished RGB frames (3 MB each) / bands gathered to rank 0, asynchronously
+        if multi:  # the job's only exchange: finished RGB frames (3 MB each) / bands gathered to rank 0, asynchronously
             k = gatherer.submit(out["tex_fg_fine" if fine else "tex_fg"][0])
             if args.sync_gather and gatherer.work[k] is not None:
                 gatherer.work[k].wait()
@@ -453,21 +460,21 @@ def main():
     dpasses = [ctypes.c_int64(0), ctypes.c_int64(0)]   # timed render passes that ran density first / on the fused per-point kernel
     L.check(L.kpn_density_first_passes(ctypes.byref(dpasses[0]), ctypes.byref(dpasses[1]), 1))
     L.check(L.kpn_density_stats(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
-    if world > 1:
+    if multi:
         gatherer.finish()                     # the last frames' gathers are inside the timed region
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # the frame of the last timed step, for the comparison with the oracle further down (world 1: rank 0's own camera)
-    frame_np = {k: v[0].cpu().numpy() for k, v in out.items() if k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")} if (world == 1 and rank == 0) else None
+    frame_np = {k: v[0].cpu().numpy() for k, v in out.items() if k in ("tex_fg", "alpha", "tex_fg_fine", "alpha_fine")} if (world == 1 and rank == 0 and not multi) else None
     gather_ms = None
-    if world > 1:                             # the exchange alone (after the timed region): one synchronous round, averaged
+    if multi:                             # the exchange alone (after the timed region): one synchronous round, averaged
         img = out["tex_fg_fine" if fine else "tex_fg"][0]
         torch.cuda.synchronize(); dist.barrier()
         tg = time.perf_counter()
@@ -487,14 +494,14 @@ def main():
     L.check(L.kpn_density_stats(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(dens[0]), ctypes.byref(dens[1]), 1))
     L.check(L.kpn_density_first_passes(ctypes.byref(dpasses[0]), ctypes.byref(dpasses[1]), 1))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
     rays_per_step = res * res
     value = (1 if strong else world) * rays_per_step * args.steps / dt
     rccl = None
-    if world > 1 and args.dist_backend == "nccl":
+    if multi and args.dist_backend == "nccl":
         try:
             rccl = "RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception as e:  # noqa: BLE001
@@ -550,12 +557,12 @@ def main():
                        # whole run stayed on the default kernels
                        "range_guard_batches_redone": ops.range_guard_count(), "range_guard": bool(L.kpn_get_range_guard()),
                        "mean_alpha_fine": alpha_mean, "parallelism": (f"one frame, rows dealt round-robin to {world} ranks (row y -> rank y mod {world}), de-interleaved on rank 0" if strong else f"frames sharded over {world} rank(s)") + ", one process per GPU"
-                                      + (f", {args.dist_backend} gather of finished frames to rank 0" if world > 1 else ""),
-                       "dist_world_size": (dist.get_world_size() if world > 1 else 1),
-                       "dist_backend": (args.dist_backend if world > 1 else None),
-                       "rccl_ranks": (dist.get_world_size() if (world > 1 and args.dist_backend == "nccl") else None),
+                                      + (f", {args.dist_backend} gather of finished frames to rank 0" if multi else ""),
+                       "dist_world_size": (dist.get_world_size() if multi else 1),
+                       "dist_backend": (args.dist_backend if multi else None),
+                       "rccl_ranks": (dist.get_world_size() if (multi and args.dist_backend == "nccl") else None),
                        "dist_library": rccl,
-                       "gather": (None if world == 1 else ("synchronous per frame" if (args.sync_gather or not gatherer.asynchronous) else
+                       "gather": (None if not multi else ("synchronous per frame" if (args.sync_gather or not gatherer.asynchronous) else
                                   "asynchronous: frame i travels while frame i+1 renders (two staging buffers)")),
                        "gather_ms_per_round_alone": gather_ms},
             "roofline": {"kernel": ROWS_KERNEL[args.geo_rows_mode], "bound": "mfma", "achieved": achieved,
@@ -681,7 +688,7 @@ def main():
                                                   "recorded_by": "scripts/bench_torch_eager.py (profiles/r04_eager_pytorch_on_mi355x.json)",
                                                   "what": e["what"]}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

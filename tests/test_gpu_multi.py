@@ -32,6 +32,22 @@ def test_rccl_branch_with_one_rank_on_one_gpu():
     assert d["dist_library"].startswith("RCCL ")
 
 
+def test_bench_distributed_path_over_rccl_with_one_rank():
+    """`bench.py --gpus 1 --force-dist`: the code path the driver's N > 1 runs take — init_process_group("nccl", device_id=...), the
+    FrameGatherer on device buffers, barriers, the MAX all-reduce of the time on a device tensor, the synchronous gather round — with a
+    process group of ONE rank on cuda:0: one JSON line, rccl_ranks 1, the RCCL version in it."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--res", "128", "--samples", "32",
+                        "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["config"]["dist_backend"] == "nccl" and d["value"] > 0
+    assert str(d["config"]["dist_library"]).startswith("RCCL ") and d["config"]["gather"].startswith("asynchronous")
+
+
 # ---- the N > 1 flow on ONE GPU (the box the driver's GPU tier runs on): two gloo ranks, both on cuda:0, the DEVICE kernels ----
 def _free_port():
     import socket
