@@ -28,6 +28,8 @@
 extern "C" {
 #endif
 
+/* 3 (round 6): kpn_render_args gained `stages` at its end (callers built against 2 must be rebuilt: the struct grew);
+ * new entry points: kpn_set_density_first / kpn_get_density_first / kpn_density_stats / kpn_density_first_passes, kpn_bwd_profile_* */
 #define KPN_ABI_VERSION 3
 #define KPN_N_KPT 24      /* configs/zju.json:44 sp_args.n_kpt */
 #define KPN_MAX_VIEWS 16
