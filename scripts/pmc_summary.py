@@ -10,7 +10,7 @@ from collections import defaultdict
 
 def main():
     d = sys.argv[1]
-    filt = sys.argv[2:] or ["k_geo_rows", "k_fuse_color", "k_mask_compact"]
+    filt = sys.argv[2:] or ["k_geo_rows", "k_fuse_color", "k_mask_compact", "k_density_h", "k_colour_h", "k_row_records"]
     agg = defaultdict(lambda: defaultdict(float))
     ndisp = defaultdict(set)
     for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
