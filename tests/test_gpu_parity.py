@@ -701,19 +701,24 @@ def test_train_render_backward(ops, golden_weights, case):
         assert_train_grads_vs_golden([x.cpu().numpy() for x in got2], g, sd, 1e-4)
 
 
-@pytest.mark.parametrize("patch", [32, 64])
-def test_train_render_backward_at_configs3_size(ops, golden_weights, patch):
+@pytest.mark.parametrize("patch,trained", [(32, False), (64, False), (32, True)])
+def test_train_render_backward_at_configs3_size(ops, golden_weights, patch, trained):
     """patch = 32: BASELINE configs[3]'s 1024 rays; patch = 64: the reference's shipped 64 x 64 patch (configs/zju.json:36-37), the
     4096-ray iteration of the driver line's secondary.training_step_4096.
     Gradient VALUES at the size configs[3] trains at — 1024 rays x (64 coarse + 128 fine-pass) evaluations, V = 3, view dropout
     in the fine query, density noise — against the oracle's reverse pass (kpo_query_backward / kpo_rgba2out_backward, pinned to
     the reference's own loss.backward() by goldens h / j / k / l at 64 rays): kpn_render_rays_train_backward_kept from the kept
     forward state (the bf16 x 3 chains of k_geo_rows_bwd and k_weight_grad at two waves per SIMD, 590 k rows per call) and the
-    classic entry point.  Per layer 1e-4 of the layer's largest gradient; the three feature-map gradients likewise."""
+    classic entry point.  Per layer 1e-4 of the layer's largest gradient; the three feature-map gradients likewise.
+    trained (round 6): the same with the hot-path weights the reference itself trained (tests/golden_io.py TRAINED_WEIGHTS)."""
     from oracle import oracle
     from keypointnerf_amd.synthetic import make_scene
     from tests.test_oracle_vs_golden import assert_flat_grads_close
     sd, w = golden_weights
+    if trained:
+        from tests.golden_io import TRAINED_WEIGHTS
+        sd = load_weights(TRAINED_WEIGHTS)
+        w = ops.PackedWeights(sd)
     scene = make_scene(n_views=3, src_hw=(128, 128), tar_hw=(64, 64), mask="ellipsoid", seed=31, tar_focal_at_512=800.0)
     s, ps = _prep(ops, scene)
     rng = np.random.default_rng(12)
